@@ -1,0 +1,142 @@
+/* petal_hip.h -- C ABI of the MI355X-native (gfx950) implementation of petal-decomposition's
+ * dense hot path: Pca / RandomizedPca / FastIca  fit / transform / inverse_transform.
+ *
+ * The reference (petabi/petal-decomposition v0.9.0, Rust) has no FFI for this path: its boundary is
+ * the crate's public generic API (src/lib.rs:17-18).  Every entry point below names the reference
+ * interface it replaces (file:line relative to the crate root); a Rust facade binds them 1:1
+ * (INTEGRATION.md shows the `extern "C"` block and the ndarray glue).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; `petal_matrix` is ndarray's (ptr, shape, strides) triple
+ *    (strides in ELEMENTS, like ndarray) plus a dtype tag and the memory space of `data`.
+ *  - small results (components, means, singular values, ...) are written to HOST memory owned by the
+ *    caller, in the dtype of the input; large results (n x k) go to a caller-described petal_matrix.
+ *  - the library never frees or mutates caller memory that is passed as `const`.
+ *  - every call is synchronous: it returns after the device work has completed.
+ *  - return value: PETAL_OK or one of the error codes; petal_last_error() holds the reference's
+ *    message text (e.g. "every dimension should be at least 3", src/pca.rs:200-203).
+ *  - a ctx is used by one thread at a time; several ctxs may coexist (one per GPU / process).
+ *  - there is NO CPU fallback: without a usable gfx950 device petal_ctx_create fails.
+ */
+#ifndef PETAL_HIP_H
+#define PETAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct petal_ctx petal_ctx;
+
+/* DecompositionError (src/lib.rs:22-28) + a device/collective failure class. */
+enum { PETAL_OK = 0, PETAL_INVALID_INPUT = 1, PETAL_LINALG_ERROR = 2, PETAL_DEVICE_ERROR = 3 };
+enum { PETAL_F32 = 0, PETAL_F64 = 1 };
+enum { PETAL_HOST = 0, PETAL_DEVICE = 1 };
+enum { PETAL_SUM = 0, PETAL_MAX = 1, PETAL_MIN = 2 };
+/* FastICA semantics: TEXTBOOK = (W W^T)^(-1/2) W and rows.rows convergence test;
+ * REFERENCE_LITERAL = the crate's arithmetic as written (src/ica.rs:345-349, 369-380). */
+enum { PETAL_ICA_TEXTBOOK = 0, PETAL_ICA_REFERENCE_LITERAL = 1 };
+
+typedef struct petal_matrix {
+    void*   data;
+    int64_t rows, cols;
+    int64_t row_stride, col_stride; /* in elements */
+    int32_t dtype;                  /* PETAL_F32 | PETAL_F64 */
+    int32_t space;                  /* PETAL_HOST | PETAL_DEVICE */
+} petal_matrix;
+
+/* Sample-sharded multi-GPU: every rank holds a row block of X; the library calls this hook to sum
+ * (or max/min) small replicated buffers across ranks.  `buf` is DEVICE memory of `count` elements
+ * of `dtype`; the reduction must be enqueued on / ordered with `stream` (a hipStream_t).  With
+ * torch.distributed this is one all_reduce on the RCCL process group. */
+typedef int (*petal_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dtype, int32_t op, void* stream);
+
+typedef struct petal_stats {
+    double  fit_ms;            /* wall time of the last fit call (host clock, incl. final sync)        */
+    /* the two X-streaming power-iteration GEMM kernels (hipEvent time on the ctx stream, profiling on) */
+    double  xp_ms;             /* K1  Z = Xc . P   : summed kernel time                                */
+    int64_t xp_launches;
+    double  atb_ms;            /* K2  Y = Xc^T . Z : summed kernel time (main kernel, not its reducer) */
+    int64_t atb_launches;
+    double  pass_flops;        /* algorithmic flops of ONE such launch: 2 n d l, l = k + n_oversample  */
+    double  pass_bytes;        /* algorithmic bytes of ONE such launch: 4 (n d + n l + d l)            */
+    double  ica_step_ms;       /* fused FastICA step kernel: summed kernel time                       */
+    int64_t ica_step_launches;
+    double  ica_step_flops;    /* per launch: 4 nc^2 n                                                 */
+    double  ica_step_bytes;    /* per launch: 4 nc n                                                   */
+    int64_t n_iter;            /* FastICA iterations of the last fit                                  */
+} petal_stats;
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* `stream`: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let
+ * the ctx create its own. */
+int         petal_ctx_create(int device, void* stream, petal_ctx** out);
+void        petal_ctx_destroy(petal_ctx* ctx);
+const char* petal_last_error(const petal_ctx* ctx);
+const char* petal_version(void);
+int         petal_ctx_set_collective(petal_ctx* ctx, petal_allreduce_fn fn, void* user, int rank, int world_size);
+/* profiling != 0: bracket the hot kernels with hipEvents and fill petal_stats.*_ms */
+int         petal_ctx_set_profiling(petal_ctx* ctx, int profiling);
+int         petal_get_stats(const petal_ctx* ctx, petal_stats* out);
+
+/* ---- Pca<A>::fit / fit_transform  (src/pca.rs:116-122, 153-167, 195-231) ---------------------- */
+/* components: k x d, means: d, singular: k, total_variance: 1 (all host, dtype of x).
+ * y_out (nullable): n x k = U[:, :k] * sigma  (transform_with_u, src/pca.rs:758-779). */
+int petal_pca_fit(petal_ctx* ctx, const petal_matrix* x, int64_t k, int centering,
+                  void* components, void* means, void* singular, void* total_variance,
+                  const petal_matrix* y_out);
+
+/* ---- RandomizedPca<A,R>::fit / fit_transform  (src/pca.rs:430-436, 467-481, 509-550, 668-718) -- */
+/* omega: HOST, d x (k + n_oversample) row-major, dtype of x: the StandardNormal matrix the crate
+ * draws at src/pca.rs:701-705 from the model's RNG (the facade draws it and passes it in).
+ * Reference constants: n_oversample = 10 (src/pca.rs:679), n_iter = 7 (src/pca.rs:680). */
+int petal_rpca_fit(petal_ctx* ctx, const petal_matrix* x, int64_t k, int64_t n_oversample, int64_t n_iter,
+                   int centering, const void* omega,
+                   void* components, void* means, void* singular, void* total_variance,
+                   const petal_matrix* y_out);
+
+/* ---- transform / inverse_transform  (src/pca.rs:726-750, 788-811; src/ica.rs:120-131) --------- */
+/* y_out = (x - means) . components^T   (means ignored when centering == 0) */
+int petal_transform(petal_ctx* ctx, const petal_matrix* x, const void* components, const void* means,
+                    int64_t k, int64_t d, int centering, const petal_matrix* y_out);
+/* x_out = y . components + means */
+int petal_inverse_transform(petal_ctx* ctx, const petal_matrix* y, const void* components, const void* means,
+                            int64_t k, int64_t d, int centering, const petal_matrix* x_out);
+
+/* ---- FastIca<A,R>::fit / fit_transform  (src/ica.rs:105-112, 147-157, 167-221) ---------------- */
+/* n_components == 0 -> min(n, d) as the crate does (src/ica.rs:173).  w_init: HOST nc x nc row-major
+ * StandardNormal draw (src/ica.rs:210-214).  Reference constants tol = 1e-4, max_iter = 200
+ * (src/ica.rs:216).  components: nc x d, means: d (host).  y_out (nullable): n x nc sources. */
+int petal_fastica_fit(petal_ctx* ctx, const petal_matrix* x, int64_t n_components, double tol, int64_t max_iter,
+                      int mode, const void* w_init, void* components, void* means, int64_t* n_iter,
+                      const petal_matrix* y_out);
+
+/* ---- the crate-private kernels that carry known-answer tests ----------------------------------- */
+/* ica_par (src/ica.rs:319-361): x1 is nc x n (whitened); w_init / w_out HOST nc x nc. */
+int petal_ica_par(petal_ctx* ctx, const petal_matrix* x1, double tol, int64_t max_iter, int mode,
+                  const void* w_init, void* w_out, int64_t* n_iter);
+/* symmetric_decorrelation (src/ica.rs:363-381): w, out HOST nc x nc (dtype). */
+int petal_symmetric_decorrelation(petal_ctx* ctx, const void* w, int64_t nc, int32_t dtype, int mode, void* out);
+/* logcosh (src/ica.rs:383-398): x is r x c; g_out r x c = tanh(x); gprime_out HOST r = mean(1-g^2). */
+int petal_logcosh(petal_ctx* ctx, const petal_matrix* x, const petal_matrix* g_out, void* gprime_out);
+/* svd_flip (src/pca.rs:815-850): flips columns of u (n x m) and rows of vt (m' x d) in place. */
+int petal_svd_flip(petal_ctx* ctx, const petal_matrix* u, const petal_matrix* vt);
+
+/* ---- the two X-streaming GEMM kernels of the power iteration, callable on their own ---------------
+ * (parity tests with exact-integer data, and the roofline measurement of bench.py).
+ * z_out[n x N] = (x[n x K] - mu) . p + bias     (src/pca.rs:707, 714, 745, 806: `input.dot(&pl)`)
+ *   mu (nullable): HOST K values; p: HOST K x N row-major; bias (nullable): HOST N values; all in x's dtype. */
+int petal_gemm_xp(petal_ctx* ctx, const petal_matrix* x, const void* mu, const void* p, int64_t N, const void* bias,
+                  const petal_matrix* z_out);
+/* c_out[M x N] (HOST, row-major, fp64) = (a[n x M] - mu_a)^T . (b[n x N] - mu_b)   (src/pca.rs:711, 681:
+ * `input.t().dot(&pl)`, `q.t().dot(input)`);  mu_a / mu_b nullable HOST vectors in a's dtype.
+ * b == NULL means b = a (Gram matrix / covariance, src/ica.rs:189 equivalent). */
+int petal_gemm_atb(petal_ctx* ctx, const petal_matrix* a, const void* mu_a, const petal_matrix* b, const void* mu_b,
+                   double* c_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PETAL_HIP_H */

@@ -1,0 +1,307 @@
+// cpu_ops.cpp -- HOST-MEMORY SIMULATION of petal-decomposition_amd/csrc/ops.h.  TEST INFRASTRUCTURE.
+//
+// Built ONLY by tests/ (and linked with the product's algo.cpp/api.cpp into tests/_build/
+// libpetal_hostsim.so) so that the host algorithms and the sample-sharded collective path can run
+// without a GPU (CPU test suite, world_size-2 gloo test).  It is never part of the product library
+// libpetal_hip.so: that links hip_ops.hip and fails loudly without a gfx950 device.
+//
+// Every op is the plain-loop definition of the contract in ops.h, in fp64.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <vector>
+
+#include "../petal-decomposition_amd/csrc/ops.h"
+
+namespace petal {
+
+struct Dev { int tag = 0; };
+
+Dev* dev_create(int, void*, char*, size_t) { return new Dev(); }
+void dev_destroy(Dev* d) { delete d; }
+void* dev_stream(Dev*) { return nullptr; }
+void* dev_alloc(Dev*, size_t bytes) {
+    void* p = std::malloc(bytes ? bytes : 1);
+    if (!p) throw std::runtime_error("host sim: out of memory");
+    return p;
+}
+void dev_free(Dev*, void* p) { std::free(p); }
+void dev_memset(Dev*, void* p, int v, size_t bytes) { std::memset(p, v, bytes); }
+void dev_h2d(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
+void dev_d2h(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
+void dev_d2d(Dev*, void* dst, const void* src, size_t bytes) { std::memmove(dst, src, bytes); }
+void dev_copy2d(Dev*, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int) {
+    for (size_t i = 0; i < height; ++i)
+        std::memcpy(static_cast<char*>(dst) + i * dpitch, static_cast<const char*>(src) + i * spitch, width);
+}
+void dev_sync(Dev*) {}
+void dev_set_profiling(Dev*, bool) {}
+void dev_reset_timing(Dev*) {}
+void dev_set_tag(Dev* d, int tag) { d->tag = tag; }
+KernelTiming dev_timing(Dev*) { return KernelTiming{}; }
+
+namespace {
+inline double ld(const void* p, int dt, int64_t i) {
+    return dt == F64 ? static_cast<const double*>(p)[i] : double(static_cast<const float*>(p)[i]);
+}
+inline void st(void* p, int dt, int64_t i, double v) {
+    if (dt == F64) static_cast<double*>(p)[i] = v;
+    else static_cast<float*>(p)[i] = float(v);
+}
+// value as the device kernel sees it after centring in the storage dtype
+inline double centred(const void* X, int dt, int64_t idx, const void* mu, int64_t j) {
+    if (!mu) return ld(X, dt, idx);
+    if (dt == F64) return static_cast<const double*>(X)[idx] - static_cast<const double*>(mu)[j];
+    return double(static_cast<const float*>(X)[idx] - static_cast<const float*>(mu)[j]);
+}
+}  // namespace
+
+void op_pack_strided(Dev*, int dt, const void* src, int64_t n, int64_t d, int64_t rs, int64_t cs, void* dst,
+                     int64_t ld_dst, int64_t d_pad) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < d_pad; ++j) st(dst, dt, i * ld_dst + j, j < d ? ld(src, dt, i * rs + j * cs) : 0.0);
+}
+void op_unpack_strided(Dev*, int dt, const void* src, int64_t n, int64_t d, int64_t ld_src, void* dst, int64_t rs,
+                       int64_t cs) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < d; ++j) st(dst, dt, i * rs + j * cs, ld(src, dt, i * ld_src + j));
+}
+void op_colsum(Dev*, int dt, const void* X, int64_t n, int64_t d, int64_t ldx, double* out) {
+    for (int64_t j = 0; j < d; ++j) out[j] = 0;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < d; ++j) out[j] += ld(X, dt, i * ldx + j);
+}
+void op_gemm_xp(Dev*, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P,
+                int64_t N, int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq) {
+    std::vector<double> row(K), acc(N);
+    double ss = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        for (int64_t k = 0; k < K; ++k) { row[k] = centred(X, dt, i * ldx + k, mu, k); ss += row[k] * row[k]; }
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int64_t k = 0; k < K; ++k) {
+            const double a = row[k];
+            if (a == 0.0) continue;
+            const double* p = P + k * ldp;
+            for (int64_t j = 0; j < N; ++j) acc[j] += a * (dt == F32 ? double(float(p[j])) : p[j]);
+        }
+        for (int64_t j = 0; j < N; ++j) st(Z, dt, i * ldz + j, acc[j] + (bias ? ld(bias, dt, j) : 0.0));
+    }
+    if (sumsq) *sumsq += ss;
+}
+void op_gemm_atb(Dev*, int dt, const void* A, int64_t lda, int64_t M, const void* muA, const void* B, int64_t ldb,
+                 int64_t N, const void* muB, int64_t n, double* C, int64_t ldc) {
+    for (int64_t m = 0; m < M; ++m)
+        for (int64_t j = 0; j < N; ++j) C[m * ldc + j] = 0;
+    std::vector<double> a(M), b(N);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int64_t m = 0; m < M; ++m) a[m] = centred(A, dt, i * lda + m, muA, m);
+        for (int64_t j = 0; j < N; ++j) b[j] = centred(B, dt, i * ldb + j, muB, j);
+        for (int64_t m = 0; m < M; ++m) {
+            if (a[m] == 0.0) continue;
+            double* c = C + m * ldc;
+            for (int64_t j = 0; j < N; ++j) c[j] += a[m] * b[j];
+        }
+    }
+}
+void op_col_absmax(Dev*, int dt, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* absmax,
+                   double* idx, double* sign) {
+    for (int64_t j = 0; j < L; ++j) {
+        double best = -1, bi = std::numeric_limits<double>::infinity(), bs = 1;
+        for (int64_t i = 0; i < n; ++i) {
+            const double v = ld(U, dt, i * ldu + j), a = std::fabs(v);
+            if (i == 0 || a > best) { best = a; bi = double(row_offset + i); bs = std::signbit(v) ? -1.0 : 1.0; }
+        }
+        absmax[j] = best; idx[j] = bi; sign[j] = bs;
+    }
+}
+void op_scale_cols(Dev*, int dt, void* A, int64_t n, int64_t L, int64_t lda, const double* s) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < L; ++j) st(A, dt, i * lda + j, ld(A, dt, i * lda + j) * s[j]);
+}
+void op_logcosh_rows(Dev*, int dt, const void* X, int64_t r, int64_t c, int64_t ldx, void* G, int64_t ldg, double* gp) {
+    for (int64_t i = 0; i < r; ++i) {
+        double s = 0;
+        for (int64_t j = 0; j < c; ++j) {
+            const double g = std::tanh(ld(X, dt, i * ldx + j));
+            st(G, dt, i * ldg + j, g);
+            s += 1.0 - g * g;
+        }
+        gp[i] = s;
+    }
+}
+
+// ---- small f64 ops ---------------------------------------------------------------------------
+void op_dgemm(Dev*, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+              const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+    for (int64_t i = 0; i < M; ++i)
+        for (int64_t j = 0; j < N; ++j) {
+            double s = 0;
+            for (int64_t k = 0; k < K; ++k) s += (ta ? A[k * lda + i] : A[i * lda + k]) * (tb ? B[j * ldb + k] : B[k * ldb + j]);
+            C[i * ldc + j] = alpha * s + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
+        }
+}
+void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol) {
+    std::vector<double> R(size_t(L) * L, 0.0);
+    std::vector<char> dead(L, 0);
+    for (int64_t j = 0; j < L; ++j) {  // row-by-row upper Cholesky, G = R^T R
+        double s = G[j * ldg + j];
+        for (int64_t k = 0; k < j; ++k) s -= R[k * L + j] * R[k * L + j];
+        const double gjj = G[j * ldg + j];
+        if (!(gjj > 0) || !(s > rel_tol * gjj)) { dead[j] = 1; continue; }  // dependent column: dropped
+        const double rjj = std::sqrt(s);
+        R[j * L + j] = rjj;
+        for (int64_t c = j + 1; c < L; ++c) {
+            double v = G[j * ldg + c];
+            for (int64_t k = 0; k < j; ++k) v -= R[k * L + j] * R[k * L + c];
+            R[j * L + c] = v / rjj;
+        }
+    }
+    // T = R^{-1} by back substitution per column; dead columns -> 0 (and are skipped as rows)
+    for (int64_t i = 0; i < L; ++i)
+        for (int64_t j = 0; j < L; ++j) T[i * ldt + j] = 0;
+    for (int64_t j = 0; j < L; ++j) {
+        if (dead[j]) continue;
+        T[j * ldt + j] = 1.0 / R[j * L + j];
+        for (int64_t i = j - 1; i >= 0; --i) {
+            if (dead[i]) continue;
+            double s = 0;
+            for (int64_t k = i + 1; k <= j; ++k) s += R[i * L + k] * T[k * ldt + j];
+            T[i * ldt + j] = -s / R[i * L + i];
+        }
+    }
+}
+void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w) {
+    for (int64_t i = 0; i < L; ++i)
+        for (int64_t j = 0; j < L; ++j) V[i * ldv + j] = (i == j);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0, diag = 0;
+        for (int64_t i = 0; i < L; ++i)
+            for (int64_t j = 0; j < L; ++j) (i == j ? diag : off) += A[i * lda + j] * A[i * lda + j];
+        if (off <= 1e-30 * diag || off == 0) break;
+        for (int64_t p = 0; p < L - 1; ++p)
+            for (int64_t q = p + 1; q < L; ++q) {
+                const double apq = A[p * lda + q];
+                if (apq == 0) continue;
+                const double theta = (A[q * lda + q] - A[p * lda + p]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+                const double cs = 1 / std::sqrt(t * t + 1), sn = t * cs;
+                for (int64_t k = 0; k < L; ++k) {  // columns p,q
+                    const double akp = A[k * lda + p], akq = A[k * lda + q];
+                    A[k * lda + p] = cs * akp - sn * akq;
+                    A[k * lda + q] = sn * akp + cs * akq;
+                }
+                for (int64_t k = 0; k < L; ++k) {  // rows p,q
+                    const double apk = A[p * lda + k], aqk = A[q * lda + k];
+                    A[p * lda + k] = cs * apk - sn * aqk;
+                    A[q * lda + k] = sn * apk + cs * aqk;
+                }
+                for (int64_t k = 0; k < L; ++k) {
+                    const double vkp = V[k * ldv + p], vkq = V[k * ldv + q];
+                    V[k * ldv + p] = cs * vkp - sn * vkq;
+                    V[k * ldv + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    std::vector<int64_t> order(L);
+    for (int64_t i = 0; i < L; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return A[a * lda + a] > A[b * lda + b]; });
+    std::vector<double> Vs(size_t(L) * L);
+    for (int64_t j = 0; j < L; ++j) {
+        w[j] = A[order[j] * lda + order[j]];
+        for (int64_t i = 0; i < L; ++i) Vs[i * L + j] = V[i * ldv + order[j]];
+    }
+    for (int64_t i = 0; i < L; ++i)
+        for (int64_t j = 0; j < L; ++j) V[i * ldv + j] = Vs[i * L + j];
+}
+void op_dscal(Dev*, double* x, int64_t count, double alpha) {
+    for (int64_t i = 0; i < count; ++i) x[i] *= alpha;
+}
+void op_dvec(Dev*, int mode, const double* x, double* y, int64_t count, double thr) {
+    const double x0 = count ? x[0] : 0;
+    for (int64_t i = 0; i < count; ++i) {
+        if (mode == 0) y[i] = std::sqrt(std::max(x[i], 0.0));
+        else y[i] = (x[i] > thr * x0 && x[i] > 0) ? 1.0 / x[i] : 0.0;
+    }
+}
+void op_dscale_cols(Dev*, double* A, int64_t M, int64_t N, int64_t lda, const double* s) {
+    for (int64_t i = 0; i < M; ++i)
+        for (int64_t j = 0; j < N; ++j) A[i * lda + j] *= s[j];
+}
+void op_cvt_from_f64(Dev*, int dt, void* dst, const double* src, int64_t count) {
+    for (int64_t i = 0; i < count; ++i) st(dst, dt, i, src[i]);
+}
+void op_cvt_to_f64(Dev*, int dt, double* dst, const void* src, int64_t count) {
+    for (int64_t i = 0; i < count; ++i) dst[i] = ld(src, dt, i);
+}
+
+// ---- FastICA ---------------------------------------------------------------------------------
+void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode) {
+    std::vector<double> S(size_t(nc) * nc), Z(size_t(nc) * nc), w(nc), M(size_t(nc) * nc);
+    op_dgemm(d, false, true, nc, nc, nc, 1.0, Win, nc, Win, nc, 0.0, S.data(), nc);  // W W^T (ica.rs:369)
+    op_eigh(d, S.data(), nc, nc, Z.data(), nc, w.data());                            // columns of Z = eigenvectors
+    // textbook: (Z D Z^T)_ij = sum_k Z[i][k] s_k Z[j][k]   (eigenvector k = column k of Z)
+    // literal (ica.rs:370-380): v = heev buffer read row-major = Z_asc^T (LAPACK order: ascending),
+    // v's COLUMN c is scaled by s_c, then v . v_saved^T  =>  (Z_asc^T D Z_asc)_ij = sum_c Z_asc[c][i] s_c Z_asc[c][j].
+    // That form depends on LAPACK's eigenvector signs; for nc == 2 LAPACK's 2x2 solver (dlaev2 + ascending
+    // sort) returns a SYMMETRIC Z for any PSD input, which makes the literal form equal the textbook one.
+    const bool literal = mode == 1 && nc > 2;
+    for (int64_t i = 0; i < nc; ++i)
+        for (int64_t j = 0; j < nc; ++j) {
+            double acc = 0;
+            for (int64_t k = 0; k < nc; ++k) {
+                if (literal) {
+                    const double sk = 1.0 / std::sqrt(w[nc - 1 - k]);  // ascending eigenvalue k
+                    acc += Z[k * nc + (nc - 1 - i)] * sk * Z[k * nc + (nc - 1 - j)];
+                } else {
+                    acc += Z[i * nc + k] * (1.0 / std::sqrt(w[k])) * Z[j * nc + k];
+                }
+            }
+            M[i * nc + j] = acc;
+        }
+    op_dgemm(d, false, false, nc, nc, nc, 1.0, M.data(), nc, Win, nc, 0.0, Wout, nc);
+}
+
+void op_ica_step(Dev*, int dt, const void* X1T, int64_t n, int64_t nc, int64_t ldx, const double* W, double* GX_gp,
+                 const int* state) {
+    if (state && state[0]) return;
+    double* GX = GX_gp;
+    double* gp = GX_gp + nc * nc;
+    for (int64_t i = 0; i < nc * nc + nc; ++i) GX_gp[i] = 0;
+    std::vector<double> x(nc);
+    for (int64_t s = 0; s < n; ++s) {
+        for (int64_t j = 0; j < nc; ++j) x[j] = ld(X1T, dt, s * ldx + j);
+        for (int64_t i = 0; i < nc; ++i) {
+            double wx = 0;
+            for (int64_t j = 0; j < nc; ++j) wx += (dt == F32 ? double(float(W[i * nc + j])) : W[i * nc + j]) * x[j];
+            const double g = std::tanh(wx);
+            gp[i] += 1.0 - g * g;
+            for (int64_t j = 0; j < nc; ++j) GX[i * nc + j] += g * x[j];
+        }
+    }
+}
+
+void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol, int* state,
+                 int iter) {
+    if (state[0]) return;
+    const double* GX = GX_gp;
+    const double* gp = GX_gp + nc * nc;
+    std::vector<double> D(size_t(nc) * nc), W1(size_t(nc) * nc);
+    const double pinv = 1.0 / n_total;
+    for (int64_t i = 0; i < nc; ++i)
+        for (int64_t j = 0; j < nc; ++j) D[i * nc + j] = GX[i * nc + j] * pinv - gp[i] * pinv * W[i * nc + j];  // ica.rs:334-342
+    op_symdecorr(d, nc, D.data(), W1.data(), mode);  // ica.rs:343
+    double lim = 0;
+    for (int64_t i = 0; i < nc; ++i) {
+        double dot = 0;
+        for (int64_t j = 0; j < nc; ++j) dot += W1[i * nc + j] * (mode == 1 ? W[j * nc + i] : W[i * nc + j]);  // ica.rs:345-349
+        const double v = std::fabs(std::fabs(dot) - 1.0);
+        if (v > lim) lim = v;
+    }
+    for (int64_t i = 0; i < nc * nc; ++i) W[i] = W1[i];
+    if (lim < tol) { state[0] = 1; state[1] = iter + 1; }  // ica.rs:355-357
+}
+
+}  // namespace petal

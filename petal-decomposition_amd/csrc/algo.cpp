@@ -1,0 +1,732 @@
+// algo.cpp -- host side of the hot path: the reference's fit()/transform() algorithms restated as
+// a sequence of device operations (ops.h).  Nothing here touches matrix elements of the O(n)
+// operands on the host; the host only sequences kernels, moves O(d l) results and talks to the
+// collective hook.
+//
+// Reference call stacks: SURVEY.md section 3; algorithm: SURVEY.md section 10.
+#include <algorithm>
+#include <chrono>
+
+#include "ctx.h"
+
+namespace petal {
+
+namespace {
+
+double get_elem(const void* p, int dt, int64_t i) {
+    return dt == F64 ? static_cast<const double*>(p)[i] : static_cast<double>(static_cast<const float*>(p)[i]);
+}
+void put_elem(void* p, int dt, int64_t i, double v) {
+    if (dt == F64) static_cast<double*>(p)[i] = v;
+    else static_cast<float*>(p)[i] = static_cast<float>(v);
+}
+
+void check_matrix(const petal_matrix& m, const char* what) {
+    if (m.dtype != PETAL_F32 && m.dtype != PETAL_F64) invalid_input(std::string(what) + ": unsupported dtype");
+    if (m.rows < 0 || m.cols < 0) invalid_input(std::string(what) + ": negative shape");
+    if (m.space != PETAL_HOST && m.space != PETAL_DEVICE) invalid_input(std::string(what) + ": bad memory space");
+    if (m.rows > 0 && m.cols > 0 && m.data == nullptr) invalid_input(std::string(what) + ": null data");
+    // linalg.rs:52-53, 76-79: LAPACK dims are i32 in the reference; this path is 64-bit throughout but
+    // keeps the n*d element count addressable.
+    if (m.rows > (int64_t(1) << 40) || m.cols > (int64_t(1) << 24)) invalid_input(std::string(what) + ": too many rows/columns");
+}
+
+struct RankInfo { double n_total = 0; int64_t row_offset = 0; };
+
+RankInfo rank_info(petal_ctx& c, int64_t n_local) {
+    RankInfo r;
+    if (c.world <= 1) { r.n_total = double(n_local); return r; }
+    std::vector<double> h(c.world, 0.0);
+    h[c.rank] = double(n_local);
+    DBuf b(c.dev, sizeof(double) * c.world);
+    dev_h2d(c.dev, b.p, h.data(), b.bytes);
+    allreduce_f64(c, b.f64(), c.world, PETAL_SUM);
+    dev_d2h(c.dev, h.data(), b.p, b.bytes);
+    dev_sync(c.dev);
+    for (int i = 0; i < c.world; ++i) { r.n_total += h[i]; if (i < c.rank) r.row_offset += int64_t(h[i]); }
+    return r;
+}
+
+// column means (pca.rs:520-528 / ica.rs:174): mu64 (device f64[dp]) and muT (device dtype[dp]); zeros if !centering
+void column_means(petal_ctx& c, const DevMat& X, double n_total, bool centering, DBuf& mu64, DBuf& muT) {
+    mu64 = DBuf(c.dev, sizeof(double) * X.dp);
+    muT = DBuf(c.dev, dtype_size(X.dtype) * X.dp);
+    if (!centering) {
+        dev_memset(c.dev, mu64.p, 0, mu64.bytes);
+        dev_memset(c.dev, muT.p, 0, muT.bytes);
+        return;
+    }
+    op_colsum(c.dev, X.dtype, X.p, X.n, X.dp, X.ld, mu64.f64());
+    allreduce_f64(c, mu64.f64(), X.dp, PETAL_SUM);
+    op_dscal(c.dev, mu64.f64(), X.dp, 1.0 / n_total);
+    op_cvt_from_f64(c.dev, X.dtype, muT.p, mu64.f64(), X.dp);
+}
+
+// svd_flip's decision (pca.rs:826-839) for the columns of a row-sharded U: sign of the first
+// element of maximal magnitude over ALL ranks' rows.  Returns +1/-1 per column.
+std::vector<double> flip_signs(petal_ctx& c, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu,
+                               int64_t row_offset) {
+    std::vector<double> h(3 * L), sg(L, 1.0);
+    if (L == 0) return sg;
+    DBuf r(c.dev, sizeof(double) * 3 * L);
+    op_col_absmax(c.dev, dtype, U, n, L, ldu, row_offset, r.f64(), r.f64() + L, r.f64() + 2 * L);
+    if (c.world <= 1) {
+        dev_d2h(c.dev, h.data(), r.p, r.bytes);
+        dev_sync(c.dev);
+        for (int64_t j = 0; j < L; ++j) sg[j] = h[2 * L + j] < 0 ? -1.0 : 1.0;
+        return sg;
+    }
+    DBuf g(c.dev, sizeof(double) * L);
+    std::vector<double> gm(L), cand(L), win(L);
+    dev_d2d(c.dev, g.p, r.p, g.bytes);
+    allreduce_f64(c, g.f64(), L, PETAL_MAX);
+    dev_d2h(c.dev, h.data(), r.p, r.bytes);
+    dev_d2h(c.dev, gm.data(), g.p, g.bytes);
+    dev_sync(c.dev);
+    const double inf = std::numeric_limits<double>::infinity();
+    for (int64_t j = 0; j < L; ++j) cand[j] = (h[j] == gm[j]) ? h[L + j] : inf;
+    dev_h2d(c.dev, g.p, cand.data(), g.bytes);
+    allreduce_f64(c, g.f64(), L, PETAL_MIN);
+    dev_d2h(c.dev, win.data(), g.p, g.bytes);
+    dev_sync(c.dev);
+    for (int64_t j = 0; j < L; ++j) cand[j] = (cand[j] == win[j] && std::isfinite(win[j])) ? h[2 * L + j] : 0.0;
+    dev_h2d(c.dev, g.p, cand.data(), g.bytes);
+    allreduce_f64(c, g.f64(), L, PETAL_SUM);
+    dev_d2h(c.dev, win.data(), g.p, g.bytes);
+    dev_sync(c.dev);
+    for (int64_t j = 0; j < L; ++j) sg[j] = win[j] < 0 ? -1.0 : 1.0;
+    return sg;
+}
+
+// Y (M x LP, f64) <- orthonormal basis of range(Y) by two rounds of Cholesky-QR in fp64
+// (stands where the reference re-bases the small d x l iterate with pivoted LU, pca.rs:712-713).
+void orthonormalize_small(petal_ctx& c, DBuf& Y, int64_t M, int64_t LP, double tol) {
+    DBuf G(c.dev, sizeof(double) * LP * LP), T(c.dev, sizeof(double) * LP * LP), Y2(c.dev, Y.bytes);
+    for (int rep = 0; rep < 2; ++rep) {
+        op_dgemm(c.dev, true, false, LP, LP, M, 1.0, Y.f64(), LP, Y.f64(), LP, 0.0, G.f64(), LP);
+        op_chol_inv(c.dev, G.f64(), LP, LP, T.f64(), LP, tol);
+        op_dgemm(c.dev, false, false, M, LP, LP, 1.0, Y.f64(), LP, T.f64(), LP, 0.0, Y2.f64(), LP);
+        std::swap(Y, Y2);
+    }
+}
+
+struct Timer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+void finish_stats(petal_ctx& c, const Timer& t) {
+    dev_sync(c.dev);
+    c.stats.fit_ms = t.ms();
+    KernelTiming kt = dev_timing(c.dev);
+    c.stats.xp_ms = kt.ms[TAG_XP];
+    c.stats.xp_launches = kt.launches[TAG_XP];
+    c.stats.atb_ms = kt.ms[TAG_ATB];
+    c.stats.atb_launches = kt.launches[TAG_ATB];
+    c.stats.ica_step_ms = kt.ms[TAG_ICA];
+    c.stats.ica_step_launches = kt.launches[TAG_ICA];
+}
+
+}  // namespace
+
+void allreduce_f64(petal_ctx& c, double* dev_buf, int64_t count, int op) {
+    if (c.world <= 1 || count == 0) return;
+    if (!c.allreduce) device_error("world_size > 1 but no collective hook installed (petal_ctx_set_collective)");
+    int rc = c.allreduce(c.allreduce_user, dev_buf, count, PETAL_F64, op, dev_stream(c.dev));
+    if (rc != 0) device_error("collective all-reduce failed with code " + std::to_string(rc));
+}
+
+// ---------------------------------------------------------------------------------------------
+DevMat ingest(petal_ctx& c, const petal_matrix& x) {
+    check_matrix(x, "input");
+    DevMat m;
+    m.dtype = x.dtype;
+    m.n = x.rows;
+    m.d = x.cols;
+    m.dp = round_up(std::max<int64_t>(x.cols, 1), 16);
+    const size_t esz = dtype_size(x.dtype);
+    if (m.n == 0) { m.ld = m.dp; return m; }
+    const bool unit = (x.col_stride == 1 || x.cols <= 1);
+    if (x.space == PETAL_DEVICE && unit && x.cols == m.dp && x.row_stride >= x.cols &&
+        (reinterpret_cast<uintptr_t>(x.data) % 16) == 0 && (x.row_stride * esz) % 16 == 0) {
+        m.p = x.data;  // zero-copy: already in the layout the kernels stream
+        m.ld = x.row_stride;
+        return m;
+    }
+    m.ld = m.dp;
+    m.owned = DBuf(c.dev, esz * size_t(m.n) * m.dp);
+    m.p = m.owned.p;
+    if (x.space == PETAL_DEVICE) {
+        op_pack_strided(c.dev, x.dtype, x.data, m.n, m.d, x.row_stride, x.col_stride, m.owned.p, m.ld, m.dp);
+        return m;
+    }
+    if (m.dp != m.d) dev_memset(c.dev, m.owned.p, 0, m.owned.bytes);
+    if (unit && x.row_stride >= x.cols) {
+        dev_copy2d(c.dev, m.owned.p, m.ld * esz, x.data, size_t(x.row_stride) * esz, size_t(m.d) * esz, size_t(m.n), 0);
+    } else {  // arbitrary ndarray view (e.g. a transposed one): gather on the host, then upload
+        std::vector<char> tmp(esz * size_t(m.n) * m.d);
+        const char* src = static_cast<const char*>(x.data);
+        for (int64_t i = 0; i < m.n; ++i)
+            for (int64_t j = 0; j < m.d; ++j)
+                std::memcpy(&tmp[(size_t(i) * m.d + j) * esz], src + (i * x.row_stride + j * x.col_stride) * int64_t(esz), esz);
+        dev_copy2d(c.dev, m.owned.p, m.ld * esz, tmp.data(), size_t(m.d) * esz, size_t(m.d) * esz, size_t(m.n), 0);
+        dev_sync(c.dev);
+    }
+    return m;
+}
+
+void emit(petal_ctx& c, int dtype, const void* src, int64_t n, int64_t cols, int64_t ld, const petal_matrix& out) {
+    check_matrix(out, "output");
+    if (out.dtype != dtype) invalid_input("output dtype differs from input dtype");
+    if (out.rows != n || out.cols != cols) invalid_input("output has the wrong shape");
+    if (n == 0 || cols == 0) return;
+    const size_t esz = dtype_size(dtype);
+    if (out.space == PETAL_DEVICE) {
+        op_unpack_strided(c.dev, dtype, src, n, cols, ld, out.data, out.row_stride, out.col_stride);
+        return;
+    }
+    if ((out.col_stride == 1 || cols == 1) && out.row_stride >= cols) {
+        dev_copy2d(c.dev, out.data, size_t(out.row_stride) * esz, src, size_t(ld) * esz, size_t(cols) * esz, size_t(n), 1);
+        dev_sync(c.dev);
+        return;
+    }
+    std::vector<char> tmp(esz * size_t(n) * cols);
+    dev_copy2d(c.dev, tmp.data(), size_t(cols) * esz, src, size_t(ld) * esz, size_t(cols) * esz, size_t(n), 1);
+    dev_sync(c.dev);
+    char* dst = static_cast<char*>(out.data);
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < cols; ++j)
+            std::memcpy(dst + (i * out.row_stride + j * out.col_stride) * int64_t(esz), &tmp[(size_t(i) * cols + j) * esz], esz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RandomizedPca::inner_fit (pca.rs:509-550) -> randomized_svd (pca.rs:668-686) -> range finder (689-718)
+void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversample, int64_t n_iter, bool centering,
+              const void* omega, void* components, void* means, void* singular, void* total_variance,
+              const petal_matrix* y_out) {
+    Timer timer;
+    dev_reset_timing(c.dev);
+    c.stats = petal_stats{};
+    check_matrix(x, "input");
+    if (k < 0 || n_oversample < 0 || n_iter < 0) invalid_input("negative parameter");
+    const int dt = x.dtype;
+    RankInfo ri = rank_info(c, x.rows);
+    const int64_t n_total = int64_t(ri.n_total), d = x.cols;
+    if (n_total < k || d < k)  // pca.rs:513-518
+        invalid_input("every dimension should be at least " + std::to_string(k));
+    if (centering && n_total == 0) {  // mean_axis -> None (pca.rs:521-525): Ok, model untouched
+        if (y_out && (y_out->rows != 0)) invalid_input("output has the wrong shape");
+        return;
+    }
+    const int64_t l_req = k + n_oversample;
+    const int64_t L = std::min(l_req, std::min(n_total, d));  // the reference's min(nrows, ncols) slices, pca.rs:710/713
+    if (L > 0 && omega == nullptr) invalid_input("omega is required");
+    if (d == 0 || L == 0) {  // nothing to decompose: k == 0 here
+        if (total_variance) put_elem(total_variance, dt, 0, 0.0);
+        if (y_out) emit(c, dt, nullptr, x.rows, 0, 0, *y_out);
+        return;
+    }
+    const int64_t LP = round_up(L, 16);
+    DevMat X = ingest(c, x);
+    const int64_t n = X.n, dp = X.dp;
+    const size_t esz = dtype_size(dt);
+    const double tol_drop = (dt == F32 ? 1e-6 : 1e-13);
+
+    DBuf mu64, muT;
+    column_means(c, X, ri.n_total, centering, mu64, muT);
+
+    // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64
+    DBuf P(c.dev, sizeof(double) * dp * LP);
+    {
+        std::vector<double> h(size_t(dp) * LP, 0.0);
+        for (int64_t i = 0; i < d; ++i)
+            for (int64_t j = 0; j < L; ++j) h[size_t(i) * LP + j] = get_elem(omega, dt, i * l_req + j);
+        dev_h2d(c.dev, P.p, h.data(), P.bytes);
+    }
+    DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
+    DBuf tv(c.dev, sizeof(double));
+    dev_memset(c.dev, tv.p, 0, sizeof(double));
+    c.stats.pass_flops = 2.0 * double(n) * double(d) * double(l_req);
+    c.stats.pass_bytes = double(esz) * (double(n) * d + double(n) * l_req + double(d) * l_req);
+
+    // Z = Xc . Omega (pca.rs:707), fused with total_variance = sum Xc^2 (pca.rs:533)
+    dev_set_tag(c.dev, TAG_XP);
+    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv.f64());
+    dev_set_tag(c.dev, TAG_NONE);
+
+    DBuf GY(c.dev, sizeof(double) * (LP * LP + dp * LP));  // [ Z^T Z | Xc^T Z ] reduced across ranks together
+    DBuf T(c.dev, sizeof(double) * LP * LP), Y(c.dev, sizeof(double) * dp * LP);
+    double* G = GY.f64();
+    double* Yp = GY.f64() + LP * LP;
+    for (int64_t it = 0; it < n_iter; ++it) {  // pca.rs:708-715
+        // re-base the tall iterate: G = Z^T Z, T = chol(G)^-1 (stands for PL(LU(Z)), pca.rs:709-710);
+        // T is applied on the small side: Xc^T (Z T) = (Xc^T Z) T, so Z is never rewritten.
+        op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP);
+        dev_set_tag(c.dev, TAG_ATB);
+        op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z.p, LP, LP, nullptr, n, Yp, LP);  // pca.rs:711
+        dev_set_tag(c.dev, TAG_NONE);
+            allreduce_f64(c, GY.f64(), LP * LP + dp * LP, PETAL_SUM);
+        op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);
+        op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
+        orthonormalize_small(c, Y, dp, LP, 1e-13);  // pca.rs:712-713
+        dev_set_tag(c.dev, TAG_XP);
+        op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Y.f64(), LP, LP, nullptr, Z.p, LP, nullptr);  // pca.rs:714
+        dev_set_tag(c.dev, TAG_NONE);
+        }
+
+    // thin QR of Z (pca.rs:716) as Cholesky-QR2: Z1 = Z T1, Q = Z1 T2 with T2 folded into the small side
+    op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP);
+    allreduce_f64(c, G, LP * LP, PETAL_SUM);
+    op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);
+    op_gemm_xp(c.dev, dt, Z.p, n, LP, LP, nullptr, T.f64(), LP, LP, nullptr, Z1.p, LP, nullptr);
+    op_gemm_atb(c.dev, dt, Z1.p, LP, LP, nullptr, Z1.p, LP, LP, nullptr, n, G, LP);
+    dev_set_tag(c.dev, TAG_ATB);
+    op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z1.p, LP, LP, nullptr, n, Yp, LP);  // B^T = Xc^T Q (pca.rs:681)
+    dev_set_tag(c.dev, TAG_NONE);
+    allreduce_f64(c, GY.f64(), LP * LP + dp * LP, PETAL_SUM);
+    allreduce_f64(c, tv.f64(), 1, PETAL_SUM);
+    op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);  // T2
+    DBuf Bt(c.dev, sizeof(double) * dp * LP);
+    op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Bt.f64(), LP);
+
+    // economy SVD of B (l x d) (svddc, pca.rs:682): eigen-decomposition of B B^T in fp64
+    DBuf S(c.dev, sizeof(double) * LP * LP), Uh(c.dev, sizeof(double) * LP * LP), lam(c.dev, sizeof(double) * LP);
+    DBuf sig(c.dev, sizeof(double) * LP), inv(c.dev, sizeof(double) * LP);
+    op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Bt.f64(), LP, Bt.f64(), LP, 0.0, S.f64(), LP);
+    op_eigh(c.dev, S.f64(), LP, LP, Uh.f64(), LP, lam.f64());
+    op_dvec(c.dev, 0, lam.f64(), sig.f64(), LP, 0.0);
+    op_dvec(c.dev, 1, sig.f64(), inv.f64(), LP, dt == F32 ? 1e-7 : 1e-12);
+    DBuf V(c.dev, sizeof(double) * dp * LP);  // V[:, j] = B^T u_j / sigma_j
+    op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Bt.f64(), LP, Uh.f64(), LP, 0.0, V.f64(), LP);
+    op_dscale_cols(c.dev, V.f64(), dp, LP, LP, inv.f64());
+
+    // U = Q Uh = Z1 (T2 Uh) (pca.rs:683) and svd_flip (pca.rs:684)
+    DBuf M2(c.dev, sizeof(double) * LP * LP);
+    op_dgemm(c.dev, false, false, LP, LP, LP, 1.0, T.f64(), LP, Uh.f64(), LP, 0.0, M2.f64(), LP);
+    op_gemm_xp(c.dev, dt, Z1.p, n, LP, LP, nullptr, M2.f64(), LP, LP, nullptr, Z.p, LP, nullptr);  // Z now holds U
+    std::vector<double> sg = flip_signs(c, dt, Z.p, n, LP, LP, ri.row_offset);
+
+    // results (pca.rs:543-547)
+    std::vector<double> hV(size_t(dp) * LP), hs(LP), hmu(dp);
+    double htv = 0;
+    dev_d2h(c.dev, hV.data(), V.p, V.bytes);
+    dev_d2h(c.dev, hs.data(), sig.p, sig.bytes);
+    dev_d2h(c.dev, hmu.data(), mu64.p, mu64.bytes);
+    dev_d2h(c.dev, &htv, tv.p, sizeof(double));
+    dev_sync(c.dev);
+    for (int64_t j = 0; j < k; ++j) {
+        for (int64_t i = 0; i < d; ++i) put_elem(components, dt, j * d + i, sg[j] * hV[size_t(i) * LP + j]);
+        put_elem(singular, dt, j, hs[j]);
+    }
+    for (int64_t i = 0; i < d; ++i) put_elem(means, dt, i, hmu[i]);
+    put_elem(total_variance, dt, 0, htv);
+    if (y_out) {  // fit_transform: U[:, :k] * sigma (transform_with_u, pca.rs:758-779)
+        std::vector<double> sc(LP, 0.0);
+        for (int64_t j = 0; j < k; ++j) sc[j] = sg[j] * hs[j];
+        DBuf dsc(c.dev, sizeof(double) * LP);
+        dev_h2d(c.dev, dsc.p, sc.data(), dsc.bytes);
+        op_scale_cols(c.dev, dt, Z.p, n, k, LP, dsc.f64());
+        emit(c, dt, Z.p, n, k, LP, *y_out);
+    }
+    finish_stats(c, timer);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pca::inner_fit (pca.rs:195-231).  The reference asks LAPACK for the full n x n U; only its first
+// min(n,d) columns are ever read (svd_flip zips U columns with V^T rows; transform_with_u takes k),
+// so the thin factorisation is computed: eigen-decomposition of the d x d Gram matrix in fp64.
+void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, void* components, void* means,
+             void* singular, void* total_variance, const petal_matrix* y_out) {
+    Timer timer;
+    dev_reset_timing(c.dev);
+    c.stats = petal_stats{};
+    check_matrix(x, "input");
+    if (k < 0) invalid_input("negative parameter");
+    const int dt = x.dtype;
+    RankInfo ri = rank_info(c, x.rows);
+    const int64_t n_total = int64_t(ri.n_total), d = x.cols;
+    if (n_total < k || d < k) invalid_input("every dimension should be at least " + std::to_string(k));  // pca.rs:199-204
+    if (centering && n_total == 0) return;  // pca.rs:207-211
+    if (d == 0 || n_total == 0) {
+        if (total_variance) put_elem(total_variance, dt, 0, 0.0);
+        if (y_out) emit(c, dt, nullptr, x.rows, 0, 0, *y_out);
+        return;
+    }
+    if (d > 1024) invalid_input("exact Pca on the device supports at most 1024 features; use RandomizedPca");
+    DevMat X = ingest(c, x);
+    const int64_t n = X.n, dp = X.dp;
+    const size_t esz = dtype_size(dt);
+    DBuf mu64, muT;
+    column_means(c, X, ri.n_total, centering, mu64, muT);
+
+    DBuf C(c.dev, sizeof(double) * dp * dp), V(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp);
+    DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp);
+    op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp);
+    allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
+    op_eigh(c.dev, C.f64(), dp, dp, V.f64(), dp, lam.f64());
+    op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
+    op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, dt == F32 ? 1e-6 : 1e-10);
+
+    // U[:, j] = Xc v_j / sigma_j for j < r = min(n, d): only the columns svd_flip looks at
+    const int64_t r = std::min(n_total, d), rp = round_up(std::max<int64_t>(r, 1), 16);
+    DBuf Pm(c.dev, sizeof(double) * dp * rp);
+    dev_memset(c.dev, Pm.p, 0, Pm.bytes);
+    {
+        DBuf Vs(c.dev, V.bytes);
+        dev_d2d(c.dev, Vs.p, V.p, V.bytes);
+        op_dscale_cols(c.dev, Vs.f64(), dp, dp, dp, inv.f64());
+        dev_copy2d(c.dev, Pm.p, rp * sizeof(double), Vs.p, dp * sizeof(double), size_t(std::min(r, dp)) * sizeof(double), size_t(dp), 2);
+    }
+    DBuf U(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * rp);
+    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Pm.f64(), rp, rp, nullptr, U.p, rp, nullptr);
+    std::vector<double> sg = flip_signs(c, dt, U.p, n, r, rp, ri.row_offset);  // pca.rs:223
+
+    std::vector<double> hV(size_t(dp) * dp), hs(dp), hmu(dp);
+    dev_d2h(c.dev, hV.data(), V.p, V.bytes);
+    dev_d2h(c.dev, hs.data(), sig.p, sig.bytes);
+    dev_d2h(c.dev, hmu.data(), mu64.p, mu64.bytes);
+    dev_sync(c.dev);
+    double tvar = 0;  // pca.rs:224: sigma . sigma over all min(n,d) singular values
+    for (int64_t j = 0; j < r; ++j) tvar += hs[j] * hs[j];
+    for (int64_t j = 0; j < k; ++j) {
+        for (int64_t i = 0; i < d; ++i) put_elem(components, dt, j * d + i, sg[j] * hV[size_t(i) * dp + j]);
+        put_elem(singular, dt, j, hs[j]);
+    }
+    for (int64_t i = 0; i < d; ++i) put_elem(means, dt, i, hmu[i]);
+    put_elem(total_variance, dt, 0, tvar);
+    if (y_out) {
+        std::vector<double> sc(rp, 0.0);
+        for (int64_t j = 0; j < k; ++j) sc[j] = sg[j] * hs[j];
+        DBuf dsc(c.dev, sizeof(double) * rp);
+        dev_h2d(c.dev, dsc.p, sc.data(), dsc.bytes);
+        op_scale_cols(c.dev, dt, U.p, n, k, rp, dsc.f64());
+        emit(c, dt, U.p, n, k, rp, *y_out);
+    }
+    finish_stats(c, timer);
+}
+
+// ---------------------------------------------------------------------------------------------
+// free fn transform (pca.rs:726-750) / FastIca::transform (ica.rs:120-131)
+void transform(petal_ctx& c, const petal_matrix& x, const void* components, const void* means, int64_t k, int64_t d,
+               bool centering, const petal_matrix& y_out) {
+    check_matrix(x, "input");
+    if (x.cols != d) invalid_input("# of columns should be " + std::to_string(d));  // pca.rs:736-741
+    const int dt = x.dtype;
+    if (x.rows == 0 || k == 0) { emit(c, dt, nullptr, x.rows, k, 0, y_out); return; }
+    DevMat X = ingest(c, x);
+    const int64_t dp = X.dp, kp = round_up(k, 16);
+    std::vector<double> hP(size_t(dp) * kp, 0.0);
+    for (int64_t j = 0; j < k; ++j)
+        for (int64_t i = 0; i < d; ++i) hP[size_t(i) * kp + j] = get_elem(components, dt, j * d + i);
+    DBuf P(c.dev, sizeof(double) * dp * kp), muT(c.dev, dtype_size(dt) * dp);
+    dev_h2d(c.dev, P.p, hP.data(), P.bytes);
+    std::vector<char> hmu(dtype_size(dt) * dp, 0);
+    if (centering) std::memcpy(hmu.data(), means, dtype_size(dt) * d);
+    dev_h2d(c.dev, muT.p, hmu.data(), muT.bytes);
+    DBuf Y(c.dev, dtype_size(dt) * size_t(X.n) * kp);
+    op_gemm_xp(c.dev, dt, X.p, X.n, dp, X.ld, centering ? muT.p : nullptr, P.f64(), kp, kp, nullptr, Y.p, kp, nullptr);
+    emit(c, dt, Y.p, X.n, k, kp, y_out);
+    dev_sync(c.dev);
+}
+
+// inverse_transform (pca.rs:788-811)
+void inverse_transform(petal_ctx& c, const petal_matrix& y, const void* components, const void* means, int64_t k,
+                       int64_t d, bool centering, const petal_matrix& x_out) {
+    check_matrix(y, "input");
+    if (y.cols != k) invalid_input("# of columns should be " + std::to_string(k));  // pca.rs:798-803
+    const int dt = y.dtype;
+    if (y.rows == 0 || d == 0) { emit(c, dt, nullptr, y.rows, d, 0, x_out); return; }
+    DevMat Y = ingest(c, y);  // n x kp
+    const int64_t kp = Y.dp, dp = round_up(d, 16);
+    std::vector<double> hP(size_t(kp) * dp, 0.0);
+    for (int64_t j = 0; j < k; ++j)
+        for (int64_t i = 0; i < d; ++i) hP[size_t(j) * dp + i] = get_elem(components, dt, j * d + i);
+    DBuf P(c.dev, sizeof(double) * kp * dp), muT(c.dev, dtype_size(dt) * dp);
+    dev_h2d(c.dev, P.p, hP.data(), P.bytes);
+    std::vector<char> hmu(dtype_size(dt) * dp, 0);
+    if (centering) std::memcpy(hmu.data(), means, dtype_size(dt) * d);
+    dev_h2d(c.dev, muT.p, hmu.data(), muT.bytes);
+    DBuf Xo(c.dev, dtype_size(dt) * size_t(Y.n) * dp);
+    op_gemm_xp(c.dev, dt, Y.p, Y.n, kp, Y.ld, nullptr, P.f64(), dp, dp, centering ? muT.p : nullptr, Xo.p, dp, nullptr);
+    emit(c, dt, Xo.p, Y.n, d, dp, x_out);
+    dev_sync(c.dev);
+}
+
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// ica_par (ica.rs:319-361) on a device-resident, sample-major X1T (n x ncp).  W (device f64 nc x nc)
+// holds w_init on entry and the result on exit.  Returns n_iter.
+int64_t ica_loop(petal_ctx& c, int dt, const void* X1T, int64_t n, int64_t nc, int64_t ld, double n_total, DBuf& W,
+                 double tol, int64_t max_iter, int mode) {
+    DBuf W0(c.dev, W.bytes), GX(c.dev, sizeof(double) * (nc * nc + nc)), state(c.dev, 2 * sizeof(int));
+    dev_d2d(c.dev, W0.p, W.p, W.bytes);
+    op_symdecorr(c.dev, nc, W0.f64(), W.f64(), mode);  // ica.rs:329
+    dev_memset(c.dev, state.p, 0, state.bytes);
+    int hstate[2] = {0, 0};
+    const int64_t check_every = 4;  // converged iterations turn into no-ops on the device; poll the flag in batches
+    int64_t it = 0;
+    while (it < max_iter) {
+        const int64_t stop = std::min(max_iter, it + check_every);
+        for (; it < stop; ++it) {
+            dev_set_tag(c.dev, TAG_ICA);
+            op_ica_step(c.dev, dt, X1T, n, nc, ld, W.f64(), GX.f64(), state.as<int>());  // ica.rs:332-333
+            dev_set_tag(c.dev, TAG_NONE);
+            allreduce_f64(c, GX.f64(), nc * nc + nc, PETAL_SUM);
+            op_ica_tail(c.dev, nc, n_total, W.f64(), GX.f64(), mode, tol, state.as<int>(), int(it));  // ica.rs:334-358
+        }
+        dev_d2h(c.dev, hstate, state.p, sizeof(hstate));
+        dev_sync(c.dev);
+        if (hstate[0]) break;
+    }
+    const int64_t n_iter = hstate[0] ? hstate[1] : max_iter;
+    c.stats.n_iter = n_iter;
+    c.stats.ica_step_flops = 4.0 * double(nc) * nc * double(n);
+    c.stats.ica_step_bytes = double(dtype_size(dt)) * nc * double(n);
+    return n_iter;
+}
+
+void check_finite_w(const std::vector<double>& w) {
+    for (double v : w)
+        if (!std::isfinite(v)) linalg_error("cannot compute eigenvalues");  // the reference panics here (ica.rs:369)
+}
+
+}  // namespace
+
+// FastIca::inner_fit (ica.rs:167-221)
+void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, double tol, int64_t max_iter, int mode,
+                 const void* w_init, void* components, void* means, int64_t* n_iter, const petal_matrix* y_out) {
+    Timer timer;
+    dev_reset_timing(c.dev);
+    c.stats = petal_stats{};
+    check_matrix(x, "input");
+    const int dt = x.dtype;
+    RankInfo ri = rank_info(c, x.rows);
+    const int64_t n_total = int64_t(ri.n_total), d = x.cols;
+    if (n_iter) *n_iter = 0;
+    if (n_total == 0) return;  // ica.rs:174-176
+    int64_t nc = n_components > 0 ? n_components : std::min(n_total, d);  // ica.rs:173
+    if (nc > std::min(n_total, d)) invalid_input("n_components should be at most min(n_samples, n_features)");
+    if (nc == 0 || d == 0) return;
+    if (d > 1024) invalid_input("FastIca whitening on the device supports at most 1024 features");
+    if (w_init == nullptr) invalid_input("w_init is required");
+    DevMat X = ingest(c, x);
+    const int64_t n = X.n, dp = X.dp, ncp = round_up(nc, 16);
+    const size_t esz = dtype_size(dt);
+    DBuf mu64, muT;
+    column_means(c, X, ri.n_total, true, mu64, muT);
+
+    // whitening (ica.rs:189-208): left singular vectors / values of Xc^T == eigenpairs of Xc^T Xc
+    DBuf C(c.dev, sizeof(double) * dp * dp), U(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp);
+    DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp);
+    op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp);
+    allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
+    op_eigh(c.dev, C.f64(), dp, dp, U.f64(), dp, lam.f64());
+    op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
+    op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, 0.0);
+    op_dscale_cols(c.dev, U.f64(), dp, dp, dp, inv.f64());  // U[:, i] / sigma_i  == K^T (ica.rs:190-203)
+    DBuf KT(c.dev, sizeof(double) * dp * ncp);              // K^T, first nc columns, zero padded
+    dev_memset(c.dev, KT.p, 0, KT.bytes);
+    dev_copy2d(c.dev, KT.p, ncp * sizeof(double), U.p, dp * sizeof(double), size_t(nc) * sizeof(double), size_t(dp), 2);
+    DBuf KTs(c.dev, KT.bytes);                              // K^T sqrt(n) (ica.rs:204-208)
+    dev_d2d(c.dev, KTs.p, KT.p, KT.bytes);
+    op_dscal(c.dev, KTs.f64(), dp * ncp, std::sqrt(ri.n_total));
+    DBuf X1T(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * ncp);
+    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, KTs.f64(), ncp, ncp, nullptr, X1T.p, ncp, nullptr);
+
+    DBuf W(c.dev, sizeof(double) * nc * nc);
+    {
+        std::vector<double> h(size_t(nc) * nc);
+        for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
+        dev_h2d(c.dev, W.p, h.data(), W.bytes);
+    }
+    const int64_t iters = ica_loop(c, dt, X1T.p, n, nc, ncp, ri.n_total, W, tol, max_iter, mode);  // ica.rs:216
+    if (n_iter) *n_iter = iters;
+
+    // components = W K (ica.rs:217)
+    DBuf Cm(c.dev, sizeof(double) * nc * dp);
+    op_dgemm(c.dev, false, true, nc, dp, nc, 1.0, W.f64(), nc, KT.f64(), ncp, 0.0, Cm.f64(), dp);
+    std::vector<double> hC(size_t(nc) * dp), hmu(dp);
+    dev_d2h(c.dev, hC.data(), Cm.p, Cm.bytes);
+    dev_d2h(c.dev, hmu.data(), mu64.p, mu64.bytes);
+    dev_sync(c.dev);
+    check_finite_w(hC);
+    for (int64_t i = 0; i < nc; ++i)
+        for (int64_t j = 0; j < d; ++j) put_elem(components, dt, i * d + j, hC[size_t(i) * dp + j]);
+    for (int64_t j = 0; j < d; ++j) put_elem(means, dt, j, hmu[j]);
+    if (y_out) {  // fit_transform (ica.rs:155-156): (components . Xc^T)^T = Xc . components^T
+        DBuf CT(c.dev, sizeof(double) * dp * ncp);
+        std::vector<double> hCT(size_t(dp) * ncp, 0.0);
+        for (int64_t i = 0; i < nc; ++i)
+            for (int64_t j = 0; j < dp; ++j) hCT[size_t(j) * ncp + i] = hC[size_t(i) * dp + j];
+        dev_h2d(c.dev, CT.p, hCT.data(), CT.bytes);
+        op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, CT.f64(), ncp, ncp, nullptr, X1T.p, ncp, nullptr);
+        emit(c, dt, X1T.p, n, nc, ncp, *y_out);
+    }
+    finish_stats(c, timer);
+}
+
+// ica_par (ica.rs:319-361) with the crate's nc x n component-major input
+void ica_par(petal_ctx& c, const petal_matrix& x1, double tol, int64_t max_iter, int mode, const void* w_init,
+             void* w_out, int64_t* n_iter) {
+    Timer timer;
+    dev_reset_timing(c.dev);
+    c.stats = petal_stats{};
+    check_matrix(x1, "input");
+    const int dt = x1.dtype;
+    const int64_t nc = x1.rows, n = x1.cols;
+    if (nc == 0) { if (n_iter) *n_iter = 0; return; }
+    petal_matrix xt = x1;  // view the transpose: sample-major n x nc
+    xt.rows = n; xt.cols = nc; xt.row_stride = x1.col_stride; xt.col_stride = x1.row_stride;
+    RankInfo ri = rank_info(c, n);
+    DevMat X1T = ingest(c, xt);
+    DBuf keep;
+    const void* xp = X1T.p;
+    if (n == 0) { keep = DBuf(c.dev, 64); xp = keep.p; }
+    DBuf W(c.dev, sizeof(double) * nc * nc);
+    std::vector<double> h(size_t(nc) * nc);
+    for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
+    dev_h2d(c.dev, W.p, h.data(), W.bytes);
+    const int64_t iters = ica_loop(c, dt, xp, n, nc, X1T.ld, ri.n_total, W, tol, max_iter, mode);
+    dev_d2h(c.dev, h.data(), W.p, W.bytes);
+    dev_sync(c.dev);
+    check_finite_w(h);
+    for (int64_t i = 0; i < nc * nc; ++i) put_elem(w_out, dt, i, h[i]);
+    if (n_iter) *n_iter = iters;
+    finish_stats(c, timer);
+}
+
+void symmetric_decorrelation(petal_ctx& c, const void* w, int64_t nc, int dtype, int mode, void* out) {
+    if (nc <= 0) return;
+    std::vector<double> h(size_t(nc) * nc);
+    for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w, dtype, i);
+    DBuf Wi(c.dev, sizeof(double) * nc * nc), Wo(c.dev, sizeof(double) * nc * nc);
+    dev_h2d(c.dev, Wi.p, h.data(), Wi.bytes);
+    op_symdecorr(c.dev, nc, Wi.f64(), Wo.f64(), mode);
+    dev_d2h(c.dev, h.data(), Wo.p, Wo.bytes);
+    dev_sync(c.dev);
+    check_finite_w(h);
+    for (int64_t i = 0; i < nc * nc; ++i) put_elem(out, dtype, i, h[i]);
+}
+
+void logcosh(petal_ctx& c, const petal_matrix& x, const petal_matrix& g_out, void* gprime_out) {
+    check_matrix(x, "input");
+    const int dt = x.dtype;
+    DevMat X = ingest(c, x);
+    const int64_t r = X.n, cc = X.d;
+    if (r == 0) return;
+    DBuf G(c.dev, dtype_size(dt) * size_t(r) * X.dp), gp(c.dev, sizeof(double) * r);
+    op_logcosh_rows(c.dev, dt, X.p, r, cc, X.ld, G.p, X.dp, gp.f64());
+    std::vector<double> h(r);
+    dev_d2h(c.dev, h.data(), gp.p, gp.bytes);
+    emit(c, dt, G.p, r, cc, X.dp, g_out);
+    dev_sync(c.dev);
+    for (int64_t i = 0; i < r; ++i) put_elem(gprime_out, dt, i, cc ? h[i] / double(cc) : 0.0);  // ica.rs:391-396
+}
+
+void svd_flip(petal_ctx& c, const petal_matrix& u, const petal_matrix& vt) {
+    check_matrix(u, "u");
+    check_matrix(vt, "vt");
+    if (u.dtype != vt.dtype) invalid_input("u and vt differ in dtype");
+    const int dt = u.dtype;
+    const int64_t m = std::min(u.cols, vt.rows);  // zip of U columns and V^T rows (pca.rs:819)
+    if (m == 0 || u.rows == 0) return;
+    DevMat U = ingest(c, u);
+    std::vector<double> sg = flip_signs(c, dt, U.p, U.n, m, U.ld, 0);
+    // apply on the host-visible matrices through a device round trip of U and V^T
+    DevMat V = ingest(c, vt);
+    std::vector<double> su(U.dp, 1.0);
+    for (int64_t j = 0; j < m; ++j) su[j] = sg[j];
+    DBuf dsu(c.dev, sizeof(double) * U.dp);
+    dev_h2d(c.dev, dsu.p, su.data(), dsu.bytes);
+    DBuf Uc(c.dev, dtype_size(dt) * size_t(U.n) * U.dp);
+    dev_copy2d(c.dev, Uc.p, U.dp * dtype_size(dt), U.p, U.ld * dtype_size(dt), U.dp * dtype_size(dt), size_t(U.n), 2);
+    op_scale_cols(c.dev, dt, Uc.p, U.n, U.d, U.dp, dsu.f64());
+    emit(c, dt, Uc.p, U.n, U.d, U.dp, u);
+    // rows of V^T: scale row j by sg[j] == scale columns of V; do it through P = diag(sg) V^T on the small side
+    std::vector<double> hv(size_t(vt.rows) * vt.cols);
+    DBuf Vc(c.dev, dtype_size(dt) * size_t(V.n) * V.dp);
+    dev_copy2d(c.dev, Vc.p, V.dp * dtype_size(dt), V.p, V.ld * dtype_size(dt), V.dp * dtype_size(dt), size_t(V.n), 2);
+    // a row scale is a column scale of the transpose; V^T is tiny (m x d): finish on the host copy
+    std::vector<char> raw(dtype_size(dt) * size_t(V.n) * V.dp);
+    dev_d2h(c.dev, raw.data(), Vc.p, raw.size());
+    dev_sync(c.dev);
+    for (int64_t j = 0; j < m; ++j)
+        if (sg[j] < 0)
+            for (int64_t i = 0; i < V.d; ++i) put_elem(raw.data(), dt, j * V.dp + i, -get_elem(raw.data(), dt, j * V.dp + i));
+    dev_h2d(c.dev, Vc.p, raw.data(), raw.size());
+    emit(c, dt, Vc.p, V.n, V.d, V.dp, vt);
+    dev_sync(c.dev);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the two X-streaming GEMMs on their own (parity tests / roofline measurement)
+void gemm_xp(petal_ctx& c, const petal_matrix& x, const void* mu, const void* p, int64_t N, const void* bias,
+             const petal_matrix& z_out) {
+    Timer timer;
+    dev_reset_timing(c.dev);
+    c.stats = petal_stats{};
+    check_matrix(x, "input");
+    const int dt = x.dtype;
+    if (N < 0) invalid_input("negative parameter");
+    if (x.rows == 0 || N == 0) { emit(c, dt, nullptr, x.rows, N, 0, z_out); return; }
+    DevMat X = ingest(c, x);
+    const int64_t K = X.dp, NP = round_up(N, 16);
+    std::vector<double> hP(size_t(K) * NP, 0.0);
+    for (int64_t i = 0; i < x.cols; ++i)
+        for (int64_t j = 0; j < N; ++j) hP[size_t(i) * NP + j] = get_elem(p, dt, i * N + j);
+    DBuf P(c.dev, sizeof(double) * K * NP), muT(c.dev, dtype_size(dt) * K), bT(c.dev, dtype_size(dt) * NP);
+    dev_h2d(c.dev, P.p, hP.data(), P.bytes);
+    std::vector<char> hmu(dtype_size(dt) * K, 0), hb(dtype_size(dt) * NP, 0);
+    if (mu) std::memcpy(hmu.data(), mu, dtype_size(dt) * x.cols);
+    if (bias) std::memcpy(hb.data(), bias, dtype_size(dt) * N);
+    dev_h2d(c.dev, muT.p, hmu.data(), muT.bytes);
+    dev_h2d(c.dev, bT.p, hb.data(), bT.bytes);
+    DBuf Z(c.dev, dtype_size(dt) * size_t(X.n) * NP);
+    c.stats.pass_flops = 2.0 * double(X.n) * double(x.cols) * double(N);
+    c.stats.pass_bytes = double(dtype_size(dt)) * (double(X.n) * x.cols + double(X.n) * N + double(x.cols) * N);
+    dev_set_tag(c.dev, TAG_XP);
+    op_gemm_xp(c.dev, dt, X.p, X.n, K, X.ld, mu ? muT.p : nullptr, P.f64(), NP, NP, bias ? bT.p : nullptr, Z.p, NP, nullptr);
+    dev_set_tag(c.dev, TAG_NONE);
+    emit(c, dt, Z.p, X.n, N, NP, z_out);
+    finish_stats(c, timer);
+}
+
+void gemm_atb(petal_ctx& c, const petal_matrix& a, const void* mu_a, const petal_matrix* b, const void* mu_b, double* c_out) {
+    Timer timer;
+    dev_reset_timing(c.dev);
+    c.stats = petal_stats{};
+    check_matrix(a, "a");
+    if (b) {
+        check_matrix(*b, "b");
+        if (b->rows != a.rows || b->dtype != a.dtype) invalid_input("a and b differ in rows or dtype");
+    }
+    const int dt = a.dtype;
+    const int64_t M = a.cols, N = b ? b->cols : a.cols;
+    if (M == 0 || N == 0) return;
+    if (a.rows == 0) { std::memset(c_out, 0, sizeof(double) * M * N); return; }
+    DevMat A = ingest(c, a);
+    DevMat B;
+    if (b) B = ingest(c, *b);
+    const DevMat& Bm = b ? B : A;
+    DBuf muA(c.dev, dtype_size(dt) * A.dp), muB(c.dev, dtype_size(dt) * Bm.dp);
+    std::vector<char> ha(dtype_size(dt) * A.dp, 0), hb(dtype_size(dt) * Bm.dp, 0);
+    if (mu_a) std::memcpy(ha.data(), mu_a, dtype_size(dt) * M);
+    if (mu_b) std::memcpy(hb.data(), mu_b, dtype_size(dt) * N);
+    dev_h2d(c.dev, muA.p, ha.data(), muA.bytes);
+    dev_h2d(c.dev, muB.p, hb.data(), muB.bytes);
+    DBuf C(c.dev, sizeof(double) * A.dp * Bm.dp);
+    c.stats.pass_flops = 2.0 * double(A.n) * double(M) * double(N);
+    c.stats.pass_bytes = double(dtype_size(dt)) * (double(A.n) * M + double(A.n) * N + double(M) * N);
+    dev_set_tag(c.dev, TAG_ATB);
+    op_gemm_atb(c.dev, dt, A.p, A.ld, A.dp, mu_a ? muA.p : nullptr, Bm.p, Bm.ld, Bm.dp, mu_b ? muB.p : nullptr, A.n, C.f64(), Bm.dp);
+    dev_set_tag(c.dev, TAG_NONE);
+    std::vector<double> h(size_t(A.dp) * Bm.dp);
+    dev_d2h(c.dev, h.data(), C.p, C.bytes);
+    dev_sync(c.dev);
+    for (int64_t i = 0; i < M; ++i)
+        for (int64_t j = 0; j < N; ++j) c_out[i * N + j] = h[size_t(i) * Bm.dp + j];
+    finish_stats(c, timer);
+}
+
+}  // namespace petal

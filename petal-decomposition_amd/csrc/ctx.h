@@ -1,0 +1,88 @@
+// ctx.h -- petal_ctx and small host-side helpers shared by algo.cpp / api.cpp.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/petal_hip.h"
+#include "ops.h"
+
+struct petal_ctx {
+    petal::Dev* dev = nullptr;
+    std::string err;
+    petal_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    int rank = 0, world = 1;
+    bool profiling = false;
+    petal_stats stats{};
+};
+
+namespace petal {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+[[noreturn]] inline void invalid_input(const std::string& m) { throw Error(PETAL_INVALID_INPUT, m); }
+[[noreturn]] inline void linalg_error(const std::string& m) { throw Error(PETAL_LINALG_ERROR, m); }
+[[noreturn]] inline void device_error(const std::string& m) { throw Error(PETAL_DEVICE_ERROR, m); }
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// RAII device buffer from the ctx's caching allocator
+struct DBuf {
+    Dev* dev = nullptr;
+    void* p = nullptr;
+    size_t bytes = 0;
+    DBuf() = default;
+    DBuf(Dev* d, size_t b) : dev(d), p(b ? dev_alloc(d, b) : nullptr), bytes(b) {}
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    DBuf(DBuf&& o) noexcept : dev(o.dev), p(o.p), bytes(o.bytes) { o.p = nullptr; }
+    DBuf& operator=(DBuf&& o) noexcept {
+        if (this != &o) { release(); dev = o.dev; p = o.p; bytes = o.bytes; o.p = nullptr; }
+        return *this;
+    }
+    ~DBuf() { release(); }
+    void release() { if (p) dev_free(dev, p); p = nullptr; }
+    double* f64() const { return static_cast<double*>(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// a row-major matrix in device memory, K-dimension padded to a multiple of 16 with zeros
+struct DevMat {
+    const void* p = nullptr;
+    int64_t n = 0, d = 0, dp = 0, ld = 0;  // rows, real cols, padded cols, leading dimension (elements)
+    int dtype = F32;
+    DBuf owned;                             // empty when zero-copy
+};
+
+// host algorithms (algo.cpp)
+DevMat ingest(petal_ctx& c, const petal_matrix& x);
+void   emit(petal_ctx& c, int dtype, const void* src, int64_t n, int64_t cols, int64_t ld, const petal_matrix& out);
+void   allreduce_f64(petal_ctx& c, double* dev_buf, int64_t count, int op);
+
+void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversample, int64_t n_iter, bool centering,
+              const void* omega, void* components, void* means, void* singular, void* total_variance,
+              const petal_matrix* y_out);
+void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, void* components, void* means,
+             void* singular, void* total_variance, const petal_matrix* y_out);
+void transform(petal_ctx& c, const petal_matrix& x, const void* components, const void* means, int64_t k, int64_t d,
+               bool centering, const petal_matrix& y_out);
+void inverse_transform(petal_ctx& c, const petal_matrix& y, const void* components, const void* means, int64_t k,
+                       int64_t d, bool centering, const petal_matrix& x_out);
+void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, double tol, int64_t max_iter, int mode,
+                 const void* w_init, void* components, void* means, int64_t* n_iter, const petal_matrix* y_out);
+void ica_par(petal_ctx& c, const petal_matrix& x1, double tol, int64_t max_iter, int mode, const void* w_init,
+             void* w_out, int64_t* n_iter);
+void symmetric_decorrelation(petal_ctx& c, const void* w, int64_t nc, int dtype, int mode, void* out);
+void logcosh(petal_ctx& c, const petal_matrix& x, const petal_matrix& g_out, void* gprime_out);
+void svd_flip(petal_ctx& c, const petal_matrix& u, const petal_matrix& vt);
+void gemm_xp(petal_ctx& c, const petal_matrix& x, const void* mu, const void* p, int64_t N, const void* bias,
+             const petal_matrix& z_out);
+void gemm_atb(petal_ctx& c, const petal_matrix& a, const void* mu_a, const petal_matrix* b, const void* mu_b, double* c_out);
+
+}  // namespace petal

@@ -1,0 +1,1289 @@
+// hip_ops.hip -- gfx950 (MI355X / CDNA4) implementation of the device-operation layer (ops.h).
+//
+// Kernel inventory (DESIGN.md has the roofline of each):
+//   k_xp_mfma     K1  Z = (X - mu) . P        tall-skinny fp32 MFMA (v_mfma_f32_16x16x4_f32); X streamed
+//                                             straight into MFMA A-fragments with 16-B loads, P pre-packed
+//                                             in fragment order; fused centring, bias and sum((X-mu)^2)
+//   k_atb_mfma    K2  C = (A - muA)^T . B     split-K fp32 MFMA over row chunks -> fp32 partial slabs,
+//                                             combined in fp64 by k_reduce_partials (deterministic, no atomics)
+//   k_ica_mfma    K7  fused FastICA step      W.X1 -> tanh -> G.X1^T + sum(1-g^2) per 16-sample tile, S tile
+//                                             never leaves the accumulators
+//   k_chol_inv / k_eigh / k_symdecorr / k_ica_tail   one-workgroup fp64 small-matrix kernels
+//   *_simple      generic (any shape, f32/f64, fp64 accumulate) kernels for small / unaligned / f64 inputs
+//
+// wave = 64 lanes everywhere.  MFMA 16x16x4 f32 fragment maps (cdna_hip_programming.md section 3):
+//   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15];
+//   C/D: reg r of lane l is D[row = 4 (l >> 4) + r][col = l & 15].
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "ops.h"
+
+namespace petal {
+
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);  \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ================================================================================================
+// Dev
+// ================================================================================================
+struct Dev {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    int tag = 0;
+    std::multimap<size_t, void*> free_list;
+    std::unordered_map<void*, size_t> live;
+    std::vector<hipEvent_t> ev_pool;
+    struct Rec { int tag; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    KernelTiming acc;
+};
+
+Dev* dev_create(int device, void* stream, char* err, size_t errlen) {
+    auto fail = [&](const std::string& m) -> Dev* {
+        if (err && errlen) std::snprintf(err, errlen, "%s", m.c_str());
+        return nullptr;
+    };
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(std::string("no HIP device visible (") + hipGetErrorString(e) + "); this library has no CPU fallback");
+    if (device < 0 || device >= count) return fail("device index out of range");
+    if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail("hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+    Dev* d = new Dev();
+    d->device = device;
+    if (stream) {
+        d->stream = static_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete d;
+            return fail("hipStreamCreate failed");
+        }
+        d->own_stream = true;
+    }
+    return d;
+}
+
+void dev_destroy(Dev* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    (void)hipStreamSynchronize(d->stream);
+    for (auto& kv : d->free_list) (void)hipFree(kv.second);
+    for (auto& kv : d->live) (void)hipFree(kv.first);
+    for (auto& r : d->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto ev : d->ev_pool) (void)hipEventDestroy(ev);
+    if (d->own_stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+void* dev_stream(Dev* d) { return d->stream; }
+
+void* dev_alloc(Dev* d, size_t bytes) {
+    const size_t sz = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+    auto it = d->free_list.find(sz);
+    void* p = nullptr;
+    if (it != d->free_list.end()) {
+        p = it->second;
+        d->free_list.erase(it);
+    } else {
+        hipError_t e = hipMalloc(&p, sz);
+        if (e != hipSuccess) {  // drop the cache and retry once
+            (void)hipStreamSynchronize(d->stream);
+            for (auto& kv : d->free_list) (void)hipFree(kv.second);
+            d->free_list.clear();
+            HIP_CHECK(hipMalloc(&p, sz));
+        }
+    }
+    d->live[p] = sz;
+    return p;
+}
+
+void dev_free(Dev* d, void* p) {
+    if (!p) return;
+    auto it = d->live.find(p);
+    if (it == d->live.end()) return;
+    // stream-ordered reuse: every consumer of this block was enqueued on d->stream before this call
+    d->free_list.emplace(it->second, p);
+    d->live.erase(it);
+}
+
+void dev_memset(Dev* d, void* p, int v, size_t bytes) { if (bytes) HIP_CHECK(hipMemsetAsync(p, v, bytes, d->stream)); }
+void dev_h2d(Dev* d, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
+    HIP_CHECK(hipStreamSynchronize(d->stream));  // callers pass short-lived pageable buffers
+}
+void dev_d2h(Dev* d, void* dst, const void* src, size_t bytes) {
+    if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
+}
+void dev_d2d(Dev* d, void* dst, const void* src, size_t bytes) {
+    if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, d->stream));
+}
+void dev_copy2d(Dev* d, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int kind) {
+    if (!width || !height) return;
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIP_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, k, d->stream));
+    if (kind == 0) HIP_CHECK(hipStreamSynchronize(d->stream));
+}
+void dev_sync(Dev* d) { HIP_CHECK(hipStreamSynchronize(d->stream)); }
+void dev_set_profiling(Dev* d, bool on) { d->profiling = on; }
+void dev_set_tag(Dev* d, int tag) { d->tag = tag; }
+
+static hipEvent_t get_event(Dev* d) {
+    if (!d->ev_pool.empty()) { hipEvent_t e = d->ev_pool.back(); d->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+static void resolve_events(Dev* d) {
+    for (auto& r : d->recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { d->acc.ms[r.tag] += ms; d->acc.launches[r.tag] += 1; }
+        d->ev_pool.push_back(r.a);
+        d->ev_pool.push_back(r.b);
+    }
+    d->recs.clear();
+}
+void dev_reset_timing(Dev* d) {
+    if (!d->recs.empty()) { (void)hipStreamSynchronize(d->stream); resolve_events(d); }
+    d->acc = KernelTiming{};
+}
+KernelTiming dev_timing(Dev* d) {
+    if (!d->recs.empty()) { HIP_CHECK(hipStreamSynchronize(d->stream)); resolve_events(d); }
+    return d->acc;
+}
+// brackets the dominant kernel of a tagged op with events on the launch stream
+struct TagScope {
+    Dev* d; bool on; hipEvent_t a{}, b{};
+    explicit TagScope(Dev* dev) : d(dev), on(dev->profiling && dev->tag > 0 && dev->tag < TAG_COUNT) {
+        if (on) { a = get_event(d); b = get_event(d); HIP_CHECK(hipEventRecord(a, d->stream)); }
+    }
+    void stop() {
+        if (on) { HIP_CHECK(hipEventRecord(b, d->stream)); d->recs.push_back({d->tag, a, b}); on = false; }
+    }
+};
+
+static inline void launch_check() { HIP_CHECK(hipGetLastError()); }
+static inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
+
+// ================================================================================================
+// generic kernels (any shape, T = float | double, fp64 accumulation)
+// ================================================================================================
+template <class T>
+__global__ void k_pack_strided(const T* __restrict__ src, int64_t n, int64_t d, int64_t rs, int64_t cs, T* __restrict__ dst,
+                               int64_t ld, int64_t dpad) {
+    const int64_t j = blockIdx.y * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.x;
+    if (j >= dpad) return;
+    dst[i * ld + j] = j < d ? src[i * rs + j * cs] : T(0);
+}
+template <class T>
+__global__ void k_unpack_strided(const T* __restrict__ src, int64_t n, int64_t d, int64_t ld, T* __restrict__ dst, int64_t rs,
+                                 int64_t cs) {
+    const int64_t j = blockIdx.y * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.x;
+    if (j >= d) return;
+    dst[i * rs + j * cs] = src[i * ld + j];
+}
+
+constexpr int CS_ROWS = 128;  // rows per block of the column-sum / column-absmax first stage
+template <class T>
+__global__ void k_colsum_part(const T* __restrict__ X, int64_t n, int64_t d, int64_t ldx, double* __restrict__ part) {
+    const int64_t j = blockIdx.y * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = min(n, r0 + CS_ROWS);
+    double s = 0;
+    for (int64_t i = r0; i < r1; ++i) s += (double)X[i * ldx + j];
+    part[(int64_t)blockIdx.x * d + j] = s;
+}
+__global__ void k_sum_parts(const double* __restrict__ part, int64_t nparts, int64_t count, double* __restrict__ out) {
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    double s = 0;
+    for (int64_t p = 0; p < nparts; ++p) s += part[p * count + j];
+    out[j] = s;
+}
+__global__ void k_reduce_partials_f32(const float* __restrict__ part, int64_t nparts, int64_t M, int64_t N,
+                                      double* __restrict__ C, int64_t ldc) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= M * N) return;
+    double s = 0;
+    for (int64_t p = 0; p < nparts; ++p) s += (double)part[p * M * N + e];
+    C[(e / N) * ldc + (e % N)] = s;
+}
+__global__ void k_add_scalar_parts(const double* __restrict__ part, int64_t nparts, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0;
+        for (int64_t p = 0; p < nparts; ++p) s += part[p];
+        out[0] += s;
+    }
+}
+
+template <class T>
+__global__ void k_xp_simple(const T* __restrict__ X, int64_t n, int64_t K, int64_t ldx, const T* __restrict__ mu,
+                            const double* __restrict__ P, int64_t N, int64_t ldp, const T* __restrict__ bias,
+                            T* __restrict__ Z, int64_t ldz, double* __restrict__ ss_part) {
+    const int64_t j = blockIdx.y * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.x;
+    double acc = 0, ss = 0;
+    const bool want_ss = ss_part != nullptr && blockIdx.y == 0 && threadIdx.x == 0;
+    if (j < N || want_ss) {
+        for (int64_t k = 0; k < K; ++k) {
+            T xv = X[i * ldx + k];
+            if (mu) xv = xv - mu[k];
+            const double a = (double)xv;
+            if (j < N) acc += a * (sizeof(T) == 4 ? (double)(float)P[k * ldp + j] : P[k * ldp + j]);
+            ss += a * a;
+        }
+    }
+    if (j < N) Z[i * ldz + j] = (T)(acc + (bias ? (double)bias[j] : 0.0));
+    if (want_ss) ss_part[i] = ss;
+}
+
+constexpr int ATB_S_ROWS = 256;
+template <class T>
+__global__ void k_atb_simple(const T* __restrict__ A, int64_t lda, int64_t M, const T* __restrict__ muA,
+                             const T* __restrict__ B, int64_t ldb, int64_t N, const T* __restrict__ muB, int64_t n,
+                             double* __restrict__ part) {
+    const int64_t j = blockIdx.y * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t m = blockIdx.z * (int64_t)blockDim.y + threadIdx.y;
+    if (j >= N || m >= M) return;
+    const int64_t r0 = (int64_t)blockIdx.x * ATB_S_ROWS, r1 = min(n, r0 + ATB_S_ROWS);
+    const T ma = muA ? muA[m] : T(0), mb = muB ? muB[j] : T(0);
+    double s = 0;
+    for (int64_t i = r0; i < r1; ++i) s += (double)(T)(A[i * lda + m] - ma) * (double)(T)(B[i * ldb + j] - mb);
+    part[((int64_t)blockIdx.x * M + m) * N + j] = s;
+}
+__global__ void k_reduce_partials_f64(const double* __restrict__ part, int64_t nparts, int64_t M, int64_t N,
+                                      double* __restrict__ C, int64_t ldc) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= M * N) return;
+    double s = 0;
+    for (int64_t p = 0; p < nparts; ++p) s += part[p * M * N + e];
+    C[(e / N) * ldc + (e % N)] = s;
+}
+
+template <class T>
+__global__ void k_absmax_part(const T* __restrict__ U, int64_t n, int64_t L, int64_t ldu, double* __restrict__ pmax,
+                              double* __restrict__ pidx, double* __restrict__ psgn) {
+    const int64_t j = blockIdx.y * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= L) return;
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = min(n, r0 + CS_ROWS);
+    double best = -1.0, bi = 0.0, bs = 1.0;
+    for (int64_t i = r0; i < r1; ++i) {
+        const double v = (double)U[i * ldu + j], a = fabs(v);
+        if (i == r0 || a > best) { best = a; bi = (double)i; bs = signbit(v) ? -1.0 : 1.0; }
+    }
+    const int64_t o = (int64_t)blockIdx.x * L + j;
+    pmax[o] = best; pidx[o] = bi; psgn[o] = bs;
+}
+__global__ void k_absmax_final(const double* __restrict__ pmax, const double* __restrict__ pidx, const double* __restrict__ psgn,
+                               int64_t nparts, int64_t L, int64_t row_offset, double* __restrict__ omax,
+                               double* __restrict__ oidx, double* __restrict__ osgn) {
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= L) return;
+    double best = -1.0, bi = INFINITY, bs = 1.0;
+    for (int64_t p = 0; p < nparts; ++p) {  // chunks in row order + strict '>' keeps the FIRST maximum (pca.rs:830)
+        const double a = pmax[p * L + j];
+        if (p == 0 || a > best) { best = a; bi = pidx[p * L + j] + (double)row_offset; bs = psgn[p * L + j]; }
+    }
+    omax[j] = best; oidx[j] = bi; osgn[j] = bs;
+}
+template <class T>
+__global__ void k_scale_cols(T* __restrict__ A, int64_t n, int64_t L, int64_t lda, const double* __restrict__ s) {
+    const int64_t j = blockIdx.y * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.x;
+    if (j < L) A[i * lda + j] = (T)((double)A[i * lda + j] * s[j]);
+}
+template <class T>
+__global__ void k_logcosh_rows(const T* __restrict__ X, int64_t r, int64_t c, int64_t ldx, T* __restrict__ G, int64_t ldg,
+                               double* __restrict__ gp) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= r) return;
+    double s = 0;
+    for (int64_t j = 0; j < c; ++j) {
+        const double g = tanh((double)X[i * ldx + j]);
+        G[i * ldg + j] = (T)g;
+        s += 1.0 - g * g;
+    }
+    gp[i] = s;
+}
+
+// ================================================================================================
+// K1: Z = (X - mu) . P + bias   -- fp32 MFMA, X streamed HBM -> VGPR -> MFMA
+// ================================================================================================
+// P is packed in B-fragment order: Ppk[((c * NTtot + nt) * 64 + lane) * 4 + s] = P[16 c + 4 (lane>>4) + s][16 nt + (lane&15)]
+// so that one 16-B load per lane yields the B operands of the four MFMA k-steps of a 16-deep K chunk.
+// The matching A fragment is one 16-B load per lane: X[row][16 c + 4 (lane>>4) + 0..3]  (k order inside the
+// chunk is permuted identically on both operands).
+__global__ void k_pack_p(const double* __restrict__ P, int64_t K, int64_t N, int64_t ldp, float* __restrict__ Ppk, int NTtot) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // one float4 slot per thread
+    const int64_t total = (K / 16) * NTtot * 64;
+    if (e >= total) return;
+    const int lane = int(e & 63);
+    const int64_t cn = e >> 6;
+    const int nt = int(cn % NTtot);
+    const int64_t c = cn / NTtot;
+    const int q = lane >> 4, j = lane & 15;
+    const int64_t col = 16 * (int64_t)nt + j;
+    f32x4 v;
+    for (int s = 0; s < 4; ++s) {
+        const int64_t k = 16 * c + 4 * q + s;
+        v[s] = (col < N && k < K) ? (float)P[k * ldp + col] : 0.0f;
+    }
+    reinterpret_cast<f32x4*>(Ppk)[e] = v;
+}
+
+template <int RT, int NT, bool CENTER, bool SUMSQ>
+__global__ __launch_bounds__(256) void k_xp_mfma(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
+                                                 const float* __restrict__ mu, const float* __restrict__ Ppk, int NTtot,
+                                                 int nt0, int N, const float* __restrict__ bias, float* __restrict__ Z,
+                                                 int64_t ldz, double* __restrict__ ss_part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+    if (row0 >= n) {
+        if (SUMSQ && lane == 0) ss_part[(int64_t)blockIdx.x * 4 + wave] = 0.0;
+        return;
+    }
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xrow[RT];
+    bool rvalid[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int64_t r = row0 + 16 * t + i;
+        rvalid[t] = r < n;
+        xrow[t] = X + (rvalid[t] ? r : (n - 1)) * ldx + 4 * q;
+    }
+    const f32x4* pb = reinterpret_cast<const f32x4*>(Ppk) + (int64_t)nt0 * 64 + lane;
+    float ssq = 0.f;
+    const int nchunk = K >> 4;
+    f32x4 a[RT], b[NT], m4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const f32x4*>(xrow[t]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) b[u] = pb[(int64_t)u * 64];
+    if (CENTER) m4 = *reinterpret_cast<const f32x4*>(mu + 4 * q);
+    for (int c = 0; c < nchunk; ++c) {
+        f32x4 an[RT], bn[NT], mn = m4;
+        const int cn = (c + 1 < nchunk) ? c + 1 : c;  // prefetch the next chunk (re-reads the last one at the end)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) an[t] = *reinterpret_cast<const f32x4*>(xrow[t] + 16 * cn);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) bn[u] = pb[((int64_t)cn * NTtot + u) * 64];
+        if (CENTER) mn = *reinterpret_cast<const f32x4*>(mu + 16 * cn + 4 * q);
+        if (CENTER) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) a[t] -= m4;
+        }
+        if (SUMSQ) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+                if (rvalid[t]) ssq += a[t][0] * a[t][0] + a[t][1] * a[t][1] + a[t][2] * a[t][2] + a[t][3] * a[t][3];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b[u][s], acc[t][u], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) a[t] = an[t];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) b[u] = bn[u];
+        m4 = mn;
+    }
+    // epilogue: D[row = 4 q + r][col = i] per tile
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int col = 16 * (nt0 + u) + i;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 16 * t + 4 * q + r;
+                if (row < n) Z[row * ldz + col] = acc[t][u][r] + bv;
+            }
+    }
+    if (SUMSQ) {
+        double s = (double)ssq;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) ss_part[(int64_t)blockIdx.x * 4 + wave] = s;
+    }
+}
+
+// ================================================================================================
+// K2: C = (A - muA)^T . (B - muB)  -- split-K fp32 MFMA over row chunks, fp32 partial slabs
+// ================================================================================================
+// A wave owns 64 columns of A (4 m-tiles) x 16*NT columns of B and a contiguous row chunk.  One 16-B load
+// per lane of A gives the A fragments of the 4 m-tiles of a 4-row k-step (tile t, row i  <->  m = m0 + 4 i + t);
+// 16-B loads of B give col tiles in groups of four (tile 4 g + e, col j  <->  col = 64 g + 4 j + e) plus
+// scalar loads for the NT % 4 remaining tiles.
+template <int NT, bool CA, bool CB>
+__global__ __launch_bounds__(256) void k_atb_mfma(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
+                                                  const float* __restrict__ B, int64_t ldb, int N, int n0col,
+                                                  const float* __restrict__ muB, int64_t n, int64_t chunk,
+                                                  float* __restrict__ part, int Npart) {
+    constexpr int G4 = NT / 4, R1 = NT % 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int m0 = (blockIdx.x * 4 + wave) * 64;
+    if (m0 >= M) return;
+    const int64_t rbeg = (int64_t)blockIdx.y * chunk, rend = min(n, rbeg + chunk);
+    const bool mvalid = (m0 + 4 * i) < M;
+    bool gvalid[G4 > 0 ? G4 : 1], evalid[R1 > 0 ? R1 : 1];
+#pragma unroll
+    for (int g = 0; g < G4; ++g) gvalid[g] = (n0col + 64 * g + 4 * i) < N;
+#pragma unroll
+    for (int e = 0; e < R1; ++e) evalid[e] = (n0col + 64 * G4 + 16 * e + i) < N;
+    f32x4 ma = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (CA && mvalid) ma = *reinterpret_cast<const f32x4*>(muA + m0 + 4 * i);
+    f32x4 mb4[G4 > 0 ? G4 : 1];
+    float mb1[R1 > 0 ? R1 : 1];
+    if (CB) {
+#pragma unroll
+        for (int g = 0; g < G4; ++g) mb4[g] = gvalid[g] ? *reinterpret_cast<const f32x4*>(muB + n0col + 64 * g + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < R1; ++e) mb1[e] = evalid[e] ? muB[n0col + 64 * G4 + 16 * e + i] : 0.f;
+    }
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap = A + m0 + 4 * i;
+    const float* bp = B + n0col;
+    constexpr int UN = 4;  // k-steps (of 4 rows) per loop iteration
+    for (int64_t r0 = rbeg; r0 < rend; r0 += 4 * UN) {
+        f32x4 av[UN], b4[UN][G4 > 0 ? G4 : 1];
+        float b1[UN][R1 > 0 ? R1 : 1];
+#pragma unroll
+        for (int s = 0; s < UN; ++s) {
+            const int64_t r = r0 + 4 * s + q;
+            const bool rv = r < rend;
+            const int64_t rc = rv ? r : rbeg;
+            av[s] = (rv && mvalid) ? *reinterpret_cast<const f32x4*>(ap + rc * lda) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (CA && rv && mvalid) av[s] -= ma;
+#pragma unroll
+            for (int g = 0; g < G4; ++g) {
+                b4[s][g] = (rv && gvalid[g]) ? *reinterpret_cast<const f32x4*>(bp + rc * ldb + 64 * g + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (CB && rv && gvalid[g]) b4[s][g] -= mb4[g];
+            }
+#pragma unroll
+            for (int e = 0; e < R1; ++e) {
+                b1[s][e] = (rv && evalid[e]) ? bp[rc * ldb + 64 * G4 + 16 * e + i] : 0.f;
+                if (CB && rv && evalid[e]) b1[s][e] -= mb1[e];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < UN; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int g = 0; g < G4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[t][4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], b4[s][g][e], acc[t][4 * g + e], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < R1; ++e)
+                    acc[t][4 * G4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], b1[s][e], acc[t][4 * G4 + e], 0, 0, 0);
+            }
+    }
+    // D[row = 4 q + r][col = i] of tile (t, u):  m = m0 + 4 (4 q + r) + t;  col from the B grouping
+    float* out = part + (int64_t)blockIdx.y * M * Npart;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * (4 * q + r) + t;
+            if (m >= M) continue;
+#pragma unroll
+            for (int g = 0; g < G4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int col = n0col + 64 * g + 4 * i + e;
+                    if (col < N) out[(int64_t)m * Npart + col] = acc[t][4 * g + e][r];
+                }
+#pragma unroll
+            for (int e = 0; e < R1; ++e) {
+                const int col = n0col + 64 * G4 + 16 * e + i;
+                if (col < N) out[(int64_t)m * Npart + col] = acc[t][4 * G4 + e][r];
+            }
+        }
+}
+
+// ================================================================================================
+// K7: fused FastICA step (ica.rs:332-333) -- per 16-sample tile: S = X1 . W^T (MFMA) -> tanh ->
+// D += G^T . X1 (MFMA) and gp += sum(1 - g^2); partial D / gp per wave, combined in fp64.
+// ================================================================================================
+__device__ __forceinline__ float tanh_fast(float x) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates correctly at +-inf; |abs err| ~ 1e-7
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+// Wpk[((kc * NT + nt) * 64 + lane) * 4 + s] = W[16 nt + (lane&15)][16 kc + 4 (lane>>4) + s]   (B = W^T)
+__global__ void k_pack_w(const double* __restrict__ W, int nc, float* __restrict__ Wpk, int NT) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NT * NT * 64) return;
+    const int lane = e & 63, cn = e >> 6, nt = cn % NT, kc = cn / NT, q = lane >> 4, j = lane & 15;
+    f32x4 v;
+    for (int s = 0; s < 4; ++s) {
+        const int comp = 16 * nt + j, k = 16 * kc + 4 * q + s;
+        v[s] = (comp < nc && k < nc) ? (float)W[comp * nc + k] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(Wpk)[e] = v;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_ica_mfma(const float* __restrict__ X1T, int64_t n, int64_t ld,
+                                                  const float* __restrict__ Wpk, int64_t tiles_per_wave,
+                                                  float* __restrict__ part, const int* __restrict__ state) {
+    if (state && state[0]) return;
+    constexpr int NCP = 16 * NT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    f32x4 wf[NT][NT];  // [kc][nt]
+#pragma unroll
+    for (int kc = 0; kc < NT; ++kc)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) wf[kc][u] = reinterpret_cast<const f32x4*>(Wpk)[(kc * NT + u) * 64 + lane];
+    f32x4 dacc[NT][NT];  // [component tile][x tile]
+    float gpa[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        gpa[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) dacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t t0 = wid * tiles_per_wave, t1 = min((n + 15) / 16, t0 + tiles_per_wave);
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        const int64_t r0 = tile * 16;
+        // A layout: lane (i, q) <- X1[r0 + i][16 kc + 4 q .. +3]
+        const int64_t ra = r0 + i;
+        const bool va = ra < n;
+        f32x4 xa[NT];
+#pragma unroll
+        for (int kc = 0; kc < NT; ++kc)
+            xa[kc] = va ? *reinterpret_cast<const f32x4*>(X1T + ra * ld + 16 * kc + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // B layout for the second product: lane (j = i, q), k-step s <- X1[r0 + 4 q + s][16 b + j]
+        float xb[4][NT];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t rb = r0 + 4 * q + s;
+            const bool vb = rb < n;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) xb[s][b] = vb ? X1T[rb * ld + 16 * b + i] : 0.f;
+        }
+        f32x4 sacc[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) sacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < NT; ++kc)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    sacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc][s], wf[kc][u][s], sacc[u], 0, 0, 0);
+        // sacc[u][r] = S[sample r0 + 4 q + r][component 16 u + i]
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float g = tanh_fast(sacc[u][r]);
+                const bool v = (r0 + 4 * q + r) < n;
+                sacc[u][r] = v ? g : 0.f;
+                gpa[u] += v ? (1.0f - g * g) : 0.f;
+            }
+        // D[component][x] += sum_samples G[sample][component] X1[sample][x]:
+        // A operand (i = component, k = q) of k-step s is G[r0 + 4 q + s][16 a + i] = sacc[a][s]
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    dacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[a][s], xb[s][b], dacc[a][b], 0, 0, 0);
+    }
+    // partial slab per wave: [NCP*NCP D | NCP gp]
+    float* out = part + wid * (NCP * NCP + NCP);
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(16 * a + 4 * q + r) * NCP + 16 * b + i] = dacc[a][b][r];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        float g = gpa[a];
+        g += __shfl_xor(g, 16, 64);
+        g += __shfl_xor(g, 32, 64);
+        if (q == 0) out[NCP * NCP + 16 * a + i] = g;
+    }
+}
+// combine the per-wave slabs in fp64 and drop the padding: GX_gp = [nc*nc | nc]
+__global__ void k_ica_reduce(const float* __restrict__ part, int64_t nparts, int NCP, int nc, double* __restrict__ out,
+                             const int* __restrict__ state) {
+    if (state && state[0]) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nc * nc + nc) return;
+    const int64_t slab = (int64_t)NCP * NCP + NCP;
+    const int src = e < nc * nc ? (e / nc) * NCP + (e % nc) : NCP * NCP + (e - nc * nc);
+    double s = 0;
+    for (int64_t p = 0; p < nparts; ++p) s += (double)part[p * slab + src];
+    out[e] = s;
+}
+
+// generic FastICA step: one block per chunk of 64 samples, fp64
+template <class T>
+__global__ void k_ica_simple(const T* __restrict__ X1T, int64_t n, int nc, int64_t ld, const double* __restrict__ W,
+                             double* __restrict__ part, const int* __restrict__ state) {
+    if (state && state[0]) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* g = reinterpret_cast<double*>(smem_raw);  // [nc][64]
+    const int64_t s0 = (int64_t)blockIdx.x * 64;
+    const int ns = (int)min((int64_t)64, n - s0);
+    for (int e = threadIdx.x; e < nc * 64; e += blockDim.x) {
+        const int c = e / 64, s = e % 64;
+        double v = 0;
+        if (s < ns) {
+            double wx = 0;
+            for (int j = 0; j < nc; ++j) wx += (sizeof(T) == 4 ? (double)(float)W[c * nc + j] : W[c * nc + j]) * (double)X1T[(s0 + s) * ld + j];
+            v = tanh(wx);
+        }
+        g[e] = v;
+    }
+    __syncthreads();
+    double* out = part + (int64_t)blockIdx.x * (nc * nc + nc);
+    for (int e = threadIdx.x; e < nc * nc + nc; e += blockDim.x) {
+        double s = 0;
+        if (e < nc * nc) {
+            const int c = e / nc, j = e % nc;
+            for (int t = 0; t < ns; ++t) s += g[c * 64 + t] * (double)X1T[(s0 + t) * ld + j];
+        } else {
+            const int c = e - nc * nc;
+            for (int t = 0; t < ns; ++t) s += 1.0 - g[c * 64 + t] * g[c * 64 + t];
+        }
+        out[e] = s;
+    }
+}
+__global__ void k_sum_parts_state(const double* __restrict__ part, int64_t nparts, int64_t count, double* __restrict__ out,
+                                  const int* __restrict__ state) {
+    if (state && state[0]) return;
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    double s = 0;
+    for (int64_t p = 0; p < nparts; ++p) s += part[p * count + j];
+    out[j] = s;
+}
+
+// ================================================================================================
+// fp64 small-matrix kernels
+// ================================================================================================
+__global__ void k_dgemm(bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* __restrict__ A,
+                        int64_t lda, const double* __restrict__ B, int64_t ldb, double beta, double* __restrict__ C, int64_t ldc) {
+    __shared__ double sa[16][17], sb[16][17];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int64_t i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+    double acc = 0;
+    for (int64_t k0 = 0; k0 < K; k0 += 16) {
+        {   // sa[ty][tx] = opA[i][k0 + tx]
+            const int64_t k = k0 + tx;
+            sa[ty][tx] = (i < M && k < K) ? (ta ? A[k * lda + i] : A[i * lda + k]) : 0.0;
+        }
+        {   // sb[ty][tx] = opB[k0 + ty][j]
+            const int64_t k = k0 + ty;
+            sb[ty][tx] = (j < N && k < K) ? (tb ? B[j * ldb + k] : B[k * ldb + j]) : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += sa[ty][k] * sb[k][tx];
+        __syncthreads();
+    }
+    if (i < M && j < N) C[i * ldc + j] = alpha * acc + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
+}
+
+// one workgroup; R (L x L scratch) and T in global memory (L2 resident)
+__global__ __launch_bounds__(1024) void k_chol_inv(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ R,
+                                                   double* __restrict__ T, int64_t ldt, double rel_tol, int* __restrict__ dead) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    __shared__ double s_piv;
+    __shared__ int s_dead;
+    for (int e = tid; e < L * L; e += nt) {
+        const int r = e / L, c = e % L;
+        R[e] = c >= r ? G[(int64_t)r * ldg + c] : 0.0;
+        T[(int64_t)r * ldt + c] = 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < L; ++j) {  // right-looking upper Cholesky G = R^T R with dependent-column dropping
+        if (tid == 0) {
+            const double s = R[j * L + j], gjj = G[(int64_t)j * ldg + j];
+            const bool dd = !(gjj > 0.0) || !(s > rel_tol * gjj);
+            s_dead = dd;
+            s_piv = dd ? 0.0 : sqrt(s);
+            dead[j] = dd;
+        }
+        __syncthreads();
+        const double piv = s_piv;
+        const bool dd = s_dead != 0;
+        for (int c = j + tid; c < L; c += nt) R[j * L + c] = dd ? 0.0 : (c == j ? piv : R[j * L + c] / piv);
+        __syncthreads();
+        if (!dd) {
+            const int rem = L - 1 - j;
+            for (int e = tid; e < rem * rem; e += nt) {
+                const int r = j + 1 + e / rem, c = j + 1 + e % rem;
+                if (c >= r) R[r * L + c] -= R[j * L + r] * R[j * L + c];
+            }
+        }
+        __syncthreads();
+    }
+    // T = R^{-1}: one thread per column, back substitution; dead rows/columns stay zero
+    for (int j = tid; j < L; j += nt) {
+        if (dead[j]) continue;
+        T[(int64_t)j * ldt + j] = 1.0 / R[j * L + j];
+        for (int r = j - 1; r >= 0; --r) {
+            if (dead[r]) continue;
+            double s = 0;
+            for (int k = r + 1; k <= j; ++k) s += R[r * L + k] * T[(int64_t)k * ldt + j];
+            T[(int64_t)r * ldt + j] = -s / R[r * L + r];
+        }
+    }
+}
+
+// ---- workgroup-wide cyclic Jacobi eigen-solver (fp64) ----------------------------------------------
+// A (L x L, lda) symmetric, destroyed; V (L x L, ldv) <- eigenvectors in columns.  Parallel ordering:
+// round-robin tournament, L/2 disjoint rotations per round, three barriers per round.
+__device__ void wg_jacobi(double* A, int64_t lda, double* V, int64_t ldv, int L, double* s_c, double* s_s, int* s_p, int* s_q,
+                          double* s_red) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int e = tid; e < L * L; e += nt) V[(int64_t)(e / L) * ldv + (e % L)] = (e / L == e % L) ? 1.0 : 0.0;
+    __syncthreads();
+    if (L < 2) return;
+    const int Le = (L + 1) & ~1, half = Le / 2, rounds = Le - 1;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        // convergence: off^2 <= 1e-30 diag^2
+        double off = 0, dg = 0;
+        for (int e = tid; e < L * L; e += nt) {
+            const int r = e / L, c = e % L;
+            const double v = A[(int64_t)r * lda + c];
+            if (r == c) dg += v * v; else off += v * v;
+        }
+        s_red[tid] = off; s_red[nt + tid] = dg;
+        __syncthreads();
+        for (int st = nt / 2; st > 0; st >>= 1) {
+            if (tid < st) { s_red[tid] += s_red[tid + st]; s_red[nt + tid] += s_red[nt + tid + st]; }
+            __syncthreads();
+        }
+        const double toff = s_red[0], tdg = s_red[nt];
+        __syncthreads();
+        if (!(toff > 1e-30 * tdg)) break;
+        for (int rd = 0; rd < rounds; ++rd) {
+            for (int k = tid; k < half; k += nt) {
+                int p, q;
+                if (k == 0) { p = Le - 1; q = rd; }
+                else { p = (rd + k) % (Le - 1); q = (rd - k + (Le - 1)) % (Le - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                double c = 1.0, s = 0.0;
+                if (q < L) {
+                    const double apq = A[(int64_t)p * lda + q];
+                    if (apq != 0.0) {
+                        const double theta = (A[(int64_t)q * lda + q] - A[(int64_t)p * lda + p]) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(t * t + 1.0);
+                        s = t * c;
+                    }
+                } else { q = p; }  // bye
+                s_p[k] = p; s_q[k] = q; s_c[k] = c; s_s[k] = s;
+            }
+            __syncthreads();
+            for (int e = tid; e < L * half; e += nt) {  // columns: A <- A J, V <- V J
+                const int r = e / half, k = e % half;
+                const int p = s_p[k], q = s_q[k];
+                if (p == q) continue;
+                const double c = s_c[k], s = s_s[k];
+                const double ap = A[(int64_t)r * lda + p], aq = A[(int64_t)r * lda + q];
+                A[(int64_t)r * lda + p] = c * ap - s * aq;
+                A[(int64_t)r * lda + q] = s * ap + c * aq;
+                const double vp = V[(int64_t)r * ldv + p], vq = V[(int64_t)r * ldv + q];
+                V[(int64_t)r * ldv + p] = c * vp - s * vq;
+                V[(int64_t)r * ldv + q] = s * vp + c * vq;
+            }
+            __syncthreads();
+            for (int e = tid; e < L * half; e += nt) {  // rows: A <- J^T A
+                const int k = e / L, cc = e % L;
+                const int p = s_p[k], q = s_q[k];
+                if (p == q) continue;
+                const double c = s_c[k], s = s_s[k];
+                const double ap = A[(int64_t)p * lda + cc], aq = A[(int64_t)q * lda + cc];
+                A[(int64_t)p * lda + cc] = c * ap - s * aq;
+                A[(int64_t)q * lda + cc] = s * ap + c * aq;
+            }
+            __syncthreads();
+        }
+    }
+}
+// sort eigenpairs descending: Vout[:, rank] = V[:, j], w[rank] = A[j][j]
+__device__ void wg_sort_eig(const double* A, int64_t lda, const double* V, int64_t ldv, int L, double* Vout, int64_t ldo,
+                            double* w, int* s_rank) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int j = tid; j < L; j += nt) {
+        const double wj = A[(int64_t)j * lda + j];
+        int rank = 0;
+        for (int k = 0; k < L; ++k) {
+            const double wk = A[(int64_t)k * lda + k];
+            rank += (wk > wj || (wk == wj && k < j)) ? 1 : 0;
+        }
+        s_rank[j] = rank;
+        w[rank] = wj;
+    }
+    __syncthreads();
+    for (int e = tid; e < L * L; e += nt) {
+        const int r = e / L, j = e % L;
+        Vout[(int64_t)r * ldo + s_rank[j]] = V[(int64_t)r * ldv + j];
+    }
+    __syncthreads();
+}
+
+constexpr int EIG_THREADS = 1024;
+constexpr int EIG_MAXL = 1024;
+struct EigShared {
+    double c[EIG_MAXL / 2], s[EIG_MAXL / 2];
+    int p[EIG_MAXL / 2], q[EIG_MAXL / 2];
+    double red[2 * EIG_THREADS];
+    int rank[EIG_MAXL];
+};
+__global__ __launch_bounds__(EIG_THREADS) void k_eigh(double* A, int L, int64_t lda, double* Vtmp, double* V, int64_t ldv, double* w) {
+    __shared__ EigShared sh;
+    wg_jacobi(A, lda, Vtmp, L, L, sh.c, sh.s, sh.p, sh.q, sh.red);
+    wg_sort_eig(A, lda, Vtmp, L, L, V, ldv, w, sh.rank);
+}
+
+// Wout = symmetric_decorrelation(Win) (ica.rs:363-381); scratch: S, Z, Zs, M each nc*nc doubles + w nc
+__device__ void wg_symdecorr(const double* Win, double* Wout, int nc, int mode, double* S, double* Zt, double* Z, double* Mm,
+                             double* w, EigShared& sh) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int e = tid; e < nc * nc; e += nt) {  // S = W W^T (ica.rs:369)
+        const int i = e / nc, j = e % nc;
+        double s = 0;
+        for (int k = 0; k < nc; ++k) s += Win[i * nc + k] * Win[j * nc + k];
+        S[e] = s;
+    }
+    __syncthreads();
+    wg_jacobi(S, nc, Zt, nc, nc, sh.c, sh.s, sh.p, sh.q, sh.red);
+    wg_sort_eig(S, nc, Zt, nc, nc, Z, nc, w, sh.rank);
+    // textbook (W W^T)^(-1/2) = Z D Z^T.  literal crate arithmetic: Z_asc^T D Z_asc with LAPACK's
+    // ascending order; for nc == 2 LAPACK's dlaev2 path returns a symmetric Z for PSD input, where both agree.
+    const bool literal = mode == 1 && nc > 2;
+    for (int e = tid; e < nc * nc; e += nt) {
+        const int i = e / nc, j = e % nc;
+        double acc = 0;
+        for (int k = 0; k < nc; ++k) {
+            if (literal) acc += Z[k * nc + (nc - 1 - i)] * (1.0 / sqrt(w[nc - 1 - k])) * Z[k * nc + (nc - 1 - j)];
+            else acc += Z[i * nc + k] * (1.0 / sqrt(w[k])) * Z[j * nc + k];
+        }
+        Mm[e] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < nc * nc; e += nt) {
+        const int i = e / nc, j = e % nc;
+        double acc = 0;
+        for (int k = 0; k < nc; ++k) acc += Mm[i * nc + k] * Win[k * nc + j];
+        Wout[e] = acc;
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(EIG_THREADS) void k_symdecorr(const double* Win, double* Wout, int nc, int mode, double* scratch) {
+    __shared__ EigShared sh;
+    double* S = scratch; double* Zt = S + nc * nc; double* Z = Zt + nc * nc; double* Mm = Z + nc * nc; double* w = Mm + nc * nc;
+    wg_symdecorr(Win, Wout, nc, mode, S, Zt, Z, Mm, w, sh);
+}
+__global__ __launch_bounds__(EIG_THREADS) void k_ica_tail(int nc, double n_total, double* W, const double* GX_gp, int mode,
+                                                          double tol, int* state, int iter, double* scratch) {
+    if (state[0]) return;
+    __shared__ EigShared sh;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double* S = scratch; double* Zt = S + nc * nc; double* Z = Zt + nc * nc; double* Mm = Z + nc * nc; double* w = Mm + nc * nc;
+    double* D = w + nc; double* W1 = D + nc * nc;
+    const double* GX = GX_gp; const double* gp = GX_gp + nc * nc;
+    const double pinv = 1.0 / n_total;
+    for (int e = tid; e < nc * nc; e += nt) D[e] = GX[e] * pinv - gp[e / nc] * pinv * W[e];  // ica.rs:334-342
+    __syncthreads();
+    wg_symdecorr(D, W1, nc, mode, S, Zt, Z, Mm, w, sh);  // ica.rs:343
+    double lim = 0;  // ica.rs:344-354
+    for (int i = tid; i < nc; i += nt) {
+        double dot = 0;
+        for (int j = 0; j < nc; ++j) dot += W1[i * nc + j] * (mode == 1 ? W[j * nc + i] : W[i * nc + j]);
+        lim = fmax(lim, fabs(fabs(dot) - 1.0));
+    }
+    sh.red[tid] = lim;
+    __syncthreads();
+    for (int st = nt / 2; st > 0; st >>= 1) {
+        if (tid < st) sh.red[tid] = fmax(sh.red[tid], sh.red[tid + st]);
+        __syncthreads();
+    }
+    const double tl = sh.red[0];
+    __syncthreads();
+    for (int e = tid; e < nc * nc; e += nt) W[e] = W1[e];
+    if (tid == 0 && (tl < tol)) { state[0] = 1; state[1] = iter + 1; }  // ica.rs:355-357
+}
+
+__global__ void k_dscal(double* x, int64_t count, double alpha) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e < count) x[e] *= alpha;
+}
+__global__ void k_dvec(int mode, const double* x, double* y, int64_t count, double thr) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    if (mode == 0) y[e] = sqrt(fmax(x[e], 0.0));
+    else y[e] = (x[e] > thr * x[0] && x[e] > 0.0) ? 1.0 / x[e] : 0.0;
+}
+__global__ void k_dscale_cols(double* A, int64_t M, int64_t N, int64_t lda, const double* s) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e < M * N) A[(e / N) * lda + (e % N)] *= s[e % N];
+}
+template <class T>
+__global__ void k_cvt_from_f64(T* dst, const double* src, int64_t count) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e < count) dst[e] = (T)src[e];
+}
+template <class T>
+__global__ void k_cvt_to_f64(double* dst, const T* src, int64_t count) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e < count) dst[e] = (double)src[e];
+}
+
+// ================================================================================================
+// host-side launchers
+// ================================================================================================
+#define DISPATCH_T(dt, ...)                              \
+    do {                                                 \
+        if ((dt) == F64) { using T = double; __VA_ARGS__; } \
+        else { using T = float; __VA_ARGS__; }           \
+    } while (0)
+
+void op_pack_strided(Dev* d, int dt, const void* src, int64_t n, int64_t dd, int64_t rs, int64_t cs, void* dst, int64_t ld,
+                     int64_t dpad) {
+    if (n == 0 || dpad == 0) return;
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_pack_strided<T>, dim3((unsigned)n, cdiv(dpad, 256)), dim3(256), 0, d->stream,
+                                      (const T*)src, n, dd, rs, cs, (T*)dst, ld, dpad));
+    launch_check();
+}
+void op_unpack_strided(Dev* d, int dt, const void* src, int64_t n, int64_t dd, int64_t ld, void* dst, int64_t rs, int64_t cs) {
+    if (n == 0 || dd == 0) return;
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_unpack_strided<T>, dim3((unsigned)n, cdiv(dd, 256)), dim3(256), 0, d->stream,
+                                      (const T*)src, n, dd, ld, (T*)dst, rs, cs));
+    launch_check();
+}
+
+void op_colsum(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx, double* out) {
+    if (dd == 0) return;
+    if (n == 0) { dev_memset(d, out, 0, sizeof(double) * dd); return; }
+    const int64_t nparts = cdiv(n, CS_ROWS);
+    double* part = (double*)dev_alloc(d, sizeof(double) * nparts * dd);
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_colsum_part<T>, dim3((unsigned)nparts, cdiv(dd, 256)), dim3(256), 0, d->stream,
+                                      (const T*)X, n, dd, ldx, part));
+    launch_check();
+    hipLaunchKernelGGL(k_sum_parts, dim3(cdiv(dd, 256)), dim3(256), 0, d->stream, part, nparts, dd, out);
+    launch_check();
+    dev_free(d, part);
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int RT, int NT>
+static void launch_xp(Dev* d, const float* X, int64_t n, int K, int64_t ldx, const float* mu, const float* Ppk, int NTtot,
+                      int nt0, int N, const float* bias, float* Z, int64_t ldz, double* ss_part, int blocks) {
+    const bool center = mu != nullptr, ss = ss_part != nullptr;
+#define XP_ARGS X, n, K, ldx, mu, Ppk, NTtot, nt0, N, bias, Z, ldz, ss_part
+    if (center && ss) hipLaunchKernelGGL((k_xp_mfma<RT, NT, true, true>), dim3(blocks), dim3(256), 0, d->stream, XP_ARGS);
+    else if (center) hipLaunchKernelGGL((k_xp_mfma<RT, NT, true, false>), dim3(blocks), dim3(256), 0, d->stream, XP_ARGS);
+    else if (ss) hipLaunchKernelGGL((k_xp_mfma<RT, NT, false, true>), dim3(blocks), dim3(256), 0, d->stream, XP_ARGS);
+    else hipLaunchKernelGGL((k_xp_mfma<RT, NT, false, false>), dim3(blocks), dim3(256), 0, d->stream, XP_ARGS);
+#undef XP_ARGS
+    launch_check();
+}
+
+void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
+                int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq) {
+    if (n == 0 || N == 0) return;
+    const bool mfma = dt == F32 && K % 16 == 0 && K > 0 && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
+                      K < (1 << 24) && N < (1 << 24);
+    if (!mfma) {
+        double* ssp = sumsq ? (double*)dev_alloc(d, sizeof(double) * n) : nullptr;
+        TagScope ts(d);
+        DISPATCH_T(dt, hipLaunchKernelGGL(k_xp_simple<T>, dim3((unsigned)n, cdiv(N, 64)), dim3(64), 0, d->stream, (const T*)X, n,
+                                          K, ldx, (const T*)mu, P, N, ldp, (const T*)bias, (T*)Z, ldz, ssp));
+        launch_check();
+        ts.stop();
+        if (sumsq) {
+            hipLaunchKernelGGL(k_add_scalar_parts, dim3(1), dim3(64), 0, d->stream, ssp, n, sumsq);
+            launch_check();
+            dev_free(d, ssp);
+        }
+        return;
+    }
+    const int NTtot = cdiv(N, 16);
+    float* Ppk = (float*)dev_alloc(d, sizeof(float) * (K / 16) * NTtot * 64 * 4);
+    {
+        const int64_t total = (K / 16) * (int64_t)NTtot * 64;
+        hipLaunchKernelGGL(k_pack_p, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk, NTtot);
+        launch_check();
+    }
+    // column panels of at most 5 tiles (RT = 4: 64 rows per wave) -- 80 accumulator registers per lane
+    const int blocks = cdiv(n, 256);
+    double* ssp = sumsq ? (double*)dev_alloc(d, sizeof(double) * blocks * 4) : nullptr;
+    TagScope ts(d);
+    for (int nt0 = 0; nt0 < NTtot;) {
+        const int rem = NTtot - nt0;
+        const int w = rem >= 5 ? 5 : rem;
+        double* sp = nt0 == 0 ? ssp : nullptr;
+        const float* Xf = (const float*)X; const float* muf = (const float*)mu; const float* bf = (const float*)bias; float* Zf = (float*)Z;
+        switch (w) {
+            case 5: launch_xp<4, 5>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+            case 4: launch_xp<4, 4>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+            case 3: launch_xp<4, 3>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+            case 2: launch_xp<4, 2>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+            default: launch_xp<4, 1>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+        }
+        nt0 += w;
+    }
+    ts.stop();
+    if (sumsq) {
+        hipLaunchKernelGGL(k_add_scalar_parts, dim3(1), dim3(64), 0, d->stream, ssp, (int64_t)blocks * 4, sumsq);
+        launch_check();
+        dev_free(d, ssp);
+    }
+    dev_free(d, Ppk);
+}
+
+template <int NT>
+static void launch_atb(Dev* d, const float* A, int64_t lda, int M, const float* muA, const float* B, int64_t ldb, int N,
+                       int n0col, const float* muB, int64_t n, int64_t chunk, float* part, int nsplit) {
+    const dim3 grid(cdiv(M, 256), nsplit), block(256);
+#define ATB_ARGS A, lda, M, muA, B, ldb, N, n0col, muB, n, chunk, part, N
+    if (muA && muB) hipLaunchKernelGGL((k_atb_mfma<NT, true, true>), grid, block, 0, d->stream, ATB_ARGS);
+    else if (muA) hipLaunchKernelGGL((k_atb_mfma<NT, true, false>), grid, block, 0, d->stream, ATB_ARGS);
+    else if (muB) hipLaunchKernelGGL((k_atb_mfma<NT, false, true>), grid, block, 0, d->stream, ATB_ARGS);
+    else hipLaunchKernelGGL((k_atb_mfma<NT, false, false>), grid, block, 0, d->stream, ATB_ARGS);
+#undef ATB_ARGS
+    launch_check();
+}
+
+void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const void* muA, const void* B, int64_t ldb, int64_t N,
+                 const void* muB, int64_t n, double* C, int64_t ldc) {
+    if (M == 0 || N == 0) return;
+    if (n == 0) { HIP_CHECK(hipMemset2DAsync(C, ldc * sizeof(double), 0, N * sizeof(double), M, d->stream)); return; }
+    const bool mfma = dt == F32 && M % 16 == 0 && N % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B) &&
+                      (!muA || aligned16(muA)) && (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
+    if (!mfma) {
+        const int64_t nparts = cdiv(n, ATB_S_ROWS);
+        double* part = (double*)dev_alloc(d, sizeof(double) * nparts * M * N);
+        TagScope ts(d);
+        DISPATCH_T(dt, hipLaunchKernelGGL(k_atb_simple<T>, dim3((unsigned)nparts, cdiv(N, 16), cdiv(M, 16)), dim3(16, 16), 0,
+                                          d->stream, (const T*)A, lda, M, (const T*)muA, (const T*)B, ldb, N, (const T*)muB, n, part));
+        launch_check();
+        ts.stop();
+        hipLaunchKernelGGL(k_reduce_partials_f64, dim3(cdiv(M * N, 256)), dim3(256), 0, d->stream, part, nparts, M, N, C, ldc);
+        launch_check();
+        dev_free(d, part);
+        return;
+    }
+    // split the rows so that about 1024 waves (one per SIMD) exist; chunk a multiple of 16 rows
+    const int mslices = cdiv(M, 64);
+    int64_t nsplit = std::max<int64_t>(1, 1024 / mslices);
+    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 64));
+    const int64_t chunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
+    nsplit = (n + chunk - 1) / chunk;
+    float* part = (float*)dev_alloc(d, sizeof(float) * nsplit * M * N);
+    const int NTtot = int(N / 16);
+    TagScope ts(d);
+    for (int nt0 = 0; nt0 < NTtot;) {
+        const int rem = NTtot - nt0;
+        const int w = rem >= 5 ? 5 : rem;
+        const float* Af = (const float*)A; const float* Bf = (const float*)B;
+        const float* ma = (const float*)muA; const float* mb = (const float*)muB;
+        switch (w) {
+            case 5: launch_atb<5>(d, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, mb, n, chunk, part, (int)nsplit); break;
+            case 4: launch_atb<4>(d, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, mb, n, chunk, part, (int)nsplit); break;
+            case 3: launch_atb<3>(d, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, mb, n, chunk, part, (int)nsplit); break;
+            case 2: launch_atb<2>(d, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, mb, n, chunk, part, (int)nsplit); break;
+            default: launch_atb<1>(d, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, mb, n, chunk, part, (int)nsplit); break;
+        }
+        nt0 += w;
+    }
+    ts.stop();
+    hipLaunchKernelGGL(k_reduce_partials_f32, dim3(cdiv(M * N, 256)), dim3(256), 0, d->stream, part, nsplit, M, N, C, ldc);
+    launch_check();
+    dev_free(d, part);
+}
+
+void op_col_absmax(Dev* d, int dt, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* absmax,
+                   double* idx, double* sign) {
+    if (L == 0) return;
+    const int64_t nparts = std::max<int64_t>(1, cdiv(n, CS_ROWS));
+    double* part = (double*)dev_alloc(d, sizeof(double) * 3 * nparts * L);
+    double *pm = part, *pi = part + nparts * L, *ps = part + 2 * nparts * L;
+    if (n == 0) {
+        std::vector<double> h(3 * L);
+        for (int64_t j = 0; j < L; ++j) { h[j] = -1.0; h[L + j] = INFINITY; h[2 * L + j] = 1.0; }
+        dev_h2d(d, absmax, h.data(), sizeof(double) * L);
+        dev_h2d(d, idx, h.data() + L, sizeof(double) * L);
+        dev_h2d(d, sign, h.data() + 2 * L, sizeof(double) * L);
+        dev_free(d, part);
+        return;
+    }
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_absmax_part<T>, dim3((unsigned)nparts, cdiv(L, 64)), dim3(64), 0, d->stream, (const T*)U,
+                                      n, L, ldu, pm, pi, ps));
+    launch_check();
+    hipLaunchKernelGGL(k_absmax_final, dim3(cdiv(L, 64)), dim3(64), 0, d->stream, pm, pi, ps, nparts, L, row_offset, absmax, idx, sign);
+    launch_check();
+    dev_free(d, part);
+}
+
+void op_scale_cols(Dev* d, int dt, void* A, int64_t n, int64_t L, int64_t lda, const double* s) {
+    if (n == 0 || L == 0) return;
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_scale_cols<T>, dim3((unsigned)n, cdiv(L, 64)), dim3(64), 0, d->stream, (T*)A, n, L, lda, s));
+    launch_check();
+}
+void op_logcosh_rows(Dev* d, int dt, const void* X, int64_t r, int64_t c, int64_t ldx, void* G, int64_t ldg, double* gp) {
+    if (r == 0) return;
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_logcosh_rows<T>, dim3(cdiv(r, 64)), dim3(64), 0, d->stream, (const T*)X, r, c, ldx, (T*)G, ldg, gp));
+    launch_check();
+}
+
+void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t ld, const double* W, double* GX_gp,
+                 const int* state) {
+    const int64_t cnt = nc * nc + nc;
+    if (n == 0) { dev_memset(d, GX_gp, 0, sizeof(double) * cnt); return; }
+    const bool mfma = dt == F32 && nc <= 64 && ld % 4 == 0 && ld >= (nc + 15) / 16 * 16 && aligned16(X1T) && n >= 256;
+    if (!mfma) {
+        if (nc > 64) throw std::runtime_error("FastICA on the device supports at most 64 components in this build");
+        const int64_t nparts = cdiv(n, 64);
+        double* part = (double*)dev_alloc(d, sizeof(double) * nparts * cnt);
+        TagScope ts(d);
+        DISPATCH_T(dt, hipLaunchKernelGGL(k_ica_simple<T>, dim3((unsigned)nparts), dim3(256), sizeof(double) * nc * 64, d->stream,
+                                          (const T*)X1T, n, (int)nc, ld, W, part, state));
+        launch_check();
+        ts.stop();
+        hipLaunchKernelGGL(k_sum_parts_state, dim3(cdiv(cnt, 256)), dim3(256), 0, d->stream, part, nparts, cnt, GX_gp, state);
+        launch_check();
+        dev_free(d, part);
+        return;
+    }
+    const int NT = int((nc + 15) / 16), NCP = 16 * NT;
+    float* Wpk = (float*)dev_alloc(d, sizeof(float) * NT * NT * 64 * 4);
+    hipLaunchKernelGGL(k_pack_w, dim3(cdiv(NT * NT * 64, 256)), dim3(256), 0, d->stream, W, (int)nc, Wpk, NT);
+    launch_check();
+    const int64_t tiles = (n + 15) / 16;
+    int64_t waves = std::min<int64_t>(2048, tiles);
+    const int64_t tpw = (tiles + waves - 1) / waves;
+    waves = (tiles + tpw - 1) / tpw;
+    const int blocks = cdiv(waves, 4);
+    const int64_t nparts = (int64_t)blocks * 4;
+    const int64_t slab = (int64_t)NCP * NCP + NCP;
+    float* part = (float*)dev_alloc(d, sizeof(float) * nparts * slab);
+    TagScope ts(d);
+    switch (NT) {
+        case 1: hipLaunchKernelGGL(k_ica_mfma<1>, dim3(blocks), dim3(256), 0, d->stream, (const float*)X1T, n, ld, Wpk, tpw, part, state); break;
+        case 2: hipLaunchKernelGGL(k_ica_mfma<2>, dim3(blocks), dim3(256), 0, d->stream, (const float*)X1T, n, ld, Wpk, tpw, part, state); break;
+        case 3: hipLaunchKernelGGL(k_ica_mfma<3>, dim3(blocks), dim3(256), 0, d->stream, (const float*)X1T, n, ld, Wpk, tpw, part, state); break;
+        default: hipLaunchKernelGGL(k_ica_mfma<4>, dim3(blocks), dim3(256), 0, d->stream, (const float*)X1T, n, ld, Wpk, tpw, part, state); break;
+    }
+    launch_check();
+    ts.stop();
+    hipLaunchKernelGGL(k_ica_reduce, dim3(cdiv(cnt, 256)), dim3(256), 0, d->stream, part, nparts, NCP, (int)nc, GX_gp, state);
+    launch_check();
+    dev_free(d, part);
+    dev_free(d, Wpk);
+}
+
+void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol, int* state, int iter) {
+    double* scratch = (double*)dev_alloc(d, sizeof(double) * (6 * nc * nc + nc));
+    hipLaunchKernelGGL(k_ica_tail, dim3(1), dim3(EIG_THREADS), 0, d->stream, (int)nc, n_total, W, GX_gp, mode, tol, state, iter, scratch);
+    launch_check();
+    dev_free(d, scratch);
+}
+void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode) {
+    double* scratch = (double*)dev_alloc(d, sizeof(double) * (4 * nc * nc + nc));
+    hipLaunchKernelGGL(k_symdecorr, dim3(1), dim3(EIG_THREADS), 0, d->stream, Win, Wout, (int)nc, mode, scratch);
+    launch_check();
+    dev_free(d, scratch);
+}
+
+void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+              const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+    if (M == 0 || N == 0) return;
+    hipLaunchKernelGGL(k_dgemm, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(16, 16), 0, d->stream, ta, tb, M, N, K, alpha, A, lda, B, ldb,
+                       beta, C, ldc);
+    launch_check();
+}
+void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol) {
+    if (L == 0) return;
+    double* R = (double*)dev_alloc(d, sizeof(double) * L * L + sizeof(int) * L);
+    int* dead = reinterpret_cast<int*>(R + L * L);
+    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, d->stream, G, (int)L, ldg, R, T, ldt, rel_tol, dead);
+    launch_check();
+    dev_free(d, R);
+}
+void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w) {
+    if (L == 0) return;
+    if (L > EIG_MAXL) throw std::runtime_error("eigh: matrix too large for the one-workgroup Jacobi solver");
+    double* Vtmp = (double*)dev_alloc(d, sizeof(double) * L * L);
+    hipLaunchKernelGGL(k_eigh, dim3(1), dim3(EIG_THREADS), 0, d->stream, A, (int)L, lda, Vtmp, V, ldv, w);
+    launch_check();
+    dev_free(d, Vtmp);
+}
+void op_dscal(Dev* d, double* x, int64_t count, double alpha) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_dscal, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, x, count, alpha);
+    launch_check();
+}
+void op_dvec(Dev* d, int mode, const double* x, double* y, int64_t count, double thr) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_dvec, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, mode, x, y, count, thr);
+    launch_check();
+}
+void op_dscale_cols(Dev* d, double* A, int64_t M, int64_t N, int64_t lda, const double* s) {
+    if (M * N == 0) return;
+    hipLaunchKernelGGL(k_dscale_cols, dim3(cdiv(M * N, 256)), dim3(256), 0, d->stream, A, M, N, lda, s);
+    launch_check();
+}
+void op_cvt_from_f64(Dev* d, int dt, void* dst, const double* src, int64_t count) {
+    if (!count) return;
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_cvt_from_f64<T>, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, (T*)dst, src, count));
+    launch_check();
+}
+void op_cvt_to_f64(Dev* d, int dt, double* dst, const void* src, int64_t count) {
+    if (!count) return;
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_cvt_to_f64<T>, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, dst, (const T*)src, count));
+    launch_check();
+}
+
+}  // namespace petal

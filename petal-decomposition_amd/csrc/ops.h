@@ -1,0 +1,106 @@
+// ops.h -- the device-operation layer the host algorithms (algo.cpp) are written against.
+//
+// The product library links exactly one implementation: hip_ops.hip (hand-written gfx950 kernels).
+// tests/ additionally build a host-memory simulation of the same functions from oracle/cpu_ops.cpp
+// (TEST INFRASTRUCTURE, never linked into the product) so that the host algorithms and the
+// sample-sharded collective path can be exercised without a GPU (world_size-2 gloo test).
+//
+// All matrices are row-major.  "f64 small" matrices live in device memory as doubles: everything
+// that is O(l^2), O(d l) or O(nc^2) is kept in fp64 so that only the O(n) streams are fp32.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace petal {
+
+enum DType : int { F32 = 0, F64 = 1 };
+inline size_t dtype_size(int dt) { return dt == F64 ? 8 : 4; }
+
+struct Dev;  // opaque: stream, allocator cache, event pool (hip) / nothing much (cpu sim)
+
+// hot-kernel tags: launches issued while a tag is set are bracketed with events when profiling is on
+enum Tag : int { TAG_NONE = 0, TAG_XP = 1, TAG_ATB = 2, TAG_ICA = 3, TAG_COUNT = 4 };
+struct KernelTiming {
+    double ms[TAG_COUNT] = {0, 0, 0, 0};
+    int64_t launches[TAG_COUNT] = {0, 0, 0, 0};
+};
+
+// ---- lifetime / memory ---------------------------------------------------------------------
+Dev*  dev_create(int device, void* stream, char* err, size_t errlen);  // nullptr on failure
+void  dev_destroy(Dev*);
+void* dev_stream(Dev*);
+void* dev_alloc(Dev*, size_t bytes);      // cached; never returns nullptr (throws std::runtime_error)
+void  dev_free(Dev*, void*);
+void  dev_memset(Dev*, void* p, int v, size_t bytes);
+void  dev_h2d(Dev*, void* dst, const void* src, size_t bytes);
+void  dev_d2h(Dev*, void* dst, const void* src, size_t bytes);
+void  dev_d2d(Dev*, void* dst, const void* src, size_t bytes);
+// pitched copies (bytes); kind: 0 h2d, 1 d2h, 2 d2d
+void  dev_copy2d(Dev*, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int kind);
+void  dev_sync(Dev*);
+void  dev_set_profiling(Dev*, bool on);
+void  dev_reset_timing(Dev*);
+void  dev_set_tag(Dev*, int tag);
+KernelTiming dev_timing(Dev*);            // resolves pending events (call after dev_sync)
+
+// ---- O(n) streaming ops --------------------------------------------------------------------
+// dst[i*ld_dst + j] = src[i*rs + j*cs] for j < d, 0 for d <= j < d_pad   (device -> device gather)
+void op_pack_strided(Dev*, int dtype, const void* src, int64_t n, int64_t d, int64_t rs, int64_t cs,
+                     void* dst, int64_t ld_dst, int64_t d_pad);
+// dst[i*rs + j*cs] = src[i*ld_src + j] (device -> device scatter), j < d
+void op_unpack_strided(Dev*, int dtype, const void* src, int64_t n, int64_t d, int64_t ld_src,
+                       void* dst, int64_t rs, int64_t cs);
+// out[j] = sum_i X[i][j]  (fp64, deterministic order)
+void op_colsum(Dev*, int dtype, const void* X, int64_t n, int64_t d, int64_t ldx, double* out);
+// Z[n x N] = (X[n x K] - mu) . P[K x N] * 1 + bias        (mu, bias nullable; mu/bias in dtype)
+// P is an f64 small matrix (ldp).  sumsq (nullable, fp64 scalar): += sum_ij (X_ij - mu_j)^2.
+// colscale (nullable, f64[N]): Z[:, j] *= colscale[j].
+void op_gemm_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
+                const double* P, int64_t N, int64_t ldp, const void* bias,
+                void* Z, int64_t ldz, double* sumsq);
+// C[M x N] (f64, ldc) = (A - muA)^T . (B - muB),  A: n x M (lda), B: n x N (ldb), reduction over n rows
+void op_gemm_atb(Dev*, int dtype, const void* A, int64_t lda, int64_t M, const void* muA,
+                 const void* B, int64_t ldb, int64_t N, const void* muB, int64_t n,
+                 double* C, int64_t ldc);
+// per column j < L of U (n x L): absmax[j] = max_i |U_ij|, idx[j] = row_offset + first such i,
+// sign[j] = U_ij >= 0 ? +1 : -1 (sign of -0.0 / 0.0 follows f64::signum: +1 for +0, -1 for -0).
+// n == 0: absmax = -1, idx = +inf, sign = +1.
+void op_col_absmax(Dev*, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset,
+                   double* absmax, double* idx, double* sign);
+// A[i][j] *= s[j] (dtype matrix, f64 scale vector), i < n, j < L
+void op_scale_cols(Dev*, int dtype, void* A, int64_t n, int64_t L, int64_t lda, const double* s);
+// G = tanh(X) elementwise (n x c), gp[j]... logcosh KAT helper: rows are components:
+// G[i][j] = tanh(X[i][j]); gp[i] = sum_j (1 - G_ij^2)   (f64 out, un-normalised)
+void op_logcosh_rows(Dev*, int dtype, const void* X, int64_t r, int64_t c, int64_t ldx, void* G, int64_t ldg, double* gp);
+
+// ---- FastICA fused step (ica.rs:332-333) -----------------------------------------------------
+// X1T: n x nc (ld) whitened samples (sample-major).  W: nc x nc f64.
+// GX[i][j] = sum_s tanh(w_i . x_s) x_s[j];  gp[i] = sum_s (1 - tanh(w_i . x_s)^2)     (f64 out)
+// state[0] != 0 (converged) -> no-op.
+void op_ica_step(Dev*, int dtype, const void* X1T, int64_t n, int64_t nc, int64_t ld,
+                 const double* W, double* GX_gp /* nc*nc + nc contiguous */, const int* state);
+// ica.rs:334-358 on one workgroup: D = GX/n_total - gp/n_total (.) W; W1 = symdecorr(D); lim; update.
+// state = {done, n_iter}; iter is the 0-based index of this iteration.  W is replaced by W1 unless done.
+void op_ica_tail(Dev*, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol,
+                 int* state, int iter);
+// Wout = symmetric_decorrelation(Win) (ica.rs:363-381)
+void op_symdecorr(Dev*, int64_t nc, const double* Win, double* Wout, int mode);
+
+// ---- f64 small-matrix ops ----------------------------------------------------------------------
+void op_dgemm(Dev*, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha,
+              const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+// G (L x L, SPD up to rounding) = R^T R;  T = R^{-1} (upper triangular, L x L, ldt).
+// A pivot with r_jj^2 <= rel_tol * G_jj (or G_jj <= 0) marks column j as dependent: T[:, j] = 0.
+void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol);
+// symmetric A (L x L) -> eigenvalues w (descending) and eigenvectors in the COLUMNS of V.  A is destroyed.
+void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w);
+// x[i] *= alpha
+void op_dscal(Dev*, double* x, int64_t count, double alpha);
+// elementwise helpers on f64 vectors:  mode 0: y = sqrt(max(x,0)); mode 1: y = x > thr*x[0] ? 1/x : 0
+void op_dvec(Dev*, int mode, const double* x, double* y, int64_t count, double thr);
+// A[i][j] *= s[j]  (f64 matrix M x N)
+void op_dscale_cols(Dev*, double* A, int64_t M, int64_t N, int64_t lda, const double* s);
+void op_cvt_from_f64(Dev*, int dtype, void* dst, const double* src, int64_t count);
+void op_cvt_to_f64(Dev*, int dtype, double* dst, const void* src, int64_t count);
+
+}  // namespace petal

@@ -1,0 +1,58 @@
+"""Parity tests proper: the HIP path (libpetal_hip.so through the C ABI) against the oracle, the
+reference's known-answer tests and exact-integer kernel checks, on a real MI355X.  Run with -m gpu."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import petal_decomposition_amd as petal
+    c = petal.Context(0)          # raises (no CPU fallback) when the HIP library or the GPU is missing
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("case", pc.ALL_KATS, ids=lambda f: f.__name__)
+def test_reference_kats(ctx, kats, case):
+    case(ctx, kats)
+
+
+# exact-integer data: any fragment-layout / indexing mistake in the MFMA kernels is an exact mismatch
+@pytest.mark.parametrize("n,K,N", [(64, 16, 16), (256, 64, 80), (1000, 48, 74), (4099, 512, 74), (777, 32, 138),
+                                   (2048, 80, 80), (5000, 208, 200), (300, 24, 7), (37, 24, 7)])
+def test_gemm_kernels_exact(ctx, n, K, N):
+    pc.gemm_exact(ctx, n, K, N, seed=n + K + N)
+
+
+def test_gemm_kernels_exact_device_resident(ctx):
+    pc.gemm_exact(ctx, 4096, 512, 80, seed=5, device=True)      # zero-copy ingest path
+    pc.gemm_exact(ctx, 1001, 100, 30, seed=6, device=True)      # device-side pad/pack path
+
+
+@pytest.mark.parametrize("n,d,k,n_iter", [(20000, 256, 32, 5), (10007, 200, 10, 7), (4096, 512, 64, 5), (1000, 64, 4, 7)])
+def test_rpca_parity(ctx, n, d, k, n_iter):
+    # BASELINE parity target: components within 1e-5 rel-err of the CPU reference path, same Omega / n_iter
+    pc.rpca_parity(ctx, n, d, k, n_iter, seed=n % 97, tol=1e-5)
+
+
+def test_rpca_parity_variants(ctx):
+    pc.rpca_parity(ctx, 6000, 96, 8, 7, seed=21, device=True)
+    pc.rpca_parity(ctx, 3000, 64, 6, 7, seed=22, centering=False)
+    pc.rpca_parity(ctx, 2000, 48, 6, 7, seed=23, dtype=np.float64, tol=1e-9)
+
+
+def test_pca_parity(ctx):
+    pc.pca_parity(ctx, 1000, 16, 4, seed=1)                       # BASELINE configs[0]: 1000 x 16 f64
+    pc.pca_parity(ctx, 5000, 64, 8, seed=2, dtype=np.float32, tol=2e-5)
+
+
+def test_ica_parity(ctx):
+    pc.ica_par_parity(ctx, 20000, 8, seed=8, dtype=np.float32, tol=1e-4)   # MFMA fused step
+    pc.ica_par_parity(ctx, 3000, 5, seed=9, dtype=np.float64, tol=1e-8)    # generic fp64 step
+    pc.ica_par_parity(ctx, 50000, 32, seed=10, dtype=np.float32, tol=1e-4)
+    pc.ica_parity(ctx, 20000, 24, 8, seed=6, dtype=np.float32, n_components=8)
+    pc.ica_parity(ctx, 5000, 6, 6, seed=5, dtype=np.float64)

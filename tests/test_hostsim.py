@@ -1,0 +1,44 @@
+"""CPU suite for the host side: the product's algo.cpp/api.cpp run against the host-memory simulation of
+the device-op layer (oracle/cpu_ops.cpp, test infrastructure).  Checks the reference's known-answer
+tests and the oracle parity of the host algorithms; the HIP kernels themselves are covered by -m gpu."""
+import numpy as np
+import pytest
+
+import hostsim
+import parity_cases as pc
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return hostsim.context()
+
+
+@pytest.mark.parametrize("case", pc.ALL_KATS, ids=lambda f: f.__name__)
+def test_reference_kats(ctx, kats, case):
+    case(ctx, kats)
+
+
+def test_gemm_ops(ctx):
+    pc.gemm_exact(ctx, 37, 24, 7)
+    pc.gemm_exact(ctx, 130, 48, 33)
+
+
+@pytest.mark.parametrize("n,d,k,n_iter", [(2000, 64, 8, 5), (1501, 50, 5, 7), (300, 40, 12, 3)])
+def test_rpca_parity(ctx, n, d, k, n_iter):
+    pc.rpca_parity(ctx, n, d, k, n_iter, seed=n)
+
+
+def test_rpca_f64_and_no_centering(ctx):
+    pc.rpca_parity(ctx, 800, 32, 4, 7, seed=3, dtype=np.float64, tol=1e-9)
+    pc.rpca_parity(ctx, 800, 32, 4, 7, seed=4, centering=False)
+
+
+def test_pca_parity(ctx):
+    pc.pca_parity(ctx, 1000, 16, 4, seed=1)                       # BASELINE configs[0]
+    pc.pca_parity(ctx, 500, 24, 6, seed=2, dtype=np.float32, tol=2e-5)
+
+
+def test_ica_parity(ctx):
+    pc.ica_parity(ctx, 3000, 6, 6, seed=5, dtype=np.float64)
+    pc.ica_parity(ctx, 3000, 12, 4, seed=6, dtype=np.float32, n_components=4)
+    pc.ica_par_parity(ctx, 2000, 5, seed=8, dtype=np.float64, tol=1e-8)
