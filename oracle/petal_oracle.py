@@ -377,33 +377,7 @@ class FastIcaOracle:
 
 
 # --------------------------------------------------------------------------- synthetic inputs
-def synth_pca(n, d, k, seed, dtype=np.float32, noise=0.01):
-    """Planted low-rank + noise + means input of BASELINE.md section 3 / SURVEY.md 8(d):
-    X = (G diag(s)) V^T + noise*N + 1 mu^T, G n x r iid N(0,1)/sqrt(n), r = 2k, V d x r orthonormal,
-    s_i = 100 sqrt(n) rho^i, rho = 10^(-3/k)."""
-    rng = np.random.default_rng(seed)
-    r = min(2 * k, d, n)
-    rho = 10.0 ** (-3.0 / max(k, 1))
-    v, _ = np.linalg.qr(rng.standard_normal((d, r)))
-    s = 100.0 * np.sqrt(n) * rho ** np.arange(r)
-    mu = rng.standard_normal(d)
-    x = np.empty((n, d), dtype=dtype)
-    step = 65536
-    for i in range(0, n, step):
-        m = min(step, n - i)
-        g = rng.standard_normal((m, r)) / np.sqrt(n)
-        x[i:i + m] = ((g * s) @ v.T + noise * rng.standard_normal((m, d)) + mu).astype(dtype)
-    return x
-
-
-def synth_ica(n, d, nc, seed, dtype=np.float32, noise=0.01):
-    """ICA input of SURVEY.md 8(d): Laplace sources through a Gaussian mixing matrix + noise."""
-    rng = np.random.default_rng(seed)
-    a = rng.standard_normal((nc, d))
-    x = np.empty((n, d), dtype=dtype)
-    step = 65536
-    for i in range(0, n, step):
-        m = min(step, n - i)
-        s = rng.laplace(size=(m, nc))
-        x[i:i + m] = (s @ a + noise * rng.standard_normal((m, d))).astype(dtype)
-    return x
+try:  # the seeded generators live in the neutral synth_data module at the repo root
+    from synth_data import synth_ica, synth_pca  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass

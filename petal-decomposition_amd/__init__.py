@@ -92,13 +92,30 @@ ABI = [
 ]
 
 
-def load_library(path: Optional[str] = None) -> C.CDLL:
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 and load them by the unversioned
+    file name, so a process that first loads the system HIP runtime (through this library) and then imports
+    torch ends up with TWO HSA runtimes and torch sees no GPU.  Importing torch first makes the dynamic
+    loader resolve this library's ``libamdhip64.so.7`` to the copy torch already loaded: one runtime, shared
+    streams and device pointers.  Skipped when torch is absent or PETAL_NO_TORCH=1."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("PETAL_NO_TORCH") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
+def load_library(path: Optional[str] = None, preload_torch: bool = True) -> C.CDLL:
     """dlopen a library implementing include/petal_hip.h and type its entry points."""
     path = path or os.environ.get("PETAL_HIP_LIBRARY") or DEFAULT_LIBRARY
     if not os.path.exists(path):
         raise RuntimeError(
             f"petal-decomposition_amd: native library not found at {path}. Build it with "
             f"`python __graft_entry__.py build` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    if preload_torch:
+        _preload_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, res, args in ABI:
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol

@@ -26,4 +26,4 @@ def build() -> str:
 
 def context():
     import petal_decomposition_amd as petal
-    return petal.Context(0, lib=petal.load_library(build()))
+    return petal.Context(0, lib=petal.load_library(build(), preload_torch=False))
