@@ -92,7 +92,7 @@ void op_gemm_xp(Dev*, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, 
     if (sumsq) *sumsq += ss;
 }
 void op_gemm_atb(Dev*, int dt, const void* A, int64_t lda, int64_t M, const void* muA, const void* B, int64_t ldb,
-                 int64_t N, const void* muB, int64_t n, double* C, int64_t ldc) {
+                 int64_t N, const void* muB, int64_t n, double* C, int64_t ldc, bool) {
     for (int64_t m = 0; m < M; ++m)
         for (int64_t j = 0; j < N; ++j) C[m * ldc + j] = 0;
     std::vector<double> a(M), b(N);

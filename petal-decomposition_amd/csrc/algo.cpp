@@ -361,7 +361,7 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
 
     DBuf C(c.dev, sizeof(double) * dp * dp), V(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp);
     DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp);
-    op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp);
+    op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
     allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
     op_eigh(c.dev, C.f64(), dp, dp, V.f64(), dp, lam.f64());
     op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
@@ -519,7 +519,7 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
     // whitening (ica.rs:189-208): left singular vectors / values of Xc^T == eigenpairs of Xc^T Xc
     DBuf C(c.dev, sizeof(double) * dp * dp), U(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp);
     DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp);
-    op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp);
+    op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
     allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
     op_eigh(c.dev, C.f64(), dp, dp, U.f64(), dp, lam.f64());
     op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);

@@ -1097,10 +1097,10 @@ static void launch_atb(Dev* d, const float* A, int64_t lda, int M, const float* 
 }
 
 void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const void* muA, const void* B, int64_t ldb, int64_t N,
-                 const void* muB, int64_t n, double* C, int64_t ldc) {
+                 const void* muB, int64_t n, double* C, int64_t ldc, bool precise) {
     if (M == 0 || N == 0) return;
     if (n == 0) { HIP_CHECK(hipMemset2DAsync(C, ldc * sizeof(double), 0, N * sizeof(double), M, d->stream)); return; }
-    const bool mfma = dt == F32 && M % 16 == 0 && N % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B) &&
+    const bool mfma = !precise && dt == F32 && M % 16 == 0 && N % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B) &&
                       (!muA || aligned16(muA)) && (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
     if (!mfma) {
         const int64_t nparts = cdiv(n, ATB_S_ROWS);

@@ -58,10 +58,12 @@ void op_colsum(Dev*, int dtype, const void* X, int64_t n, int64_t d, int64_t ldx
 void op_gemm_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
                 const double* P, int64_t N, int64_t ldp, const void* bias,
                 void* Z, int64_t ldz, double* sumsq);
-// C[M x N] (f64, ldc) = (A - muA)^T . (B - muB),  A: n x M (lda), B: n x N (ldb), reduction over n rows
+// C[M x N] (f64, ldc) = (A - muA)^T . (B - muB),  A: n x M (lda), B: n x N (ldb), reduction over n rows.
+// precise: every product and the whole accumulation in fp64 (needed where the result's small eigenvalues
+// matter: exact Pca, FastICA whitening); otherwise fp32 MFMA chunks combined in fp64.
 void op_gemm_atb(Dev*, int dtype, const void* A, int64_t lda, int64_t M, const void* muA,
                  const void* B, int64_t ldb, int64_t N, const void* muB, int64_t n,
-                 double* C, int64_t ldc);
+                 double* C, int64_t ldc, bool precise = false);
 // per column j < L of U (n x L): absmax[j] = max_i |U_ij|, idx[j] = row_offset + first such i,
 // sign[j] = U_ij >= 0 ? +1 : -1 (sign of -0.0 / 0.0 follows f64::signum: +1 for +0, -1 for -0).
 // n == 0: absmax = -1, idx = +inf, sign = +1.
