@@ -98,16 +98,15 @@ std::vector<double> flip_signs(petal_ctx& c, int dtype, const void* U, int64_t n
     return sg;
 }
 
-// Y (M x LP, f64) <- orthonormal basis of range(Y) by two rounds of Cholesky-QR in fp64
-// (stands where the reference re-bases the small d x l iterate with pivoted LU, pca.rs:712-713).
+// Y (M x LP, f64) <- orthonormal basis of range(Y) by Cholesky-QR in fp64 (stands where the reference re-bases
+// the small d x l iterate with pivoted LU, pca.rs:712-713).  One round leaves ||Y^T Y - I|| ~ 1e-16 cond(Y)^2,
+// far below the fp32 rounding the basis undergoes when it is packed for the MFMA kernel.
 void orthonormalize_small(petal_ctx& c, DBuf& Y, int64_t M, int64_t LP, double tol) {
     DBuf G(c.dev, sizeof(double) * LP * LP), T(c.dev, sizeof(double) * LP * LP), Y2(c.dev, Y.bytes);
-    for (int rep = 0; rep < 2; ++rep) {
-        op_dgemm(c.dev, true, false, LP, LP, M, 1.0, Y.f64(), LP, Y.f64(), LP, 0.0, G.f64(), LP);
-        op_chol_inv(c.dev, G.f64(), LP, LP, T.f64(), LP, tol);
-        op_dgemm(c.dev, false, false, M, LP, LP, 1.0, Y.f64(), LP, T.f64(), LP, 0.0, Y2.f64(), LP);
-        std::swap(Y, Y2);
-    }
+    op_dgemm(c.dev, true, false, LP, LP, M, 1.0, Y.f64(), LP, Y.f64(), LP, 0.0, G.f64(), LP);
+    op_chol_inv(c.dev, G.f64(), LP, LP, T.f64(), LP, tol);
+    op_dgemm(c.dev, false, false, M, LP, LP, 1.0, Y.f64(), LP, T.f64(), LP, 0.0, Y2.f64(), LP);
+    std::swap(Y, Y2);
 }
 
 struct Timer {
@@ -293,7 +292,10 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     DBuf S(c.dev, sizeof(double) * LP * LP), Uh(c.dev, sizeof(double) * LP * LP), lam(c.dev, sizeof(double) * LP);
     DBuf sig(c.dev, sizeof(double) * LP), inv(c.dev, sizeof(double) * LP);
     op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Bt.f64(), LP, Bt.f64(), LP, 0.0, S.f64(), LP);
-    op_eigh(c.dev, S.f64(), LP, LP, Uh.f64(), LP, lam.f64());
+    // only the leading L x L block of S is non-zero (columns L..LP-1 of every iterate are exact zero padding)
+    dev_memset(c.dev, Uh.p, 0, Uh.bytes);
+    dev_memset(c.dev, lam.p, 0, lam.bytes);
+    op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam.f64());
     op_dvec(c.dev, 0, lam.f64(), sig.f64(), LP, 0.0);
     op_dvec(c.dev, 1, sig.f64(), inv.f64(), LP, dt == F32 ? 1e-7 : 1e-12);
     DBuf V(c.dev, sizeof(double) * dp * LP);  // V[:, j] = B^T u_j / sigma_j

@@ -37,6 +37,13 @@ namespace petal {
     } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef PETAL_DEBUG_COUNTERS
+__device__ int g_dbg[4];
+__device__ long long g_cyc[8];
+#define DBG_T(i) do { if (threadIdx.x == 0) { long long _t = clock64(); g_cyc[i] += _t - _t0; _t0 = _t; } } while (0)
+#else
+#define DBG_T(i) do {} while (0)
+#endif
 
 // ================================================================================================
 // Dev
@@ -216,27 +223,38 @@ __global__ void k_colsum_part(const T* __restrict__ X, int64_t n, int64_t d, int
     for (int64_t i = r0; i < r1; ++i) s += (double)X[i * ldx + j];
     part[(int64_t)blockIdx.x * d + j] = s;
 }
-__global__ void k_sum_parts(const double* __restrict__ part, int64_t nparts, int64_t count, double* __restrict__ out) {
-    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (j >= count) return;
+// out[(e / N) * ldc + e % N] = sum_p part[p * count + e]  (fp64 accumulation, fixed order => deterministic).
+// block = 32 elements x 8 part-lanes.
+template <class TP>
+__global__ __launch_bounds__(256) void k_sum_parts2(const TP* __restrict__ part, int64_t nparts, int64_t count,
+                                                    double* __restrict__ out, int64_t N, int64_t ldc, bool accumulate) {
+    __shared__ double red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + tx;
     double s = 0;
-    for (int64_t p = 0; p < nparts; ++p) s += part[p * count + j];
-    out[j] = s;
-}
-__global__ void k_reduce_partials_f32(const float* __restrict__ part, int64_t nparts, int64_t M, int64_t N,
-                                      double* __restrict__ C, int64_t ldc) {
-    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (e >= M * N) return;
-    double s = 0;
-    for (int64_t p = 0; p < nparts; ++p) s += (double)part[p * M * N + e];
-    C[(e / N) * ldc + (e % N)] = s;
-}
-__global__ void k_add_scalar_parts(const double* __restrict__ part, int64_t nparts, double* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0;
-        for (int64_t p = 0; p < nparts; ++p) s += part[p];
-        out[0] += s;
+    if (e < count)
+        for (int64_t p = ty; p < nparts; p += 8) s += (double)part[p * count + e];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < count) {
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][tx];
+        double* o = out + (e / N) * ldc + (e % N);
+        *o = accumulate ? *o + t : t;
     }
+}
+__global__ __launch_bounds__(256) void k_add_scalar_parts(const double* __restrict__ part, int64_t nparts, double* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0;
+    for (int64_t p = threadIdx.x; p < nparts; p += 256) s += part[p];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += red[0];
 }
 
 template <class T>
@@ -274,15 +292,6 @@ __global__ void k_atb_simple(const T* __restrict__ A, int64_t lda, int64_t M, co
     for (int64_t i = r0; i < r1; ++i) s += (double)(T)(A[i * lda + m] - ma) * (double)(T)(B[i * ldb + j] - mb);
     part[((int64_t)blockIdx.x * M + m) * N + j] = s;
 }
-__global__ void k_reduce_partials_f64(const double* __restrict__ part, int64_t nparts, int64_t M, int64_t N,
-                                      double* __restrict__ C, int64_t ldc) {
-    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (e >= M * N) return;
-    double s = 0;
-    for (int64_t p = 0; p < nparts; ++p) s += part[p * M * N + e];
-    C[(e / N) * ldc + (e % N)] = s;
-}
-
 template <class T>
 __global__ void k_absmax_part(const T* __restrict__ U, int64_t n, int64_t L, int64_t ldu, double* __restrict__ pmax,
                               double* __restrict__ pidx, double* __restrict__ psgn) {
@@ -297,17 +306,24 @@ __global__ void k_absmax_part(const T* __restrict__ U, int64_t n, int64_t L, int
     const int64_t o = (int64_t)blockIdx.x * L + j;
     pmax[o] = best; pidx[o] = bi; psgn[o] = bs;
 }
-__global__ void k_absmax_final(const double* __restrict__ pmax, const double* __restrict__ pidx, const double* __restrict__ psgn,
-                               int64_t nparts, int64_t L, int64_t row_offset, double* __restrict__ omax,
-                               double* __restrict__ oidx, double* __restrict__ osgn) {
-    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (j >= L) return;
-    double best = -1.0, bi = INFINITY, bs = 1.0;
-    for (int64_t p = 0; p < nparts; ++p) {  // chunks in row order + strict '>' keeps the FIRST maximum (pca.rs:830)
+// one wave per column: lanes scan the row chunks in order (strict '>' keeps the first maximum, pca.rs:830),
+// then a lexicographic (larger |u|, then smaller row) butterfly picks the winner.
+__global__ __launch_bounds__(64) void k_absmax_final(const double* __restrict__ pmax, const double* __restrict__ pidx,
+                                                     const double* __restrict__ psgn, int64_t nparts, int64_t L,
+                                                     int64_t row_offset, double* __restrict__ omax, double* __restrict__ oidx,
+                                                     double* __restrict__ osgn) {
+    const int64_t j = blockIdx.x;
+    const int lane = threadIdx.x;
+    double best = -2.0, bi = INFINITY, bs = 1.0;
+    for (int64_t p = lane; p < nparts; p += 64) {
         const double a = pmax[p * L + j];
-        if (p == 0 || a > best) { best = a; bi = pidx[p * L + j] + (double)row_offset; bs = psgn[p * L + j]; }
+        if (a > best) { best = a; bi = pidx[p * L + j]; bs = psgn[p * L + j]; }
     }
-    omax[j] = best; oidx[j] = bi; osgn[j] = bs;
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(best, off, 64), oi = __shfl_down(bi, off, 64), os = __shfl_down(bs, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; bs = os; }
+    }
+    if (lane == 0) { omax[j] = best; oidx[j] = bi + (double)row_offset; osgn[j] = bs; }
 }
 template <class T>
 __global__ void k_scale_cols(T* __restrict__ A, int64_t n, int64_t L, int64_t lda, const double* __restrict__ s) {
@@ -355,10 +371,10 @@ __global__ void k_pack_p(const double* __restrict__ P, int64_t K, int64_t N, int
 }
 
 template <int RT, int NT, bool CENTER, bool SUMSQ>
-__global__ __launch_bounds__(256) void k_xp_mfma(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
-                                                 const float* __restrict__ mu, const float* __restrict__ Ppk, int NTtot,
-                                                 int nt0, int N, const float* __restrict__ bias, float* __restrict__ Z,
-                                                 int64_t ldz, double* __restrict__ ss_part) {
+__global__ __launch_bounds__(256, 2) void k_xp_mfma(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
+                                                    const float* __restrict__ mu, const float* __restrict__ Ppk, int NTtot,
+                                                    int nt0, int N, const float* __restrict__ bias, float* __restrict__ Z,
+                                                    int64_t ldz, double* __restrict__ ss_part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
@@ -380,25 +396,22 @@ __global__ __launch_bounds__(256) void k_xp_mfma(const float* __restrict__ X, in
         xrow[t] = X + (rvalid[t] ? r : (n - 1)) * ldx + 4 * q;
     }
     const f32x4* pb = reinterpret_cast<const f32x4*>(Ppk) + (int64_t)nt0 * 64 + lane;
+    const float* mup = mu + 4 * q;
     float ssq = 0.f;
     const int nchunk = K >> 4;
-    f32x4 a[RT], b[NT], m4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one 16-deep K chunk: RT + NT (+1) independent 16-B loads per lane, then 4 RT NT MFMAs
+    auto load_chunk = [&](int c, f32x4(&a)[RT], f32x4(&b)[NT], f32x4& m) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const f32x4*>(xrow[t]);
+        for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const f32x4*>(xrow[t] + 16 * c);
 #pragma unroll
-    for (int u = 0; u < NT; ++u) b[u] = pb[(int64_t)u * 64];
-    if (CENTER) m4 = *reinterpret_cast<const f32x4*>(mu + 4 * q);
-    for (int c = 0; c < nchunk; ++c) {
-        f32x4 an[RT], bn[NT], mn = m4;
-        const int cn = (c + 1 < nchunk) ? c + 1 : c;  // prefetch the next chunk (re-reads the last one at the end)
-#pragma unroll
-        for (int t = 0; t < RT; ++t) an[t] = *reinterpret_cast<const f32x4*>(xrow[t] + 16 * cn);
-#pragma unroll
-        for (int u = 0; u < NT; ++u) bn[u] = pb[((int64_t)cn * NTtot + u) * 64];
-        if (CENTER) mn = *reinterpret_cast<const f32x4*>(mu + 16 * cn + 4 * q);
+        for (int u = 0; u < NT; ++u) b[u] = pb[((int64_t)c * NTtot + u) * 64];
+        if (CENTER) m = *reinterpret_cast<const f32x4*>(mup + 16 * c);
+    };
+    auto compute = [&](f32x4(&a)[RT], f32x4(&b)[NT], const f32x4& m) {
         if (CENTER) {
 #pragma unroll
-            for (int t = 0; t < RT; ++t) a[t] -= m4;
+            for (int t = 0; t < RT; ++t) a[t] -= m;
         }
         if (SUMSQ) {
 #pragma unroll
@@ -412,12 +425,24 @@ __global__ __launch_bounds__(256) void k_xp_mfma(const float* __restrict__ X, in
 #pragma unroll
                 for (int u = 0; u < NT; ++u)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b[u][s], acc[t][u], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) a[t] = an[t];
-#pragma unroll
-        for (int u = 0; u < NT; ++u) b[u] = bn[u];
-        m4 = mn;
+    };
+    // software pipeline, two register stages: the loads of chunk c+1 are in flight while chunk c feeds the MFMAs.
+    // sched_barrier(0) pins the issue order (hipcc otherwise sinks the prefetch below the MFMAs and drains vmcnt(0)).
+    f32x4 a0[RT], b0[NT], a1[RT], b1[NT];
+    f32x4 m0 = f32x4{0.f, 0.f, 0.f, 0.f}, m1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_chunk(0, a0, b0, m0);
+    int c = 0;
+    for (; c + 2 <= nchunk; c += 2) {
+        load_chunk(c + 1, a1, b1, m1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a0, b0, m0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(c + 2 < nchunk ? c + 2 : nchunk - 1, a0, b0, m0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a1, b1, m1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (c < nchunk) compute(a0, b0, m0);
     // epilogue: D[row = 4 q + r][col = i] per tile
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -433,9 +458,9 @@ __global__ __launch_bounds__(256) void k_xp_mfma(const float* __restrict__ X, in
             }
     }
     if (SUMSQ) {
-        double s = (double)ssq;
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) ss_part[(int64_t)blockIdx.x * 4 + wave] = s;
+        double sred = (double)ssq;
+        for (int off = 32; off > 0; off >>= 1) sred += __shfl_down(sred, off, 64);
+        if (lane == 0) ss_part[(int64_t)blockIdx.x * 4 + wave] = sred;
     }
 }
 
@@ -447,59 +472,63 @@ __global__ __launch_bounds__(256) void k_xp_mfma(const float* __restrict__ X, in
 // 16-B loads of B give col tiles in groups of four (tile 4 g + e, col j  <->  col = 64 g + 4 j + e) plus
 // scalar loads for the NT % 4 remaining tiles.
 template <int NT, bool CA, bool CB>
-__global__ __launch_bounds__(256) void k_atb_mfma(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
-                                                  const float* __restrict__ B, int64_t ldb, int N, int n0col,
-                                                  const float* __restrict__ muB, int64_t n, int64_t chunk,
-                                                  float* __restrict__ part, int Npart) {
+__global__ __launch_bounds__(256, 2) void k_atb_mfma(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
+                                                     const float* __restrict__ B, int64_t ldb, int N, int n0col,
+                                                     const float* __restrict__ muB, int64_t n, int64_t chunk,
+                                                     float* __restrict__ part, int Npart) {
     constexpr int G4 = NT / 4, R1 = NT % 4;
+    constexpr int G4n = G4 > 0 ? G4 : 1, R1n = R1 > 0 ? R1 : 1;
+    constexpr int UN = 4;  // k-steps (of 4 rows) per pipeline stage: 16 rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int m0 = (blockIdx.x * 4 + wave) * 64;
     if (m0 >= M) return;
     const int64_t rbeg = (int64_t)blockIdx.y * chunk, rend = min(n, rbeg + chunk);
-    const bool mvalid = (m0 + 4 * i) < M;
-    bool gvalid[G4 > 0 ? G4 : 1], evalid[R1 > 0 ? R1 : 1];
+    // Columns beyond M / N are never stored, so their loads are simply clamped into the row (any finite value
+    // will do); rows beyond rend must contribute nothing: only the ragged tail stage masks them (B := 0).
+    const float* ap = A + min(m0 + 4 * i, M - 4);
+    const float* bp4[G4n];
+    const float* bp1[R1n];
 #pragma unroll
-    for (int g = 0; g < G4; ++g) gvalid[g] = (n0col + 64 * g + 4 * i) < N;
+    for (int g = 0; g < G4; ++g) bp4[g] = B + min(n0col + 64 * g + 4 * i, N - 4);
 #pragma unroll
-    for (int e = 0; e < R1; ++e) evalid[e] = (n0col + 64 * G4 + 16 * e + i) < N;
+    for (int e = 0; e < R1; ++e) bp1[e] = B + min(n0col + 64 * G4 + 16 * e + i, N - 1);
     f32x4 ma = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (CA && mvalid) ma = *reinterpret_cast<const f32x4*>(muA + m0 + 4 * i);
-    f32x4 mb4[G4 > 0 ? G4 : 1];
-    float mb1[R1 > 0 ? R1 : 1];
+    if (CA) ma = *reinterpret_cast<const f32x4*>(muA + min(m0 + 4 * i, M - 4));
+    f32x4 mb4[G4n];
+    float mb1[R1n];
     if (CB) {
 #pragma unroll
-        for (int g = 0; g < G4; ++g) mb4[g] = gvalid[g] ? *reinterpret_cast<const f32x4*>(muB + n0col + 64 * g + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < G4; ++g) mb4[g] = *reinterpret_cast<const f32x4*>(muB + min(n0col + 64 * g + 4 * i, N - 4));
 #pragma unroll
-        for (int e = 0; e < R1; ++e) mb1[e] = evalid[e] ? muB[n0col + 64 * G4 + 16 * e + i] : 0.f;
+        for (int e = 0; e < R1; ++e) mb1[e] = muB[min(n0col + 64 * G4 + 16 * e + i, N - 1)];
     }
     f32x4 acc[4][NT];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* ap = A + m0 + 4 * i;
-    const float* bp = B + n0col;
-    constexpr int UN = 4;  // k-steps (of 4 rows) per loop iteration
-    for (int64_t r0 = rbeg; r0 < rend; r0 += 4 * UN) {
-        f32x4 av[UN], b4[UN][G4 > 0 ? G4 : 1];
-        float b1[UN][R1 > 0 ? R1 : 1];
+
+    auto load_stage = [&](int64_t r0, f32x4(&av)[UN], f32x4(&b4)[UN][G4n], float(&b1)[UN][R1n]) {
 #pragma unroll
         for (int s = 0; s < UN; ++s) {
             const int64_t r = r0 + 4 * s + q;
-            const bool rv = r < rend;
-            const int64_t rc = rv ? r : rbeg;
-            av[s] = (rv && mvalid) ? *reinterpret_cast<const f32x4*>(ap + rc * lda) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (CA && rv && mvalid) av[s] -= ma;
+            av[s] = *reinterpret_cast<const f32x4*>(ap + r * lda);
 #pragma unroll
-            for (int g = 0; g < G4; ++g) {
-                b4[s][g] = (rv && gvalid[g]) ? *reinterpret_cast<const f32x4*>(bp + rc * ldb + 64 * g + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-                if (CB && rv && gvalid[g]) b4[s][g] -= mb4[g];
-            }
+            for (int g = 0; g < G4; ++g) b4[s][g] = *reinterpret_cast<const f32x4*>(bp4[g] + r * ldb);
 #pragma unroll
-            for (int e = 0; e < R1; ++e) {
-                b1[s][e] = (rv && evalid[e]) ? bp[rc * ldb + 64 * G4 + 16 * e + i] : 0.f;
-                if (CB && rv && evalid[e]) b1[s][e] -= mb1[e];
+            for (int e = 0; e < R1; ++e) b1[s][e] = bp1[e][r * ldb];
+        }
+    };
+    auto compute_stage = [&](f32x4(&av)[UN], f32x4(&b4)[UN][G4n], float(&b1)[UN][R1n]) {
+#pragma unroll
+        for (int s = 0; s < UN; ++s) {
+            if (CA) av[s] -= ma;
+            if (CB) {
+#pragma unroll
+                for (int g = 0; g < G4; ++g) b4[s][g] -= mb4[g];
+#pragma unroll
+                for (int e = 0; e < R1; ++e) b1[s][e] -= mb1[e];
             }
         }
 #pragma unroll
@@ -515,6 +544,55 @@ __global__ __launch_bounds__(256) void k_atb_mfma(const float* __restrict__ A, i
                 for (int e = 0; e < R1; ++e)
                     acc[t][4 * G4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], b1[s][e], acc[t][4 * G4 + e], 0, 0, 0);
             }
+    };
+    // software pipeline over the full 16-row stages, two register stages (see k_xp_mfma)
+    const int64_t nfull = (rend - rbeg) / (4 * UN);
+    f32x4 av0[UN], b40[UN][G4n], av1[UN], b41[UN][G4n];
+    float b10[UN][R1n], b11[UN][R1n];
+    if (nfull > 0) {
+        load_stage(rbeg, av0, b40, b10);
+        int64_t st = 0;
+        for (; st + 2 <= nfull; st += 2) {
+            load_stage(rbeg + (st + 1) * 4 * UN, av1, b41, b11);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_stage(av0, b40, b10);
+            __builtin_amdgcn_sched_barrier(0);
+            load_stage(rbeg + (st + 2 < nfull ? st + 2 : nfull - 1) * 4 * UN, av0, b40, b10);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_stage(av1, b41, b11);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (st < nfull) compute_stage(av0, b40, b10);
+    }
+    {   // ragged tail (< 16 rows): rows past rend are read from a clamped row and masked to zero on the B side
+        const int64_t r0 = rbeg + nfull * 4 * UN;
+        for (int64_t rs = r0; rs < rend; rs += 4) {
+            const int64_t r = rs + q;
+            const bool rv = r < rend;
+            const int64_t rc = rv ? r : rend - 1;
+            f32x4 a1 = *reinterpret_cast<const f32x4*>(ap + rc * lda);
+            if (CA) a1 -= ma;
+#pragma unroll
+            for (int g = 0; g < G4; ++g) {
+                f32x4 bv = *reinterpret_cast<const f32x4*>(bp4[g] + rc * ldb);
+                if (CB) bv -= mb4[g];
+                if (!rv) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[t][4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], bv[e], acc[t][4 * g + e], 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < R1; ++e) {
+                float bv = bp1[e][rc * ldb];
+                if (CB) bv -= mb1[e];
+                if (!rv) bv = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t][4 * G4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], bv, acc[t][4 * G4 + e], 0, 0, 0);
+            }
+        }
     }
     // D[row = 4 q + r][col = i] of tile (t, u):  m = m0 + 4 (4 q + r) + t;  col from the B grouping
     float* out = part + (int64_t)blockIdx.y * M * Npart;
@@ -730,51 +808,120 @@ __global__ void k_dgemm(bool ta, bool tb, int64_t M, int64_t N, int64_t K, doubl
     if (i < M && j < N) C[i * ldc + j] = alpha * acc + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
 }
 
-// one workgroup; R (L x L scratch) and T in global memory (L2 resident)
-__global__ __launch_bounds__(1024) void k_chol_inv(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ R,
-                                                   double* __restrict__ T, int64_t ldt, double rel_tol, int* __restrict__ dead) {
+// One workgroup.  The working copy of G lives in LDS as a packed upper triangle (L (L+1) / 2 doubles, 83.5 KB at
+// L = 144); T = R^-1 is built in LDS too when it fits, else directly in global memory.
+//   factorisation: right-looking, ONE barrier per column: rows are left unscaled (U[j][c], d_j = U[j][j]) and the
+//                  trailing update uses U[j][r] U[j][c] / d_j; R = diag(d)^-1/2 U is formed in one pass afterwards.
+//                  A pivot d_j <= rel_tol * G_jj (or G_jj <= 0) marks column j as dependent: row/column j := 0.
+//   inverse:       blocked (16 x 16): diagonal blocks by substitution, then block super-diagonals
+//                  T_IJ = -T_II (sum_K R_IK T_KJ): 1 + 3 (L/16 - 1) barriers.
+constexpr int CHOL_THREADS = 512;
+__device__ __forceinline__ int pk(int r, int c, int L) { return r * L - (r * (r - 1)) / 2 + (c - r); }
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T,
+                                                           int64_t ldt, double rel_tol, int t_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) double sm_chol[];
     const int tid = threadIdx.x, nt = blockDim.x;
-    __shared__ double s_piv;
-    __shared__ int s_dead;
+    const int np = L * (L + 1) / 2;
+    double* Rw = sm_chol;
+    double* gd = Rw + np;
+    int* dead = reinterpret_cast<int*>(gd + L);
+    double* Tl = t_in_lds ? (gd + L + (L + 1) / 2) : T;
+    const int64_t tl = t_in_lds ? L : ldt;
     for (int e = tid; e < L * L; e += nt) {
         const int r = e / L, c = e % L;
-        R[e] = c >= r ? G[(int64_t)r * ldg + c] : 0.0;
-        T[(int64_t)r * ldt + c] = 0.0;
+        if (c >= r) Rw[pk(r, c, L)] = G[(int64_t)r * ldg + c];
+        if (c == r) gd[r] = G[(int64_t)r * ldg + c];
+        Tl[(int64_t)r * tl + c] = 0.0;
     }
     __syncthreads();
-    for (int j = 0; j < L; ++j) {  // right-looking upper Cholesky G = R^T R with dependent-column dropping
-        if (tid == 0) {
-            const double s = R[j * L + j], gjj = G[(int64_t)j * ldg + j];
-            const bool dd = !(gjj > 0.0) || !(s > rel_tol * gjj);
-            s_dead = dd;
-            s_piv = dd ? 0.0 : sqrt(s);
-            dead[j] = dd;
-        }
-        __syncthreads();
-        const double piv = s_piv;
-        const bool dd = s_dead != 0;
-        for (int c = j + tid; c < L; c += nt) R[j * L + c] = dd ? 0.0 : (c == j ? piv : R[j * L + c] / piv);
-        __syncthreads();
-        if (!dd) {
-            const int rem = L - 1 - j;
-            for (int e = tid; e < rem * rem; e += nt) {
-                const int r = j + 1 + e / rem, c = j + 1 + e % rem;
-                if (c >= r) R[r * L + c] -= R[j * L + r] * R[j * L + c];
+#ifdef PETAL_DEBUG_COUNTERS
+    long long _t0 = clock64();
+#endif
+    for (int j = 0; j < L; ++j) {
+        const double dj = Rw[pk(j, j, L)], gj = gd[j];
+        const bool ok = (gj > 0.0) && (dj > rel_tol * gj);
+        if (tid == 0) dead[j] = ok ? 0 : 1;
+        if (ok) {  // threads as a 16 x 32 grid over (r, c): no integer division in the update loop
+            const double inv = 1.0 / dj;
+            const int ty = tid >> 5, tx = tid & 31;
+            const double* uj = Rw + pk(j, j, L) - j;  // uj[c] = U[j][c]
+            for (int r = j + 1 + ty; r < L; r += 16) {
+                const double f = uj[r] * inv;
+                double* rr = Rw + pk(r, r, L) - r;     // rr[c] = Rw[r][c], c >= r
+                for (int c = r + tx; c < L; c += 32) rr[c] -= f * uj[c];
             }
         }
         __syncthreads();
     }
-    // T = R^{-1}: one thread per column, back substitution; dead rows/columns stay zero
-    for (int j = tid; j < L; j += nt) {
-        if (dead[j]) continue;
-        T[(int64_t)j * ldt + j] = 1.0 / R[j * L + j];
-        for (int r = j - 1; r >= 0; --r) {
-            if (dead[r]) continue;
-            double s = 0;
-            for (int k = r + 1; k <= j; ++k) s += R[r * L + k] * T[(int64_t)k * ldt + j];
-            T[(int64_t)r * ldt + j] = -s / R[r * L + r];
+    for (int r = tid; r < L; r += nt) gd[r] = dead[r] ? 0.0 : Rw[pk(r, r, L)];
+    __syncthreads();
+    for (int e = tid; e < L * L; e += nt) {
+        const int r = e / L, c = e % L;
+        if (c >= r) {
+            const double dr = gd[r];
+            Rw[pk(r, c, L)] = (dr > 0.0 && !dead[c]) ? Rw[pk(r, c, L)] / sqrt(dr) : 0.0;
         }
     }
+    __syncthreads();
+    DBG_T(6);
+    // ---- blocked inverse ----
+    const int nb = (L + 15) / 16;
+    for (int t = tid; t < nb * 16; t += nt) {  // diagonal blocks: one thread per column, substitution inside the block
+        const int bI = t / 16, j = t;
+        if (j < L && !dead[j]) {
+            Tl[(int64_t)j * tl + j] = 1.0 / Rw[pk(j, j, L)];
+            for (int r = j - 1; r >= 16 * bI; --r) {
+                if (dead[r]) continue;
+                double sacc = 0;
+                for (int k = r + 1; k <= j; ++k) sacc += Rw[pk(r, k, L)] * Tl[(int64_t)k * tl + j];
+                Tl[(int64_t)r * tl + j] = -sacc / Rw[pk(r, r, L)];
+            }
+        }
+    }
+    __syncthreads();
+    for (int dl = 1; dl < nb; ++dl) {
+        const int nblk = nb - dl, nel = nblk * 256;
+        // (a) W_IJ = sum_{K = I+1 .. J} R_IK T_KJ, parked in T_IJ's (still zero) slot
+        for (int e = tid; e < nel; e += nt) {
+            const int bI = e / 256, r = 16 * bI + (e % 256) / 16, c = 16 * (bI + dl) + (e % 16);
+            if (r < L && c < L) {
+                double w = 0;
+                const int k1 = min(L, 16 * (bI + dl + 1));
+                for (int k = 16 * (bI + 1); k < k1; ++k) w += Rw[pk(r, k, L)] * Tl[(int64_t)k * tl + c];
+                Tl[(int64_t)r * tl + c] = w;
+            }
+        }
+        __syncthreads();
+        // (b) T_IJ = -T_II W_IJ (results held in registers across the barrier: W is overwritten in place)
+        double res[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = tid + it * nt;
+            res[it] = 0;
+            if (e < nel) {
+                const int bI = e / 256, r = 16 * bI + (e % 256) / 16, c = 16 * (bI + dl) + (e % 16);
+                if (r < L && c < L) {
+                    double t2 = 0;
+                    const int m1 = min(L, 16 * (bI + 1));
+                    for (int m = r; m < m1; ++m) t2 += Tl[(int64_t)r * tl + m] * Tl[(int64_t)m * tl + c];
+                    res[it] = -t2;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = tid + it * nt;
+            if (e < nel) {
+                const int bI = e / 256, r = 16 * bI + (e % 256) / 16, c = 16 * (bI + dl) + (e % 16);
+                if (r < L && c < L) Tl[(int64_t)r * tl + c] = res[it];
+            }
+        }
+        __syncthreads();
+    }
+    DBG_T(7);
+    if (t_in_lds)
+        for (int e = tid; e < L * L; e += nt) T[(int64_t)(e / L) * ldt + (e % L)] = Tl[e];
 }
 
 // ---- workgroup-wide cyclic Jacobi eigen-solver (fp64) ----------------------------------------------
@@ -787,6 +934,7 @@ __device__ void wg_jacobi(double* A, int64_t lda, double* V, int64_t ldv, int L,
     __syncthreads();
     if (L < 2) return;
     const int Le = (L + 1) & ~1, half = Le / 2, rounds = Le - 1;
+    bool last = false;
     for (int sweep = 0; sweep < 40; ++sweep) {
         // convergence: off^2 <= 1e-30 diag^2
         double off = 0, dg = 0;
@@ -803,7 +951,9 @@ __device__ void wg_jacobi(double* A, int64_t lda, double* V, int64_t ldv, int L,
         }
         const double toff = s_red[0], tdg = s_red[nt];
         __syncthreads();
-        if (!(toff > 1e-30 * tdg)) break;
+        // quadratic convergence: once off/diag <= 1e-11 one more sweep brings it to rounding level
+        if (!(toff > 1e-30 * tdg) || last) break;
+        if (!(toff > 1e-22 * tdg)) last = true;
         for (int rd = 0; rd < rounds; ++rd) {
             for (int k = tid; k < half; k += nt) {
                 int p, q;
@@ -849,6 +999,133 @@ __device__ void wg_jacobi(double* A, int64_t lda, double* V, int64_t ldv, int L,
         }
     }
 }
+// LDS-resident variant for L <= 16 MB (MB <= 8): A and V are L x L with leading dimension L.  Threads form an
+// (L rows) x (8 pair-lanes) grid for the column phase and a (L/2 pairs) x (16 column-lanes) grid for the row phase;
+// every thread first gathers all its operands into registers, then scatters the rotated values, so the LDS round
+// trips of one phase overlap instead of serialising behind possibly-aliasing stores.
+template <int MB>
+__device__ void wg_jacobi_fast(double* A, double* V, int L, double* s_c, double* s_s, int* s_p, int* s_q, double* s_red) {
+    const int LD = L | 1;  // odd leading dimension: column accesses (stride LD doubles) spread over all LDS banks
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    for (int e = tid; e < L * LD; e += nt) V[e] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < L; e += nt) V[e * LD + e] = 1.0;
+    __syncthreads();
+    if (L < 2) return;
+    const int Le = (L + 1) & ~1, half = Le / 2, rounds = Le - 1;
+    bool last = false;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double tot = 0, dg = 0;  // off-diagonal and diagonal energy, accumulated separately (no cancellation)
+        {
+            int r = tid / L, c = tid - r * L;  // one division per sweep; then advance (r, c) by nt elements
+            const int dr = nt / L, dc = nt - dr * L;
+            for (int e = tid; e < L * L; e += nt) {
+                const double v = A[r * LD + c];
+                if (r == c) dg += v * v; else tot += v * v;
+                r += dr; c += dc;
+                if (c >= L) { c -= L; ++r; }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) { tot += __shfl_down(tot, off, 64); dg += __shfl_down(dg, off, 64); }
+        if (lane == 0) { s_red[wv] = tot; s_red[32 + wv] = dg; }
+        __syncthreads();
+        double toff = 0, tdg = 0;
+        for (int w = 0; w < nw; ++w) { toff += s_red[w]; tdg += s_red[32 + w]; }
+        __syncthreads();
+#ifdef PETAL_DEBUG_COUNTERS
+        if (tid == 0) g_dbg[0] = sweep;
+#endif
+        if (!(toff > 1e-30 * tdg) || last) break;
+        if (!(toff > 1e-17 * tdg)) last = true;  // quadratic convergence: one more sweep reaches rounding level
+        for (int rd = 0; rd < rounds; ++rd) {
+#ifdef PETAL_DEBUG_COUNTERS
+            long long _t0 = clock64();
+#endif
+            if (tid < half) {
+                const int k = tid;
+                int p, q;
+                if (k == 0) { p = Le - 1; q = rd; }
+                else { p = rd + k; if (p >= Le - 1) p -= Le - 1; q = rd - k; if (q < 0) q += Le - 1; }
+                if (p > q) { const int t = p; p = q; q = t; }
+                double c = 1.0, sn = 0.0;
+                if (q < L) {
+                    const double apq = A[p * LD + q];
+                    if (apq != 0.0) {
+                        const double theta = (A[q * LD + q] - A[p * LD + p]) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(t * t + 1.0);
+                        sn = t * c;
+                    }
+                } else { q = p; }  // bye
+                s_p[k] = p; s_q[k] = q; s_c[k] = c; s_s[k] = sn;
+            }
+            DBG_T(0);
+            __syncthreads();
+            DBG_T(1);
+            {   // columns: A <- A J, V <- V J
+                const int kk = tid & 7;
+                for (int r = tid >> 3; r < L; r += nt >> 3) {
+                    double ap[MB], aq[MB], vp[MB], vq[MB], cc[MB], sn[MB];
+                    int pp[MB], qq[MB];
+                    double* ar = A + r * LD;
+                    double* vr = V + r * LD;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        const int k = min(kk + 8 * m, half - 1);
+                        const int p = s_p[k], q = s_q[k];
+                        pp[m] = p;
+                        qq[m] = (kk + 8 * m < half && p != q) ? q : -1;
+                        cc[m] = s_c[k]; sn[m] = s_s[k];
+                        ap[m] = ar[p]; aq[m] = ar[q]; vp[m] = vr[p]; vq[m] = vr[q];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        if (qq[m] >= 0) {
+                            ar[pp[m]] = cc[m] * ap[m] - sn[m] * aq[m];
+                            ar[qq[m]] = sn[m] * ap[m] + cc[m] * aq[m];
+                            vr[pp[m]] = cc[m] * vp[m] - sn[m] * vq[m];
+                            vr[qq[m]] = sn[m] * vp[m] + cc[m] * vq[m];
+                        }
+                    }
+                }
+            }
+            DBG_T(2);
+            __syncthreads();
+            DBG_T(3);
+            {   // rows: A <- J^T A
+                const int c0 = tid & 15;
+                for (int k = tid >> 4; k < half; k += nt >> 4) {
+                    const int p = s_p[k], q = s_q[k];
+                    if (p == q) continue;
+                    const double c = s_c[k], sn = s_s[k];
+                    double ap[MB], aq[MB];
+                    double* rp = A + p * LD;
+                    double* rq = A + q * LD;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        const int col = min(c0 + 16 * m, L - 1);
+                        ap[m] = rp[col]; aq[m] = rq[col];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        const int col = c0 + 16 * m;
+                        if (col < L) { rp[col] = c * ap[m] - sn * aq[m]; rq[col] = sn * ap[m] + c * aq[m]; }
+                    }
+                }
+            }
+            DBG_T(4);
+            __syncthreads();
+            DBG_T(5);
+        }
+    }
+}
+// MB == 0: matrices in global memory (any L), generic loops; MB > 0: LDS-resident fast path for L <= 16 MB
+template <int MB>
+__device__ __forceinline__ void wg_jacobi_any(double* A, int64_t lda, double* V, int64_t ldv, int L, double* s_c, double* s_s,
+                                              int* s_p, int* s_q, double* s_red) {
+    if constexpr (MB == 0) wg_jacobi(A, lda, V, ldv, L, s_c, s_s, s_p, s_q, s_red);
+    else wg_jacobi_fast<MB>(A, V, L, s_c, s_s, s_p, s_q, s_red);
+}
 // sort eigenpairs descending: Vout[:, rank] = V[:, j], w[rank] = A[j][j]
 __device__ void wg_sort_eig(const double* A, int64_t lda, const double* V, int64_t ldv, int L, double* Vout, int64_t ldo,
                             double* w, int* s_rank) {
@@ -871,33 +1148,52 @@ __device__ void wg_sort_eig(const double* A, int64_t lda, const double* V, int64
     __syncthreads();
 }
 
-constexpr int EIG_THREADS = 1024;
 constexpr int EIG_MAXL = 1024;
-struct EigShared {
-    double c[EIG_MAXL / 2], s[EIG_MAXL / 2];
-    int p[EIG_MAXL / 2], q[EIG_MAXL / 2];
-    double red[2 * EIG_THREADS];
-    int rank[EIG_MAXL];
-};
-__global__ __launch_bounds__(EIG_THREADS) void k_eigh(double* A, int L, int64_t lda, double* Vtmp, double* V, int64_t ldv, double* w) {
-    __shared__ EigShared sh;
-    wg_jacobi(A, lda, Vtmp, L, L, sh.c, sh.s, sh.p, sh.q, sh.red);
-    wg_sort_eig(A, lda, Vtmp, L, L, V, ldv, w, sh.rank);
+struct JacWs { double* c; double* s; double* red; int* p; int* q; int* rank; };
+__host__ __device__ inline size_t jac_ws_doubles(int L, int nthreads) {
+    const int half = ((L + 1) & ~1) / 2;
+    return (size_t)2 * half + 2 * (size_t)nthreads + (2 * (size_t)half + L + 1) / 2 + 1;
+}
+__device__ __forceinline__ JacWs jac_carve(double* base, int L, int nthreads) {
+    const int half = ((L + 1) & ~1) / 2;
+    JacWs w;
+    w.c = base; w.s = w.c + half; w.red = w.s + half;
+    w.p = reinterpret_cast<int*>(w.red + 2 * nthreads); w.q = w.p + half; w.rank = w.q + half;
+    return w;
+}
+// MB > 0: A and the eigenvector accumulator live in LDS (2 L^2 doubles; L <= 16 MB, L <= 88); MB == 0: global memory
+template <int MB>
+__global__ __launch_bounds__(MB > 0 ? 768 : 1024) void k_eigh(double* A, int L, int64_t lda, double* Vtmp, double* V, int64_t ldv, double* w) {
+    extern __shared__ __attribute__((aligned(16))) double sm_eig[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    JacWs ws = jac_carve(sm_eig, L, nt);
+    double* Aw = A; double* Vw = Vtmp; int64_t la = lda;
+    if constexpr (MB > 0) {
+        la = L | 1;
+        Aw = sm_eig + jac_ws_doubles(L, nt); Vw = Aw + (size_t)L * la;
+        for (int e = tid; e < L * L; e += nt) Aw[(e / L) * la + (e % L)] = A[(int64_t)(e / L) * lda + (e % L)];
+        __syncthreads();
+    }
+    wg_jacobi_any<MB>(Aw, la, Vw, la, L, ws.c, ws.s, ws.p, ws.q, ws.red);
+    wg_sort_eig(Aw, la, Vw, la, L, V, ldv, w, ws.rank);
 }
 
-// Wout = symmetric_decorrelation(Win) (ica.rs:363-381); scratch: S, Z, Zs, M each nc*nc doubles + w nc
+// Wout = symmetric_decorrelation(Win) (ica.rs:363-381).  S (= W W^T, then destroyed) and the eigenvector accumulator
+// Zt are the Jacobi-hot matrices (LDS when nc <= 64); Z, Mm, w are scratch in global memory.
+template <int MB>
 __device__ void wg_symdecorr(const double* Win, double* Wout, int nc, int mode, double* S, double* Zt, double* Z, double* Mm,
-                             double* w, EigShared& sh) {
+                             double* w, JacWs& ws) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int ls = MB > 0 ? (nc | 1) : nc;  // the LDS-resident matrices use an odd leading dimension
     for (int e = tid; e < nc * nc; e += nt) {  // S = W W^T (ica.rs:369)
         const int i = e / nc, j = e % nc;
-        double s = 0;
-        for (int k = 0; k < nc; ++k) s += Win[i * nc + k] * Win[j * nc + k];
-        S[e] = s;
+        double acc = 0;
+        for (int k = 0; k < nc; ++k) acc += Win[i * nc + k] * Win[j * nc + k];
+        S[i * ls + j] = acc;
     }
     __syncthreads();
-    wg_jacobi(S, nc, Zt, nc, nc, sh.c, sh.s, sh.p, sh.q, sh.red);
-    wg_sort_eig(S, nc, Zt, nc, nc, Z, nc, w, sh.rank);
+    wg_jacobi_any<MB>(S, ls, Zt, ls, nc, ws.c, ws.s, ws.p, ws.q, ws.red);
+    wg_sort_eig(S, ls, Zt, ls, nc, Z, nc, w, ws.rank);
     // textbook (W W^T)^(-1/2) = Z D Z^T.  literal crate arithmetic: Z_asc^T D Z_asc with LAPACK's
     // ascending order; for nc == 2 LAPACK's dlaev2 path returns a symmetric Z for PSD input, where both agree.
     const bool literal = mode == 1 && nc > 2;
@@ -919,36 +1215,45 @@ __device__ void wg_symdecorr(const double* Win, double* Wout, int nc, int mode, 
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(EIG_THREADS) void k_symdecorr(const double* Win, double* Wout, int nc, int mode, double* scratch) {
-    __shared__ EigShared sh;
+constexpr int ICA_TAIL_THREADS = 512;
+template <int MB>
+__global__ __launch_bounds__(ICA_TAIL_THREADS) void k_symdecorr(const double* Win, double* Wout, int nc, int mode, double* scratch) {
+    constexpr bool use_lds = MB > 0;
+    extern __shared__ __attribute__((aligned(16))) double sm_sd[];
+    JacWs ws = jac_carve(sm_sd, nc, blockDim.x);
     double* S = scratch; double* Zt = S + nc * nc; double* Z = Zt + nc * nc; double* Mm = Z + nc * nc; double* w = Mm + nc * nc;
-    wg_symdecorr(Win, Wout, nc, mode, S, Zt, Z, Mm, w, sh);
+    if (use_lds) { S = sm_sd + jac_ws_doubles(nc, blockDim.x); Zt = S + nc * (nc | 1); }
+    wg_symdecorr<MB>(Win, Wout, nc, mode, S, Zt, Z, Mm, w, ws);
 }
-__global__ __launch_bounds__(EIG_THREADS) void k_ica_tail(int nc, double n_total, double* W, const double* GX_gp, int mode,
-                                                          double tol, int* state, int iter, double* scratch) {
+template <int MB>
+__global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_total, double* W, const double* GX_gp, int mode,
+                                                               double tol, int* state, int iter, double* scratch) {
     if (state[0]) return;
-    __shared__ EigShared sh;
+    constexpr bool use_lds = MB > 0;
+    extern __shared__ __attribute__((aligned(16))) double sm_tail[];
     const int tid = threadIdx.x, nt = blockDim.x;
+    JacWs ws = jac_carve(sm_tail, nc, nt);
     double* S = scratch; double* Zt = S + nc * nc; double* Z = Zt + nc * nc; double* Mm = Z + nc * nc; double* w = Mm + nc * nc;
     double* D = w + nc; double* W1 = D + nc * nc;
+    if (use_lds) { S = sm_tail + jac_ws_doubles(nc, nt); Zt = S + nc * (nc | 1); }
     const double* GX = GX_gp; const double* gp = GX_gp + nc * nc;
     const double pinv = 1.0 / n_total;
     for (int e = tid; e < nc * nc; e += nt) D[e] = GX[e] * pinv - gp[e / nc] * pinv * W[e];  // ica.rs:334-342
     __syncthreads();
-    wg_symdecorr(D, W1, nc, mode, S, Zt, Z, Mm, w, sh);  // ica.rs:343
+    wg_symdecorr<MB>(D, W1, nc, mode, S, Zt, Z, Mm, w, ws);  // ica.rs:343
     double lim = 0;  // ica.rs:344-354
     for (int i = tid; i < nc; i += nt) {
         double dot = 0;
         for (int j = 0; j < nc; ++j) dot += W1[i * nc + j] * (mode == 1 ? W[j * nc + i] : W[i * nc + j]);
         lim = fmax(lim, fabs(fabs(dot) - 1.0));
     }
-    sh.red[tid] = lim;
+    ws.red[tid] = lim;
     __syncthreads();
     for (int st = nt / 2; st > 0; st >>= 1) {
-        if (tid < st) sh.red[tid] = fmax(sh.red[tid], sh.red[tid + st]);
+        if (tid < st) ws.red[tid] = fmax(ws.red[tid], ws.red[tid + st]);
         __syncthreads();
     }
-    const double tl = sh.red[0];
+    const double tl = ws.red[0];
     __syncthreads();
     for (int e = tid; e < nc * nc; e += nt) W[e] = W1[e];
     if (tid == 0 && (tl < tol)) { state[0] = 1; state[1] = iter + 1; }  // ica.rs:355-357
@@ -1010,7 +1315,7 @@ void op_colsum(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx
     DISPATCH_T(dt, hipLaunchKernelGGL(k_colsum_part<T>, dim3((unsigned)nparts, cdiv(dd, 256)), dim3(256), 0, d->stream,
                                       (const T*)X, n, dd, ldx, part));
     launch_check();
-    hipLaunchKernelGGL(k_sum_parts, dim3(cdiv(dd, 256)), dim3(256), 0, d->stream, part, nparts, dd, out);
+    hipLaunchKernelGGL(k_sum_parts2<double>, dim3(cdiv(dd, 32)), dim3(256), 0, d->stream, part, nparts, dd, out, dd, dd, false);
     launch_check();
     dev_free(d, part);
 }
@@ -1043,7 +1348,7 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
         launch_check();
         ts.stop();
         if (sumsq) {
-            hipLaunchKernelGGL(k_add_scalar_parts, dim3(1), dim3(64), 0, d->stream, ssp, n, sumsq);
+            hipLaunchKernelGGL(k_add_scalar_parts, dim3(1), dim3(256), 0, d->stream, ssp, n, sumsq);
             launch_check();
             dev_free(d, ssp);
         }
@@ -1076,7 +1381,7 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
     }
     ts.stop();
     if (sumsq) {
-        hipLaunchKernelGGL(k_add_scalar_parts, dim3(1), dim3(64), 0, d->stream, ssp, (int64_t)blocks * 4, sumsq);
+        hipLaunchKernelGGL(k_add_scalar_parts, dim3(1), dim3(256), 0, d->stream, ssp, (int64_t)blocks * 4, sumsq);
         launch_check();
         dev_free(d, ssp);
     }
@@ -1110,7 +1415,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
                                           d->stream, (const T*)A, lda, M, (const T*)muA, (const T*)B, ldb, N, (const T*)muB, n, part));
         launch_check();
         ts.stop();
-        hipLaunchKernelGGL(k_reduce_partials_f64, dim3(cdiv(M * N, 256)), dim3(256), 0, d->stream, part, nparts, M, N, C, ldc);
+        hipLaunchKernelGGL(k_sum_parts2<double>, dim3(cdiv(M * N, 32)), dim3(256), 0, d->stream, part, nparts, M * N, C, N, ldc, false);
         launch_check();
         dev_free(d, part);
         return;
@@ -1118,6 +1423,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     // split the rows so that about 1024 waves (one per SIMD) exist; chunk a multiple of 16 rows
     const int mslices = cdiv(M, 64);
     int64_t nsplit = std::max<int64_t>(1, 1024 / mslices);
+    nsplit = std::min<int64_t>(nsplit, 256);  // bounds the partial-slab traffic of narrow (Gram) products
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 64));
     const int64_t chunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
     nsplit = (n + chunk - 1) / chunk;
@@ -1139,7 +1445,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         nt0 += w;
     }
     ts.stop();
-    hipLaunchKernelGGL(k_reduce_partials_f32, dim3(cdiv(M * N, 256)), dim3(256), 0, d->stream, part, nsplit, M, N, C, ldc);
+    hipLaunchKernelGGL(k_sum_parts2<float>, dim3(cdiv(M * N, 32)), dim3(256), 0, d->stream, part, nsplit, M * N, C, N, ldc, false);
     launch_check();
     dev_free(d, part);
 }
@@ -1162,7 +1468,7 @@ void op_col_absmax(Dev* d, int dt, const void* U, int64_t n, int64_t L, int64_t 
     DISPATCH_T(dt, hipLaunchKernelGGL(k_absmax_part<T>, dim3((unsigned)nparts, cdiv(L, 64)), dim3(64), 0, d->stream, (const T*)U,
                                       n, L, ldu, pm, pi, ps));
     launch_check();
-    hipLaunchKernelGGL(k_absmax_final, dim3(cdiv(L, 64)), dim3(64), 0, d->stream, pm, pi, ps, nparts, L, row_offset, absmax, idx, sign);
+    hipLaunchKernelGGL(k_absmax_final, dim3((unsigned)L), dim3(64), 0, d->stream, pm, pi, ps, nparts, L, row_offset, absmax, idx, sign);
     launch_check();
     dev_free(d, part);
 }
@@ -1224,15 +1530,41 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
     dev_free(d, Wpk);
 }
 
+static void set_max_lds(const void* fn) { HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+
+#define MB_DISPATCH(mb, CALL)            \
+    switch (mb) {                        \
+        case 0: { constexpr int MBv = 0; CALL; } break; \
+        case 1: { constexpr int MBv = 1; CALL; } break; \
+        case 2: { constexpr int MBv = 2; CALL; } break; \
+        case 3: { constexpr int MBv = 3; CALL; } break; \
+        case 4: { constexpr int MBv = 4; CALL; } break; \
+        case 5: { constexpr int MBv = 5; CALL; } break; \
+        default: { constexpr int MBv = 6; CALL; } break; \
+    }
+
 void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol, int* state, int iter) {
     double* scratch = (double*)dev_alloc(d, sizeof(double) * (6 * nc * nc + nc));
-    hipLaunchKernelGGL(k_ica_tail, dim3(1), dim3(EIG_THREADS), 0, d->stream, (int)nc, n_total, W, GX_gp, mode, tol, state, iter, scratch);
+    const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
+    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 2 * nc * (nc | 1) : 0));
+    MB_DISPATCH(mb, {
+        static bool once = false;
+        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_ica_tail<MBv>)); once = true; }
+        hipLaunchKernelGGL(k_ica_tail<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, (int)nc, n_total, W, GX_gp, mode, tol,
+                           state, iter, scratch);
+    });
     launch_check();
     dev_free(d, scratch);
 }
 void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode) {
     double* scratch = (double*)dev_alloc(d, sizeof(double) * (4 * nc * nc + nc));
-    hipLaunchKernelGGL(k_symdecorr, dim3(1), dim3(EIG_THREADS), 0, d->stream, Win, Wout, (int)nc, mode, scratch);
+    const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
+    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 2 * nc * (nc | 1) : 0));
+    MB_DISPATCH(mb, {
+        static bool once = false;
+        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_symdecorr<MBv>)); once = true; }
+        hipLaunchKernelGGL(k_symdecorr<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, Win, Wout, (int)nc, mode, scratch);
+    });
     launch_check();
     dev_free(d, scratch);
 }
@@ -1246,17 +1578,31 @@ void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double 
 }
 void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol) {
     if (L == 0) return;
-    double* R = (double*)dev_alloc(d, sizeof(double) * L * L + sizeof(int) * L);
-    int* dead = reinterpret_cast<int*>(R + L * L);
-    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, d->stream, G, (int)L, ldg, R, T, ldt, rel_tol, dead);
+    if (L > 144) throw std::runtime_error("chol_inv: matrix too large for the one-workgroup LDS kernel (L <= 144)");
+    const size_t base = sizeof(double) * (L * (L + 1) / 2 + L + (L + 1) / 2);
+    const size_t with_t = base + sizeof(double) * L * L;
+    const int t_in_lds = with_t <= 150 * 1024 ? 1 : 0;
+    const size_t lds = t_in_lds ? with_t : base;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_in_lds);
     launch_check();
-    dev_free(d, R);
 }
 void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w) {
     if (L == 0) return;
     if (L > EIG_MAXL) throw std::runtime_error("eigh: matrix too large for the one-workgroup Jacobi solver");
+    const int mb = L <= 88 ? (int)((L + 15) / 16) : 0;
+    const int threads = mb ? (int)std::min<int64_t>(1024, std::max<int64_t>(64, (8 * L + 63) / 64 * 64)) : 1024;
     double* Vtmp = (double*)dev_alloc(d, sizeof(double) * L * L);
-    hipLaunchKernelGGL(k_eigh, dim3(1), dim3(EIG_THREADS), 0, d->stream, A, (int)L, lda, Vtmp, V, ldv, w);
+    const size_t lds = sizeof(double) * (jac_ws_doubles((int)L, threads) + (mb ? 2 * L * (L | 1) : 0));
+    MB_DISPATCH(mb, {
+        static bool once = false;
+        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_eigh<MBv>)); once = true; }
+        hipLaunchKernelGGL(k_eigh<MBv>, dim3(1), dim3(threads), lds, d->stream, A, (int)L, lda, Vtmp, V, ldv, w);
+    });
     launch_check();
     dev_free(d, Vtmp);
 }
