@@ -41,7 +41,9 @@ def main():
     ap.add_argument("--n-iter", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-northstar", action="store_true")
-    ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes per launch from a separate rocprofv3 --pmc pass")
+    ap.add_argument("--pmc-traffic", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass "
+                         "(default: the committed measurement in profiles/r01_pmc_traffic.json for this workload)")
     args = ap.parse_args()
 
     import torch
@@ -108,9 +110,17 @@ def main():
         dom = max(kinds, key=lambda kname: kinds[kname][0])
         avg_ms = per[dom]
         achieved = pass_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = args.pmc_traffic
+        if traffic is None:  # PMC passes cannot run inside the timed bench: use the committed rocprofv3 measurement
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                    pmc = json.load(f)
+                traffic = pmc[f"{n}x{d} l={l}"][dom.split(" ")[0]]["hbm_bytes_corrected"]
+            except Exception:
+                traffic = None
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TF,
                     "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4),
-                    "traffic": args.pmc_traffic, "avg_launch_ms": round(avg_ms, 5),
+                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
                     "flops_per_launch": pass_flops, "bytes_per_launch": pass_bytes,
                     "hbm_GBps_algorithmic": round(pass_bytes / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
                     "other_kernel": {kname: {"avg_launch_ms": round(v, 5),

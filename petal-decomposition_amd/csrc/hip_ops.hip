@@ -370,6 +370,16 @@ __global__ void k_pack_p(const double* __restrict__ P, int64_t K, int64_t N, int
     reinterpret_cast<f32x4*>(Ppk)[e] = v;
 }
 
+// X is read exactly once per pass.  Non-temporal loads were tried here (to keep the re-read small operand in
+// L2) and measured SLOWER on gfx950 (K1 at 1e6 x 512: 77 vs 88 TFLOP/s, FETCH_SIZE up 40 %), so plain loads stay.
+__device__ __forceinline__ f32x4 ld_stream(const float* p) {
+#ifdef PETAL_NT_LOADS
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+    return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
+
 template <int RT, int NT, bool CENTER, bool SUMSQ>
 __global__ __launch_bounds__(256, 2) void k_xp_mfma(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
                                                     const float* __restrict__ mu, const float* __restrict__ Ppk, int NTtot,
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void k_xp_mfma(const float* __restrict__ X,
     // one 16-deep K chunk: RT + NT (+1) independent 16-B loads per lane, then 4 RT NT MFMAs
     auto load_chunk = [&](int c, f32x4(&a)[RT], f32x4(&b)[NT], f32x4& m) {
 #pragma unroll
-        for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const f32x4*>(xrow[t] + 16 * c);
+        for (int t = 0; t < RT; ++t) a[t] = ld_stream(xrow[t] + 16 * c);
 #pragma unroll
         for (int u = 0; u < NT; ++u) b[u] = pb[((int64_t)c * NTtot + u) * 64];
         if (CENTER) m = *reinterpret_cast<const f32x4*>(mup + 16 * c);
@@ -513,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void k_atb_mfma(const float* __restrict__ A
 #pragma unroll
         for (int s = 0; s < UN; ++s) {
             const int64_t r = r0 + 4 * s + q;
-            av[s] = *reinterpret_cast<const f32x4*>(ap + r * lda);
+            av[s] = ld_stream(ap + r * lda);
 #pragma unroll
             for (int g = 0; g < G4; ++g) b4[s][g] = *reinterpret_cast<const f32x4*>(bp4[g] + r * ldb);
 #pragma unroll
