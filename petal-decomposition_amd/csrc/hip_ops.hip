@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -403,7 +404,11 @@ __global__ __launch_bounds__(256, 2) void k_xp_mfma(const float* __restrict__ X,
     for (int t = 0; t < RT; ++t) {
         const int64_t r = row0 + 16 * t + i;
         rvalid[t] = r < n;
+#ifdef PETAL_EXP_AFIXED
+        xrow[t] = X + (int64_t)(16 * t + i) * ldx + 4 * q;  // experiment: every wave re-reads the same 64 rows (cache resident)
+#else
         xrow[t] = X + (rvalid[t] ? r : (n - 1)) * ldx + 4 * q;
+#endif
     }
     const f32x4* pb = reinterpret_cast<const f32x4*>(Ppk) + (int64_t)nt0 * 64 + lane;
     const float* mup = mu + 4 * q;
@@ -411,6 +416,113 @@ __global__ __launch_bounds__(256, 2) void k_xp_mfma(const float* __restrict__ X,
     const int nchunk = K >> 4;
 
     // one 16-deep K chunk: RT + NT (+1) independent 16-B loads per lane, then 4 RT NT MFMAs
+    auto load_chunk = [&](int c, f32x4(&a)[RT], f32x4(&b)[NT], f32x4& m) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) a[t] = ld_stream(xrow[t] + 16 * c);
+#pragma unroll
+#ifdef PETAL_EXP_BFIXED
+        for (int u = 0; u < NT; ++u) b[u] = pb[((int64_t)(c & 1) * NTtot + u) * 64];  // experiment: P chunk always cache resident
+#else
+        for (int u = 0; u < NT; ++u) b[u] = pb[((int64_t)c * NTtot + u) * 64];
+#endif
+        if (CENTER) m = *reinterpret_cast<const f32x4*>(mup + 16 * c);
+    };
+    auto compute = [&](f32x4(&a)[RT], f32x4(&b)[NT], const f32x4& m) {
+        if (CENTER) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) a[t] -= m;
+        }
+        if (SUMSQ) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+                if (rvalid[t]) ssq += a[t][0] * a[t][0] + a[t][1] * a[t][1] + a[t][2] * a[t][2] + a[t][3] * a[t][3];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u][s], a[t][s], acc[t][u], 0, 0, 0);  // Z^T tile
+    };
+    // software pipeline, THREE register stages: the loads of chunks c+1 and c+2 are in flight while chunk c feeds the
+    // MFMAs (two chunks of MFMA time, ~2 x 2560 cycles per wave, cover the loaded HBM latency at 2 waves / SIMD).
+    // sched_barrier(0) pins the issue order (hipcc otherwise sinks the prefetch below the MFMAs and drains vmcnt(0)).
+    f32x4 a0[RT], b0[NT], a1[RT], b1[NT], a2[RT], b2[NT];
+    f32x4 m0 = f32x4{0.f, 0.f, 0.f, 0.f}, m1 = m0, m2 = m0;
+    const int last = nchunk - 1;
+    load_chunk(0, a0, b0, m0);
+    load_chunk(last < 1 ? last : 1, a1, b1, m1);
+    int c = 0;
+    for (; c + 3 <= nchunk; c += 3) {
+        load_chunk(c + 2 < last ? c + 2 : last, a2, b2, m2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a0, b0, m0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(c + 3 < last ? c + 3 : last, a0, b0, m0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a1, b1, m1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(c + 4 < last ? c + 4 : last, a1, b1, m1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a2, b2, m2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c < nchunk) compute(a0, b0, m0);
+    if (c + 1 < nchunk) compute(a1, b1, m1);
+    // epilogue.  The MFMA operands are swapped (P fragment as A, X fragment as B), so the accumulator tile is Z^T:
+    // reg r of lane (i, q) is Z[row0 + 16 t + i][16 u + 4 q + r] -- one 16-B store per lane and tile instead of four
+    // 4-B stores (the store tail is issue-bound: -10 % kernel time at 1e6 x 512).
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int col = 16 * (nt0 + u) + 4 * q;
+        if (col >= N) continue;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int64_t row = row0 + 16 * t + i;
+#ifdef PETAL_EXP_NOSTORE
+            if (row < n && acc[t][u][0] == 12345.678f)
+#else
+            if (row < n)
+#endif
+                *reinterpret_cast<f32x4*>(Z + row * ldz + col) = acc[t][u] + bv;
+        }
+    }
+    if (SUMSQ) {
+        double sred = (double)ssq;
+        for (int off = 32; off > 0; off >>= 1) sred += __shfl_down(sred, off, 64);
+        if (lane == 0) ss_part[(int64_t)blockIdx.x * 4 + wave] = sred;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1, "fat tile" form: ONE wave per SIMD with the whole register file.  Every wave owns a contiguous, balanced range
+// of 16-row tiles (6 or 7 of them at 100000 rows over 1024 SIMDs) and walks it as register tiles of 8 / 4 / 2 / 1
+// row-tiles x NT column tiles; each register tile is one pass over K with a three-stage register pipeline.  Against
+// the 64-row / two-waves-per-SIMD form above this (a) balances the SIMDs to within one 16-row tile instead of one
+// 64-row tile, (b) halves the re-reads of the packed P per row, (c) leaves nothing to arbitrate on the MFMA pipe.
+template <int RT, int NT, bool CENTER, bool SUMSQ, int STAGES = 3>
+__device__ __forceinline__ void xp_tile(const float* __restrict__ X, int64_t n, int K, int64_t ldx, const float* __restrict__ mu,
+                                        const f32x4* __restrict__ pb, int NTtot, int nt0, int N, const float* __restrict__ bias,
+                                        float* __restrict__ Z, int64_t ldz, int64_t row0, int lane, float& ssq) {
+    const int i = lane & 15, q = lane >> 4;
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xrow[RT];
+    bool rvalid[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int64_t r = row0 + 16 * t + i;
+        rvalid[t] = r < n;
+        xrow[t] = X + (rvalid[t] ? r : (n - 1)) * ldx + 4 * q;
+    }
+    const float* mup = mu + 4 * q;
+    const int nchunk = K >> 4;
     auto load_chunk = [&](int c, f32x4(&a)[RT], f32x4(&b)[NT], f32x4& m) {
 #pragma unroll
         for (int t = 0; t < RT; ++t) a[t] = ld_stream(xrow[t] + 16 * c);
@@ -434,43 +546,135 @@ __global__ __launch_bounds__(256, 2) void k_xp_mfma(const float* __restrict__ X,
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int u = 0; u < NT; ++u)
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b[u][s], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u][s], a[t][s], acc[t][u], 0, 0, 0);  // Z^T tile
     };
-    // software pipeline, two register stages: the loads of chunk c+1 are in flight while chunk c feeds the MFMAs.
-    // sched_barrier(0) pins the issue order (hipcc otherwise sinks the prefetch below the MFMAs and drains vmcnt(0)).
-    f32x4 a0[RT], b0[NT], a1[RT], b1[NT];
-    f32x4 m0 = f32x4{0.f, 0.f, 0.f, 0.f}, m1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    load_chunk(0, a0, b0, m0);
-    int c = 0;
-    for (; c + 2 <= nchunk; c += 2) {
-        load_chunk(c + 1, a1, b1, m1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a0, b0, m0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_chunk(c + 2 < nchunk ? c + 2 : nchunk - 1, a0, b0, m0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a1, b1, m1);
-        __builtin_amdgcn_sched_barrier(0);
+    const int last = nchunk - 1;
+    if constexpr (STAGES == 3) {
+        f32x4 a0[RT], b0[NT], a1[RT], b1[NT], a2[RT], b2[NT];
+        f32x4 m0 = f32x4{0.f, 0.f, 0.f, 0.f}, m1 = m0, m2 = m0;
+        load_chunk(0, a0, b0, m0);
+        load_chunk(last < 1 ? last : 1, a1, b1, m1);
+        int c = 0;
+        for (; c + 3 <= nchunk; c += 3) {
+            load_chunk(c + 2 < last ? c + 2 : last, a2, b2, m2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a0, b0, m0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(c + 3 < last ? c + 3 : last, a0, b0, m0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a1, b1, m1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(c + 4 < last ? c + 4 : last, a1, b1, m1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a2, b2, m2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c < nchunk) compute(a0, b0, m0);
+        if (c + 1 < nchunk) compute(a1, b1, m1);
+    } else {
+        f32x4 a0[RT], b0[NT], a1[RT], b1[NT];
+        f32x4 m0 = f32x4{0.f, 0.f, 0.f, 0.f}, m1 = m0;
+        load_chunk(0, a0, b0, m0);
+        int c = 0;
+        for (; c + 2 <= nchunk; c += 2) {
+            load_chunk(c + 1, a1, b1, m1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a0, b0, m0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(c + 2 < last ? c + 2 : last, a0, b0, m0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a1, b1, m1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c < nchunk) compute(a0, b0, m0);
     }
-    if (c < nchunk) compute(a0, b0, m0);
-    // epilogue: D[row = 4 q + r][col = i] per tile
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        const int col = 16 * (nt0 + u) + i;
+    for (int u = 0; u < NT; ++u) {  // Z^T accumulator tiles: one 16-B store per lane and tile (see k_xp_mfma)
+        const int col = 16 * (nt0 + u) + 4 * q;
         if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + 16 * t + 4 * q + r;
-                if (row < n) Z[row * ldz + col] = acc[t][u][r] + bv;
-            }
+        for (int t = 0; t < RT; ++t) {
+            const int64_t row = row0 + 16 * t + i;
+            if (row < n) *reinterpret_cast<f32x4*>(Z + row * ldz + col) = acc[t][u] + bv;
+        }
+    }
+}
+
+// K1, persistent form (default): ONE 512-thread workgroup per CU (two waves per SIMD: waves w and w + 4 share one).
+// All W = 8 * gridDim.x waves sweep the matrix together: in round j wave g owns the 64-row tile (j W + g), so the rows
+// in flight at any time form one contiguous window (TLB / DRAM-page friendly, like a plain grid launch).  The last,
+// partial round deals the remaining 16-row tiles out in balanced 0..4-tile pieces, the longer pieces to waves 0..3 of
+// each workgroup (four different SIMDs): every SIMD ends within one 16-row tile of the average (7 vs 6.1 tiles at
+// 100000 rows; the 64-row-per-wave grid form leaves it at 8).
+#ifndef PETAL_PERS_STAGES
+#define PETAL_PERS_STAGES 2
+#endif
+template <int NT, bool CENTER, bool SUMSQ>
+__global__ __launch_bounds__(512, 2) void k_xp_pers(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
+                                                    const float* __restrict__ mu, const float* __restrict__ Ppk, int NTtot,
+                                                    int nt0, int N, const float* __restrict__ bias, float* __restrict__ Z,
+                                                    int64_t ldz, double* __restrict__ ss_part, int64_t ntiles16) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4* pb = reinterpret_cast<const f32x4*>(Ppk) + (int64_t)nt0 * 64 + lane;
+    float ssq = 0.f;
+    const int64_t W = (int64_t)gridDim.x * 8, g = (int64_t)blockIdx.x * 8 + wave;
+    const int64_t nfull = ntiles16 / (4 * W);  // rounds in which every wave owns a full 64-row tile
+    int64_t t = 0;
+#define XP_TILE(R, S) xp_tile<R, NT, CENTER, SUMSQ, S>(X, n, K, ldx, mu, pb, NTtot, nt0, N, bias, Z, ldz, 16 * t, lane, ssq)
+#ifdef PETAL_EXP_STAGGER
+    {   // experiment: de-phase the workgroups (and the two waves of a SIMD) so the chip's load bursts do not coincide
+        const int dly = (int)(blockIdx.x & 15) * 5 + (wave >= 4 ? 40 : 0);
+        for (int k = 0; k < dly; ++k) __builtin_amdgcn_s_sleep(1);
+    }
+#endif
+    for (int64_t j = 0; j < nfull; ++j) {
+        t = (j * W + g) * 4;
+        XP_TILE(4, PETAL_PERS_STAGES);
+    }
+    {
+        const int64_t rem = ntiles16 - 4 * W * nfull;  // < 4 W tiles of 16 rows
+        const int64_t base = rem / W, extra = rem - base * W;
+        const int64_t rank = wave < 4 ? (int64_t)blockIdx.x * 4 + wave : W / 2 + (int64_t)blockIdx.x * 4 + (wave - 4);
+        const int64_t cnt = base + (rank < extra ? 1 : 0);
+        t = 4 * W * nfull + rank * base + (rank < extra ? rank : extra);
+        if (cnt == 4) XP_TILE(4, PETAL_PERS_STAGES);
+        else if (cnt == 3) XP_TILE(3, 2);
+        else if (cnt == 2) XP_TILE(2, 2);
+        else if (cnt == 1) XP_TILE(1, 2);
+    }
+#undef XP_TILE
+    if (SUMSQ) {
+        double sred = (double)ssq;
+        for (int off = 32; off > 0; off >>= 1) sred += __shfl_down(sred, off, 64);
+        if (lane == 0) ss_part[(int64_t)blockIdx.x * 8 + wave] = sred;
+    }
+}
+
+template <int NT, int RTMAX, bool CENTER, bool SUMSQ>
+__global__ __launch_bounds__(256, 1) void k_xp_fat(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
+                                                   const float* __restrict__ mu, const float* __restrict__ Ppk, int NTtot,
+                                                   int nt0, int N, const float* __restrict__ bias, float* __restrict__ Z,
+                                                   int64_t ldz, double* __restrict__ ss_part, int64_t ntiles16, int nwaves) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const f32x4* pb = reinterpret_cast<const f32x4*>(Ppk) + (int64_t)nt0 * 64 + lane;
+    float ssq = 0.f;
+    if (wid < nwaves) {
+        int64_t t = wid * ntiles16 / nwaves;
+        const int64_t t1 = (wid + 1) * ntiles16 / nwaves;
+#define XP_TILE(R) xp_tile<R, NT, CENTER, SUMSQ>(X, n, K, ldx, mu, pb, NTtot, nt0, N, bias, Z, ldz, 16 * t, lane, ssq)
+        if constexpr (RTMAX >= 8) { for (; t1 - t >= 8; t += 8) XP_TILE(8); }
+        for (; t1 - t >= 4; t += 4) XP_TILE(4);
+        for (; t1 - t >= 2; t += 2) XP_TILE(2);
+        for (; t1 - t >= 1; t += 1) XP_TILE(1);
+#undef XP_TILE
     }
     if (SUMSQ) {
         double sred = (double)ssq;
         for (int off = 32; off > 0; off >>= 1) sred += __shfl_down(sred, off, 64);
-        if (lane == 0) ss_part[(int64_t)blockIdx.x * 4 + wave] = sred;
+        if (lane == 0) ss_part[wid] = sred;
     }
 }
 
@@ -847,32 +1051,76 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
 #ifdef PETAL_DEBUG_COUNTERS
     long long _t0 = clock64();
 #endif
-    for (int j = 0; j < L; ++j) {
-        const double dj = Rw[pk(j, j, L)], gj = gd[j];
-        const bool ok = (gj > 0.0) && (dj > rel_tol * gj);
-        if (tid == 0) dead[j] = ok ? 0 : 1;
-        if (ok) {  // threads as a 16 x 32 grid over (r, c): no integer division in the update loop
-            const double inv = 1.0 / dj;
-            const int ty = tid >> 5, tx = tid & 31;
-            const double* uj = Rw + pk(j, j, L) - j;  // uj[c] = U[j][c]
-            for (int r = j + 1 + ty; r < L; r += 16) {
-                const double f = uj[r] * inv;
-                double* rr = Rw + pk(r, r, L) - r;     // rr[c] = Rw[r][c], c >= r
-                for (int c = r + tx; c < L; c += 32) rr[c] -= f * uj[c];
+    // ---- blocked (16) left-looking factorisation: 3 barriers per block row instead of one per column ----
+    {
+        const int nbk = (L + 15) / 16;
+        for (int J = 0; J < nbk; ++J) {
+            const int jb = 16 * J;
+            // (1) block row J -= (finished rows above)^T (finished rows above): threads = 16 rows x 32 column lanes
+            if (jb > 0) {
+                const int r = jb + (tid >> 5);
+                if (r < L) {
+                    for (int c = r + (tid & 31); c < L; c += 32) {
+                        double acc = 0;
+                        for (int k = 0; k < jb; ++k) acc += Rw[pk(k, r, L)] * Rw[pk(k, c, L)];
+                        Rw[pk(r, c, L)] -= acc;
+                    }
+                }
             }
+            __syncthreads();
+            // (2) diagonal block: one wave, column c of the block in the registers of lane c, pivots broadcast by readlane
+            if (tid < 64) {
+                const int c = jb + tid;
+                double a[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = (tid < 16 && i <= tid && c < L) ? Rw[pk(jb + i, c, L)] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    double sres = a[i];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) sres -= __shfl(a[k], i, 64) * a[k];
+                    const double dii = __shfl(sres, i, 64);
+                    const double gi = (jb + i < L) ? gd[jb + i] : 0.0;
+                    const bool ok = (gi > 0.0) && (dii > rel_tol * gi);
+                    const double rii = ok ? sqrt(dii) : 0.0;
+                    a[i] = (!ok || tid < i) ? 0.0 : (tid == i ? rii : sres / rii);
+                    if (tid == 0 && jb + i < L) dead[jb + i] = ok ? 0 : 1;
+                }
+                if (tid < 16 && c < L) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (i <= tid) Rw[pk(jb + i, c, L)] = a[i];
+                }
+            }
+            __syncthreads();
+            // (3) panel: R[jb.., c] = R_JJ^-T A[jb.., c] for every column right of the block (one thread per column)
+            {
+                const int c = jb + 16 + tid;
+                if (c < L) {
+                    double v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = Rw[pk(jb + i, c, L)];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        double sres = v[i];
+#pragma unroll
+                        for (int k = 0; k < i; ++k) sres -= Rw[pk(jb + k, jb + i, L)] * v[k];
+                        const double rii = Rw[pk(jb + i, jb + i, L)];
+                        v[i] = rii > 0.0 ? sres / rii : 0.0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) Rw[pk(jb + i, c, L)] = v[i];
+                }
+            }
+            __syncthreads();
+        }
+        // dependent columns: zero the column above the (already zero) diagonal
+        for (int e = tid; e < L * L; e += nt) {
+            const int r = e / L, c = e % L;
+            if (c > r && dead[c]) Rw[pk(r, c, L)] = 0.0;
         }
         __syncthreads();
     }
-    for (int r = tid; r < L; r += nt) gd[r] = dead[r] ? 0.0 : Rw[pk(r, r, L)];
-    __syncthreads();
-    for (int e = tid; e < L * L; e += nt) {
-        const int r = e / L, c = e % L;
-        if (c >= r) {
-            const double dr = gd[r];
-            Rw[pk(r, c, L)] = (dr > 0.0 && !dead[c]) ? Rw[pk(r, c, L)] / sqrt(dr) : 0.0;
-        }
-    }
-    __syncthreads();
     DBG_T(6);
     // ---- blocked inverse ----
     const int nb = (L + 15) / 16;
@@ -1349,7 +1597,7 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
                 int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq) {
     if (n == 0 || N == 0) return;
     const bool mfma = dt == F32 && K % 16 == 0 && K > 0 && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
-                      K < (1 << 24) && N < (1 << 24);
+                      K < (1 << 24) && N < (1 << 24) && N % 16 == 0 && ldz % 4 == 0 && aligned16(Z) && (!bias || aligned16(bias));
     if (!mfma) {
         double* ssp = sumsq ? (double*)dev_alloc(d, sizeof(double) * n) : nullptr;
         TagScope ts(d);
@@ -1371,22 +1619,128 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
         hipLaunchKernelGGL(k_pack_p, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk, NTtot);
         launch_check();
     }
-    // column panels of at most 5 tiles (RT = 4: 64 rows per wave) -- 80 accumulator registers per lane
-    const int blocks = cdiv(n, 256);
+    static const bool use_fat = [] { const char* e = getenv("PETAL_K1_FAT"); return e && e[0] == '1'; }();
+    static const bool use_classic = [] { const char* e = getenv("PETAL_K1_CLASSIC"); return e && e[0] == '1'; }();
+    static const bool force_pers = [] { const char* e = getenv("PETAL_K1_PERS"); return e && e[0] == '1'; }();
+    static int num_cu = 0;
+    if (!num_cu) { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, d->device)); num_cu = prop.multiProcessorCount; }
+    // Form selection (measured, MI355X): with fewer than two 64-row tiles per wave slot the grid form leaves SIMDs
+    // a whole 64-row tile apart (100000 x 512: 74 TFLOP/s) and the balanced persistent form wins (84); with many tiles
+    // per slot the hardware dispatcher balances the grid form dynamically and it is the faster one (1e6 x 512: 95 vs 76).
+    const bool small = (n + 63) / 64 < (int64_t)num_cu * 8 * 2;
+    if (!use_fat && !use_classic && (small || force_pers)) {
+        // persistent form: one 512-thread workgroup per CU, balanced ranges of 16-row tiles, column panels of <= 5 tiles
+        const int64_t ntiles16 = (n + 15) / 16;
+        const int blocks = (int)std::min<int64_t>(num_cu, (ntiles16 + 7) / 8);
+        double* ssp = sumsq ? (double*)dev_alloc(d, sizeof(double) * blocks * 8) : nullptr;
+        TagScope ts(d);
+        for (int nt0 = 0; nt0 < NTtot;) {
+            const int rem = NTtot - nt0;
+            const int w = rem >= 5 ? 5 : rem;
+            double* sp = nt0 == 0 ? ssp : nullptr;
+            const float* Xf = (const float*)X; const float* muf = (const float*)mu; const float* bf = (const float*)bias; float* Zf = (float*)Z;
+            const bool center = muf != nullptr, ss = sp != nullptr;
+#define XPP_ARGS Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, ntiles16
+#define XPP_LAUNCH(NTv)                                                                                                      \
+            do {                                                                                                             \
+                if (center && ss) hipLaunchKernelGGL((k_xp_pers<NTv, true, true>), dim3(blocks), dim3(512), 0, d->stream, XPP_ARGS);   \
+                else if (center) hipLaunchKernelGGL((k_xp_pers<NTv, true, false>), dim3(blocks), dim3(512), 0, d->stream, XPP_ARGS);   \
+                else if (ss) hipLaunchKernelGGL((k_xp_pers<NTv, false, true>), dim3(blocks), dim3(512), 0, d->stream, XPP_ARGS);       \
+                else hipLaunchKernelGGL((k_xp_pers<NTv, false, false>), dim3(blocks), dim3(512), 0, d->stream, XPP_ARGS);              \
+            } while (0)
+            switch (w) {
+                case 5: XPP_LAUNCH(5); break;
+                case 4: XPP_LAUNCH(4); break;
+                case 3: XPP_LAUNCH(3); break;
+                case 2: XPP_LAUNCH(2); break;
+                default: XPP_LAUNCH(1); break;
+            }
+#undef XPP_LAUNCH
+#undef XPP_ARGS
+            launch_check();
+            nt0 += w;
+        }
+        ts.stop();
+        if (sumsq) {
+            hipLaunchKernelGGL(k_add_scalar_parts, dim3(1), dim3(256), 0, d->stream, ssp, (int64_t)blocks * 8, sumsq);
+            launch_check();
+            dev_free(d, ssp);
+        }
+        dev_free(d, Ppk);
+        return;
+    }
+    if (!use_fat) {
+        // classic form: 64-row wave tiles, two waves per SIMD, column panels of <= 5 tiles
+        static const int rt_env = [] { const char* e = getenv("PETAL_K1_RT"); return e ? atoi(e) : 4; }();
+        if (rt_env == 2 && NTtot == 5) {  // experiment: 32-row wave tiles
+            const int blocks2 = cdiv(n, 128);
+            TagScope ts2(d);
+            launch_xp<2, 5>(d, (const float*)X, n, (int)K, ldx, (const float*)mu, Ppk, NTtot, 0, (int)N, (const float*)bias, (float*)Z, ldz, nullptr, blocks2);
+            ts2.stop();
+            dev_free(d, Ppk);
+            return;
+        }
+        const int blocks = cdiv(n, 256);
+        double* ssp = sumsq ? (double*)dev_alloc(d, sizeof(double) * blocks * 4) : nullptr;
+        TagScope ts(d);
+        for (int nt0 = 0; nt0 < NTtot;) {
+            const int rem = NTtot - nt0;
+            const int w = rem >= 5 ? 5 : rem;
+            double* sp = nt0 == 0 ? ssp : nullptr;
+            const float* Xf = (const float*)X; const float* muf = (const float*)mu; const float* bf = (const float*)bias; float* Zf = (float*)Z;
+            switch (w) {
+                case 5: launch_xp<4, 5>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+                case 4: launch_xp<4, 4>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+                case 3: launch_xp<4, 3>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+                case 2: launch_xp<4, 2>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+                default: launch_xp<4, 1>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+            }
+            nt0 += w;
+        }
+        ts.stop();
+        if (sumsq) {
+            hipLaunchKernelGGL(k_add_scalar_parts, dim3(1), dim3(256), 0, d->stream, ssp, (int64_t)blocks * 4, sumsq);
+            launch_check();
+            dev_free(d, ssp);
+        }
+        dev_free(d, Ppk);
+        return;
+    }
+    // fat-tile form (PETAL_K1_FAT=1; measured slower so far): 1024 waves (one per SIMD), balanced ranges of 16-row tiles
+    const int64_t ntiles16 = (n + 15) / 16;
+    const int nwaves = (int)std::min<int64_t>(1024, ntiles16);
+    const int blocks = cdiv(nwaves, 4);
     double* ssp = sumsq ? (double*)dev_alloc(d, sizeof(double) * blocks * 4) : nullptr;
     TagScope ts(d);
     for (int nt0 = 0; nt0 < NTtot;) {
         const int rem = NTtot - nt0;
-        const int w = rem >= 5 ? 5 : rem;
+        const int w = rem >= 9 ? 9 : rem;
         double* sp = nt0 == 0 ? ssp : nullptr;
         const float* Xf = (const float*)X; const float* muf = (const float*)mu; const float* bf = (const float*)bias; float* Zf = (float*)Z;
+        const bool center = muf != nullptr, ss = sp != nullptr;
+#define XPF_ARGS Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, ntiles16, nwaves
+#define XPF_LAUNCH(NTv, RTv)                                                                                              \
+        do { /* the (rare, once per fit) sum-of-squares variants use half the register tile to stay out of scratch */   \
+            constexpr int RTs = RTv / 2;                                                                                  \
+            if (center && ss) hipLaunchKernelGGL((k_xp_fat<NTv, RTs, true, true>), dim3(blocks), dim3(256), 0, d->stream, XPF_ARGS);   \
+            else if (center) hipLaunchKernelGGL((k_xp_fat<NTv, RTv, true, false>), dim3(blocks), dim3(256), 0, d->stream, XPF_ARGS); \
+            else if (ss) hipLaunchKernelGGL((k_xp_fat<NTv, RTs, false, true>), dim3(blocks), dim3(256), 0, d->stream, XPF_ARGS);     \
+            else hipLaunchKernelGGL((k_xp_fat<NTv, RTv, false, false>), dim3(blocks), dim3(256), 0, d->stream, XPF_ARGS);            \
+        } while (0)
         switch (w) {
-            case 5: launch_xp<4, 5>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
-            case 4: launch_xp<4, 4>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
-            case 3: launch_xp<4, 3>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
-            case 2: launch_xp<4, 2>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
-            default: launch_xp<4, 1>(d, Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, blocks); break;
+            case 9: XPF_LAUNCH(9, 4); break;
+            case 8: XPF_LAUNCH(8, 4); break;
+            case 7: XPF_LAUNCH(7, 4); break;
+            case 6: XPF_LAUNCH(6, 4); break;
+            case 5: XPF_LAUNCH(5, 8); break;
+            case 4: XPF_LAUNCH(4, 8); break;
+            case 3: XPF_LAUNCH(3, 8); break;
+            case 2: XPF_LAUNCH(2, 8); break;
+            default: XPF_LAUNCH(1, 8); break;
         }
+#undef XPF_LAUNCH
+#undef XPF_ARGS
+        launch_check();
         nt0 += w;
     }
     ts.stop();
