@@ -221,6 +221,9 @@ void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, do
 void op_dscal(Dev*, double* x, int64_t count, double alpha) {
     for (int64_t i = 0; i < count; ++i) x[i] *= alpha;
 }
+void op_daxpy(Dev*, int64_t count, double alpha, const double* x, double* y) {
+    for (int64_t i = 0; i < count; ++i) y[i] += alpha * x[i];
+}
 void op_dvec(Dev*, int mode, const double* x, double* y, int64_t count, double thr) {
     const double x0 = count ? x[0] : 0;
     for (int64_t i = 0; i < count; ++i) {

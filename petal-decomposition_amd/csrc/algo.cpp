@@ -6,6 +6,7 @@
 // Reference call stacks: SURVEY.md section 3; algorithm: SURVEY.md section 10.
 #include <algorithm>
 #include <chrono>
+#include <cstdint>
 
 #include "ctx.h"
 
@@ -107,6 +108,68 @@ void orthonormalize_small(petal_ctx& c, DBuf& Y, int64_t M, int64_t LP, double t
     op_chol_inv(c.dev, G.f64(), LP, LP, T.f64(), LP, tol);
     op_dgemm(c.dev, false, false, M, LP, LP, 1.0, Y.f64(), LP, T.f64(), LP, 0.0, Y2.f64(), LP);
     std::swap(Y, Y2);
+}
+
+// Top-nc eigenpairs of the symmetric PSD matrix C (dp x dp fp64, device) by block subspace iteration with
+// Rayleigh-Ritz, all in fp64 on the small-matrix kernels.  The one-workgroup Jacobi solver needs ~150 ms at d = 256
+// (its matrices do not fit LDS); when only nc << d pairs are wanted (FastICA with n_components, Pca with k < d) a
+// block of p = nc + 16 vectors converges in a few products.  On success V[:, :nc] (ld = dp) and w[:nc] are filled and
+// true is returned; otherwise the caller runs the full solver.  Convergence: ||C v - w v|| <= 1e-12 w_0 for every pair.
+bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc, double* V, double* w) {
+    const int64_t p = std::min<int64_t>(round_up(nc + 16, 16), dp);
+    if (nc <= 0 || p >= d || d <= 88) return false;
+    Dev* dv = c.dev;
+    DBuf Q(dv, sizeof(double) * dp * p), Y(dv, sizeof(double) * dp * p), G(dv, sizeof(double) * p * p), T(dv, sizeof(double) * p * p);
+    DBuf H(dv, sizeof(double) * p * p), S(dv, sizeof(double) * p * p), th(dv, sizeof(double) * p), R(dv, sizeof(double) * dp * p);
+    DBuf QS(dv, sizeof(double) * dp * p);
+    {
+        std::vector<double> h(size_t(dp) * p, 0.0);
+        uint64_t st = 0x9E3779B97F4A7C15ull;
+        for (int64_t i = 0; i < d; ++i)
+            for (int64_t j = 0; j < p; ++j) {
+                st = st * 6364136223846793005ull + 1442695040888963407ull;
+                h[size_t(i) * p + j] = double(int64_t(st >> 11)) / double(1ll << 52) - 1.0;
+            }
+        dev_h2d(dv, Y.p, h.data(), Y.bytes);
+    }
+    auto orth = [&](DBuf& src, DBuf& dst) {  // dst = orthonormal basis of range(src), two Cholesky-QR rounds
+        const double* in = src.f64();
+        for (int rep = 0; rep < 2; ++rep) {
+            op_dgemm(dv, true, false, p, p, dp, 1.0, in, p, in, p, 0.0, G.f64(), p);
+            op_chol_inv(dv, G.f64(), p, p, T.f64(), p, 1e-14);
+            double* out = rep == 0 ? R.f64() : dst.f64();
+            op_dgemm(dv, false, false, dp, p, p, 1.0, in, p, T.f64(), p, 0.0, out, p);
+            in = out;
+        }
+    };
+    std::vector<double> hG(size_t(p) * p), hth(p);
+    for (int it = 0; it < 40; ++it) {
+        if (it == 0) op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, Y.f64(), p, 0.0, R.f64(), p), std::swap(Y, R);
+        orth(Y, Q);
+        op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, Q.f64(), p, 0.0, Y.f64(), p);  // Y = C Q
+        if (it % 2 == 1 || it == 0) {
+            op_dgemm(dv, true, false, p, p, dp, 1.0, Q.f64(), p, Y.f64(), p, 0.0, H.f64(), p);  // Rayleigh quotient
+            op_eigh(dv, H.f64(), p, p, S.f64(), p, th.f64());
+            op_dgemm(dv, false, false, dp, p, p, 1.0, Q.f64(), p, S.f64(), p, 0.0, QS.f64(), p);  // Ritz vectors
+            op_dgemm(dv, false, false, dp, p, p, 1.0, Y.f64(), p, S.f64(), p, 0.0, R.f64(), p);   // C (Q S)
+            DBuf QST(dv, QS.bytes);                                                               // (Q S) diag(theta)
+            dev_d2d(dv, QST.p, QS.p, QS.bytes);
+            op_dscale_cols(dv, QST.f64(), dp, p, p, th.f64());
+            op_daxpy(dv, dp * p, -1.0, QST.f64(), R.f64());                                       // residuals
+            op_dgemm(dv, true, false, p, p, dp, 1.0, R.f64(), p, R.f64(), p, 0.0, G.f64(), p);
+            dev_d2h(dv, hG.data(), G.p, G.bytes);
+            dev_d2h(dv, hth.data(), th.p, th.bytes);
+            dev_sync(dv);
+            double worst = 0;
+            for (int64_t j = 0; j < nc; ++j) worst = std::max(worst, std::sqrt(std::max(hG[size_t(j) * p + j], 0.0)));
+            if (std::isfinite(worst) && hth[0] > 0 && worst <= 1e-12 * hth[0]) {
+                dev_copy2d(dv, V, dp * sizeof(double), QS.p, p * sizeof(double), size_t(nc) * sizeof(double), size_t(dp), 2);
+                dev_d2d(dv, w, th.p, sizeof(double) * nc);
+                return true;
+            }
+        }
+    }
+    return false;
 }
 
 struct Timer {
@@ -365,12 +428,23 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp);
     op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
     allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
-    op_eigh(c.dev, C.f64(), dp, dp, V.f64(), dp, lam.f64());
+    // total_variance = sigma . sigma over ALL singular values (pca.rs:224) = trace of the Gram matrix
+    std::vector<double> hdiag(dp);
+    dev_copy2d(c.dev, hdiag.data(), sizeof(double), C.p, (dp + 1) * sizeof(double), sizeof(double), size_t(dp), 1);
+    dev_sync(c.dev);
+    double trace = 0;
+    for (int64_t j = 0; j < d; ++j) trace += hdiag[j];
+    dev_memset(c.dev, V.p, 0, V.bytes);
+    dev_memset(c.dev, lam.p, 0, lam.bytes);
+    // only the top-k pairs reach the outputs (components, singular values, the k columns of U that svd_flip signs)
+    const bool partial = topk_eigh(c, C.f64(), d, dp, k, V.f64(), lam.f64());
+    if (!partial) op_eigh(c.dev, C.f64(), dp, dp, V.f64(), dp, lam.f64());
     op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
     op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, dt == F32 ? 1e-6 : 1e-10);
 
-    // U[:, j] = Xc v_j / sigma_j for j < r = min(n, d): only the columns svd_flip looks at
-    const int64_t r = std::min(n_total, d), rp = round_up(std::max<int64_t>(r, 1), 16);
+    // U[:, j] = Xc v_j / sigma_j for j < r: only the columns svd_flip looks at (all min(n, d) of them in the crate;
+    // the signs of columns >= k never reach an output)
+    const int64_t r = partial ? k : std::min(n_total, d), rp = round_up(std::max<int64_t>(r, 1), 16);
     DBuf Pm(c.dev, sizeof(double) * dp * rp);
     dev_memset(c.dev, Pm.p, 0, Pm.bytes);
     {
@@ -388,8 +462,7 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     dev_d2h(c.dev, hs.data(), sig.p, sig.bytes);
     dev_d2h(c.dev, hmu.data(), mu64.p, mu64.bytes);
     dev_sync(c.dev);
-    double tvar = 0;  // pca.rs:224: sigma . sigma over all min(n,d) singular values
-    for (int64_t j = 0; j < r; ++j) tvar += hs[j] * hs[j];
+    const double tvar = trace;
     for (int64_t j = 0; j < k; ++j) {
         for (int64_t i = 0; i < d; ++i) put_elem(components, dt, j * d + i, sg[j] * hV[size_t(i) * dp + j]);
         put_elem(singular, dt, j, hs[j]);
@@ -523,7 +596,10 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
     DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp);
     op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
     allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
-    op_eigh(c.dev, C.f64(), dp, dp, U.f64(), dp, lam.f64());
+    dev_memset(c.dev, U.p, 0, U.bytes);
+    dev_memset(c.dev, lam.p, 0, lam.bytes);
+    if (!topk_eigh(c, C.f64(), d, dp, nc, U.f64(), lam.f64()))  // only the first nc pairs are used below
+        op_eigh(c.dev, C.f64(), dp, dp, U.f64(), dp, lam.f64());
     op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
     op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, 0.0);
     op_dscale_cols(c.dev, U.f64(), dp, dp, dp, inv.f64());  // U[:, i] / sigma_i  == K^T (ica.rs:190-203)

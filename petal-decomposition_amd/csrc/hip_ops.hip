@@ -831,6 +831,73 @@ __global__ __launch_bounds__(256, 2) void k_atb_mfma(const float* __restrict__ A
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2p: the `precise` form of C = (A - muA)^T (B - muB): every product and the whole accumulation in fp64 on
+// v_mfma_f64_16x16x4_f64 (exact Pca and FastICA whitening need the small eigenvalues of the Gram matrix, which an fp32
+// accumulation would drown).  A wave owns 32 columns of A (2 m-tiles: one 8-B load per lane, tile t row i <-> m =
+// m0 + 2 i + t) x 64 columns of B (4 tiles: one 16-B load, tile e col j <-> col = n0 + 4 j + e) and a row chunk.
+// f64 C/D map: reg r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool CA, bool CB>
+__global__ __launch_bounds__(256) void k_atb_f64(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
+                                                 const float* __restrict__ B, int64_t ldb, int N, const float* __restrict__ muB,
+                                                 int64_t n, int64_t chunk, double* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int m0 = (blockIdx.x * 4 + wave) * 32, n0 = blockIdx.y * 64;
+    if (m0 >= M) return;
+    const int64_t rbeg = (int64_t)blockIdx.z * chunk, rend = min(n, rbeg + chunk);
+    const int mc = min(m0 + 2 * i, M - 2), nc4 = min(n0 + 4 * i, N - 4);  // clamped: out-of-range outputs are never stored
+    const float* ap = A + mc;
+    const float* bp = B + nc4;
+    f32x2 ma = f32x2{0.f, 0.f};
+    f32x4 mb = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (CA) ma = *reinterpret_cast<const f32x2*>(muA + mc);
+    if (CB) mb = *reinterpret_cast<const f32x4*>(muB + nc4);
+    f64x4 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int64_t r0 = rbeg; r0 < rend; r0 += 16) {
+        f32x2 av[4];
+        f32x4 bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t r = r0 + 4 * s + q;
+            const int64_t rc = r < rend ? r : rend - 1;
+            av[s] = *reinterpret_cast<const f32x2*>(ap + rc * lda);
+            bv[s] = *reinterpret_cast<const f32x4*>(bp + rc * ldb);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool rv = (r0 + 4 * s + q) < rend;
+            if (CA) av[s] -= ma;            // centred in the storage type, exactly like the crate's `input - &means`
+            if (CB) bv[s] -= mb;
+            if (!rv) bv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[t][e] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[s][t], (double)bv[s][e], acc[t][e], 0, 0, 0);
+        }
+    }
+    double* out = part + (int64_t)blockIdx.z * M * N;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 2 * (q + 4 * r) + t;
+            if (m >= M) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = n0 + 4 * i + e;
+                if (col < N) out[(int64_t)m * N + col] = acc[t][e][r];
+            }
+        }
+}
+
 // ================================================================================================
 // K7: fused FastICA step (ica.rs:332-333) -- per 16-sample tile: S = X1 . W^T (MFMA) -> tanh ->
 // D += G^T . X1 (MFMA) and gp += sum(1 - g^2); partial D / gp per wave, combined in fp64.
@@ -924,33 +991,58 @@ __global__ __launch_bounds__(256) void k_ica_mfma(const float* __restrict__ X1T,
                 for (int b = 0; b < NT; ++b)
                     dacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[a][s], xb[s][b], dacc[a][b], 0, 0, 0);
     }
-    // partial slab per wave: [NCP*NCP D | NCP gp]
-    float* out = part + wid * (NCP * NCP + NCP);
+    // one partial slab per WORKGROUP: the four waves add their tiles into LDS in a fixed order (deterministic), then
+    // the slab [NCP*NCP D | NCP gp] is written once, coalesced
+    __shared__ float s_slab[NCP * NCP + NCP];
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
+            for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
+                for (int b = 0; b < NT; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(16 * a + 4 * q + r) * NCP + 16 * b + i] = dacc[a][b][r];
+                    for (int r = 0; r < 4; ++r) {
+                        float* dst = &s_slab[(16 * a + 4 * q + r) * NCP + 16 * b + i];
+                        *dst = (w == 0 ? 0.f : *dst) + dacc[a][b][r];
+                    }
 #pragma unroll
-    for (int a = 0; a < NT; ++a) {
-        float g = gpa[a];
-        g += __shfl_xor(g, 16, 64);
-        g += __shfl_xor(g, 32, 64);
-        if (q == 0) out[NCP * NCP + 16 * a + i] = g;
+            for (int a = 0; a < NT; ++a) {
+                float gsum = gpa[a];
+                gsum += __shfl_xor(gsum, 16, 64);
+                gsum += __shfl_xor(gsum, 32, 64);
+                if (q == 0) {
+                    float* dst = &s_slab[NCP * NCP + 16 * a + i];
+                    *dst = (w == 0 ? 0.f : *dst) + gsum;
+                }
+            }
+        }
+        __syncthreads();
     }
+    float* out = part + (int64_t)blockIdx.x * (NCP * NCP + NCP);
+    for (int e = threadIdx.x; e < NCP * NCP + NCP; e += 256) out[e] = s_slab[e];
 }
-// combine the per-wave slabs in fp64 and drop the padding: GX_gp = [nc*nc | nc]
-__global__ void k_ica_reduce(const float* __restrict__ part, int64_t nparts, int NCP, int nc, double* __restrict__ out,
-                             const int* __restrict__ state) {
+// combine the per-workgroup slabs in fp64 (fixed order) and drop the padding: GX_gp = [nc*nc | nc].
+// block = 32 outputs x 8 part-lanes.
+__global__ __launch_bounds__(256) void k_ica_reduce(const float* __restrict__ part, int64_t nparts, int NCP, int nc,
+                                                    double* __restrict__ out, const int* __restrict__ state) {
     if (state && state[0]) return;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nc * nc + nc) return;
+    __shared__ double red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + tx;
     const int64_t slab = (int64_t)NCP * NCP + NCP;
-    const int src = e < nc * nc ? (e / nc) * NCP + (e % nc) : NCP * NCP + (e - nc * nc);
-    double s = 0;
-    for (int64_t p = 0; p < nparts; ++p) s += (double)part[p * slab + src];
-    out[e] = s;
+    double sacc = 0;
+    if (e < nc * nc + nc) {
+        const int src = e < nc * nc ? (e / nc) * NCP + (e % nc) : NCP * NCP + (e - nc * nc);
+        for (int64_t p = ty; p < nparts; p += 8) sacc += (double)part[p * slab + src];
+    }
+    red[ty][tx] = sacc;
+    __syncthreads();
+    if (ty == 0 && e < nc * nc + nc) {
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][tx];
+        out[e] = t;
+    }
 }
 
 // generic FastICA step: one block per chunk of 64 samples, fp64
@@ -1473,6 +1565,59 @@ __device__ void wg_symdecorr(const double* Win, double* Wout, int nc, int mode, 
     }
     __syncthreads();
 }
+// Orthogonal polar factor of D (= (D D^T)^(-1/2) D, the symmetric decorrelation of ica.rs:363-381) by the
+// Newton-Schulz iteration X <- 1.5 X - 0.5 (X X^T) X from X0 = D / ||D||_F, entirely in LDS: two nc^3 products and
+// three barriers per step instead of a full Jacobi eigen-solve (305 us -> tens of us at nc = 32).  Converges
+// quadratically once the singular values are O(1); returns false (caller falls back to the eigen-solver) if D is
+// singular / non-finite or 60 steps do not reach ||X X^T - I||_F <= 1e-13.
+__device__ bool wg_polar_ns(const double* D, double* Wout, int nc, double* X, double* T, double* Y, double* s_red) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    const int ld = nc | 1;
+    auto block_sum = [&](double v) {
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        __syncthreads();
+        if (lane == 0) s_red[wv] = v;
+        __syncthreads();
+        double t = 0;
+        for (int w = 0; w < nw; ++w) t += s_red[w];
+        return t;
+    };
+    double ss = 0;
+    for (int e = tid; e < nc * nc; e += nt) ss += D[e] * D[e];
+    const double fro2 = block_sum(ss);
+    if (!(fro2 > 0.0) || !(fro2 < 1e300)) return false;
+    const double inv = 1.0 / sqrt(fro2);
+    for (int e = tid; e < nc * nc; e += nt) X[(e / nc) * ld + (e % nc)] = D[e] * inv;
+    __syncthreads();
+    bool ok = false;
+    for (int it = 0; it < 60; ++it) {
+        double err = 0;
+        for (int e = tid; e < nc * nc; e += nt) {
+            const int i = e / nc, j = e - i * nc;
+            double acc = 0;
+            for (int k = 0; k < nc; ++k) acc += X[i * ld + k] * X[j * ld + k];
+            T[i * ld + j] = acc;
+            const double dlt = acc - (i == j ? 1.0 : 0.0);
+            err += dlt * dlt;
+        }
+        const double terr = block_sum(err);  // (its barriers also publish T)
+        if (!(terr == terr)) return false;
+        if (terr <= 1e-26) { ok = true; break; }
+        for (int e = tid; e < nc * nc; e += nt) {
+            const int i = e / nc, j = e - i * nc;
+            double acc = 0;
+            for (int k = 0; k < nc; ++k) acc += T[i * ld + k] * X[k * ld + j];
+            Y[i * ld + j] = 1.5 * X[i * ld + j] - 0.5 * acc;
+        }
+        __syncthreads();
+        double* sw = X; X = Y; Y = sw;
+    }
+    if (!ok) return false;
+    for (int e = tid; e < nc * nc; e += nt) Wout[e] = X[(e / nc) * ld + (e % nc)];
+    __syncthreads();
+    return true;
+}
+
 constexpr int ICA_TAIL_THREADS = 512;
 template <int MB>
 __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_symdecorr(const double* Win, double* Wout, int nc, int mode, double* scratch) {
@@ -1498,7 +1643,11 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
     const double pinv = 1.0 / n_total;
     for (int e = tid; e < nc * nc; e += nt) D[e] = GX[e] * pinv - gp[e / nc] * pinv * W[e];  // ica.rs:334-342
     __syncthreads();
-    wg_symdecorr<MB>(D, W1, nc, mode, S, Zt, Z, Mm, w, ws);  // ica.rs:343
+    bool done_ns = false;  // ica.rs:343
+    if constexpr (MB > 0) {
+        if (mode == 0 || nc <= 2) done_ns = wg_polar_ns(D, W1, nc, S, Zt, Zt + nc * (nc | 1), ws.red);
+    }
+    if (!done_ns) wg_symdecorr<MB>(D, W1, nc, mode, S, Zt, Z, Mm, w, ws);
     double lim = 0;  // ica.rs:344-354
     for (int i = tid; i < nc; i += nt) {
         double dot = 0;
@@ -1520,6 +1669,10 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
 __global__ void k_dscal(double* x, int64_t count, double alpha) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e < count) x[e] *= alpha;
+}
+__global__ void k_daxpy(int64_t count, double alpha, const double* x, double* y) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e < count) y[e] += alpha * x[e];
 }
 __global__ void k_dvec(int mode, const double* x, double* y, int64_t count, double thr) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1771,6 +1924,30 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     if (n == 0) { HIP_CHECK(hipMemset2DAsync(C, ldc * sizeof(double), 0, N * sizeof(double), M, d->stream)); return; }
     const bool mfma = !precise && dt == F32 && M % 16 == 0 && N % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B) &&
                       (!muA || aligned16(muA)) && (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
+    const bool mfma64 = precise && dt == F32 && M % 16 == 0 && N % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) &&
+                        aligned16(B) && (!muA || aligned16(muA)) && (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
+    if (mfma64) {
+        const int mslices = cdiv(M, 32), npanels = cdiv(N, 64);
+        int64_t nsplit = std::max<int64_t>(1, 2048 / ((int64_t)mslices * npanels));
+        nsplit = std::min<int64_t>(nsplit, 64);
+        nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 256));
+        const int64_t chunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
+        nsplit = (n + chunk - 1) / chunk;
+        double* part = (double*)dev_alloc(d, sizeof(double) * nsplit * M * N);
+        const dim3 grid(cdiv(M, 128), npanels, (unsigned)nsplit), block(256);
+        const float* Af = (const float*)A; const float* Bf = (const float*)B; const float* ma = (const float*)muA; const float* mb = (const float*)muB;
+        TagScope ts(d);
+        if (ma && mb) hipLaunchKernelGGL((k_atb_f64<true, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part);
+        else if (ma) hipLaunchKernelGGL((k_atb_f64<true, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part);
+        else if (mb) hipLaunchKernelGGL((k_atb_f64<false, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part);
+        else hipLaunchKernelGGL((k_atb_f64<false, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part);
+        launch_check();
+        ts.stop();
+        hipLaunchKernelGGL(k_sum_parts2<double>, dim3(cdiv(M * N, 32)), dim3(256), 0, d->stream, part, nsplit, M * N, C, N, ldc, false);
+        launch_check();
+        dev_free(d, part);
+        return;
+    }
     if (!mfma) {
         const int64_t nparts = cdiv(n, ATB_S_ROWS);
         double* part = (double*)dev_alloc(d, sizeof(double) * nparts * M * N);
@@ -1876,7 +2053,7 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
     const int64_t tpw = (tiles + waves - 1) / waves;
     waves = (tiles + tpw - 1) / tpw;
     const int blocks = cdiv(waves, 4);
-    const int64_t nparts = (int64_t)blocks * 4;
+    const int64_t nparts = (int64_t)blocks;  // one slab per workgroup
     const int64_t slab = (int64_t)NCP * NCP + NCP;
     float* part = (float*)dev_alloc(d, sizeof(float) * nparts * slab);
     TagScope ts(d);
@@ -1888,7 +2065,7 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
     }
     launch_check();
     ts.stop();
-    hipLaunchKernelGGL(k_ica_reduce, dim3(cdiv(cnt, 256)), dim3(256), 0, d->stream, part, nparts, NCP, (int)nc, GX_gp, state);
+    hipLaunchKernelGGL(k_ica_reduce, dim3(cdiv(cnt, 32)), dim3(256), 0, d->stream, part, nparts, NCP, (int)nc, GX_gp, state);
     launch_check();
     dev_free(d, part);
     dev_free(d, Wpk);
@@ -1910,7 +2087,7 @@ static void set_max_lds(const void* fn) { HIP_CHECK(hipFuncSetAttribute(fn, hipF
 void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol, int* state, int iter) {
     double* scratch = (double*)dev_alloc(d, sizeof(double) * (6 * nc * nc + nc));
     const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
-    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 2 * nc * (nc | 1) : 0));
+    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 3 * nc * (nc | 1) : 0));
     MB_DISPATCH(mb, {
         static bool once = false;
         if (!once) { set_max_lds(reinterpret_cast<const void*>(k_ica_tail<MBv>)); once = true; }
@@ -1973,6 +2150,11 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
 void op_dscal(Dev* d, double* x, int64_t count, double alpha) {
     if (!count) return;
     hipLaunchKernelGGL(k_dscal, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, x, count, alpha);
+    launch_check();
+}
+void op_daxpy(Dev* d, int64_t count, double alpha, const double* x, double* y) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_daxpy, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, count, alpha, x, y);
     launch_check();
 }
 void op_dvec(Dev* d, int mode, const double* x, double* y, int64_t count, double thr) {

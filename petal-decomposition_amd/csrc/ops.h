@@ -98,6 +98,8 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
 void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w);
 // x[i] *= alpha
 void op_dscal(Dev*, double* x, int64_t count, double alpha);
+// y[i] += alpha * x[i]
+void op_daxpy(Dev*, int64_t count, double alpha, const double* x, double* y);
 // elementwise helpers on f64 vectors:  mode 0: y = sqrt(max(x,0)); mode 1: y = x > thr*x[0] ? 1/x : 0
 void op_dvec(Dev*, int mode, const double* x, double* y, int64_t count, double thr);
 // A[i][j] *= s[j]  (f64 matrix M x N)

@@ -56,3 +56,15 @@ def test_ica_parity(ctx):
     pc.ica_par_parity(ctx, 50000, 32, seed=10, dtype=np.float32, tol=1e-4)
     pc.ica_parity(ctx, 20000, 24, 8, seed=6, dtype=np.float32, n_components=8)
     pc.ica_parity(ctx, 5000, 6, 6, seed=5, dtype=np.float64)
+
+
+def test_topk_subspace_eigensolver_paths(ctx):
+    pc.pca_parity(ctx, 3000, 256, 8, seed=31, dtype=np.float64, tol=1e-8)
+    pc.pca_parity(ctx, 20000, 256, 16, seed=33, dtype=np.float32, tol=2e-5)     # fp64-MFMA precise Gram + subspace iteration
+    pc.ica_parity(ctx, 30000, 128, 8, seed=32, dtype=np.float32, n_components=8)
+
+
+def test_full_size_configs(ctx):
+    """BASELINE configs[1] and configs[2] at full size: oracle parity where the oracle finishes in seconds."""
+    pc.rpca_parity(ctx, 100000, 512, 64, 5, seed=2, tol=1e-5, device=True)          # configs[1]
+    pc.ica_parity(ctx, 200000, 256, 32, seed=5, dtype=np.float32, n_components=32, device=True)   # configs[2]

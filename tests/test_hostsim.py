@@ -42,3 +42,9 @@ def test_ica_parity(ctx):
     pc.ica_parity(ctx, 3000, 6, 6, seed=5, dtype=np.float64)
     pc.ica_parity(ctx, 3000, 12, 4, seed=6, dtype=np.float32, n_components=4)
     pc.ica_par_parity(ctx, 2000, 5, seed=8, dtype=np.float64, tol=1e-8)
+
+
+def test_topk_subspace_eigensolver_paths(ctx):
+    # d > 88 and k / n_components << d: whitening and exact Pca go through the block subspace iteration
+    pc.pca_parity(ctx, 1500, 128, 6, seed=31, dtype=np.float64, tol=1e-8)
+    pc.ica_parity(ctx, 3000, 100, 6, seed=32, dtype=np.float64, n_components=6)
