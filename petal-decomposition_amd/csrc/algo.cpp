@@ -316,25 +316,29 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv.f64());
     dev_set_tag(c.dev, TAG_NONE);
 
-    DBuf GY(c.dev, sizeof(double) * (LP * LP + dp * LP));  // [ Z^T Z | Xc^T Z ] reduced across ranks together
+    DBuf GY(c.dev, sizeof(double) * (LP * LP + dp * LP));  // [ Z^T Z | Xc^T Z ]
     DBuf T(c.dev, sizeof(double) * LP * LP), Y(c.dev, sizeof(double) * dp * LP);
     double* G = GY.f64();
     double* Yp = GY.f64() + LP * LP;
+    double* Pcur = P.f64();  // the orthonormal basis the current Z was formed with
     for (int64_t it = 0; it < n_iter; ++it) {  // pca.rs:708-715
-        // re-base the tall iterate: G = Z^T Z, T = chol(G)^-1 (stands for PL(LU(Z)), pca.rs:709-710);
-        // T is applied on the small side: Xc^T (Z T) = (Xc^T Z) T, so Z is never rewritten.
-        op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP);
         dev_set_tag(c.dev, TAG_ATB);
-        op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z.p, LP, LP, nullptr, n, Yp, LP);  // pca.rs:711
+        op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z.p, LP, LP, nullptr, n, Yp, LP);  // Yp = Xc^T Z (pca.rs:711)
         dev_set_tag(c.dev, TAG_NONE);
-            allreduce_f64(c, GY.f64(), LP * LP + dp * LP, PETAL_SUM);
+        allreduce_f64(c, Yp, dp * LP, PETAL_SUM);
+        // re-base the tall iterate (stands for PL(LU(Z)), pca.rs:709-710): its Gram matrix needs no pass over Z, since
+        // Z = Xc P gives Z^T Z = P^T (Xc^T Z) = P^T Yp; T = chol(G)^-1 is applied on the small side,
+        // Xc^T (Z T) = Yp T, so the tall matrix is never rewritten either.
+        // (op_chol_inv reads the upper triangle only, which symmetrises the rounding-level asymmetry of P^T Yp)
+        op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Pcur, LP, Yp, LP, 0.0, G, LP);
         op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);
         op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
         orthonormalize_small(c, Y, dp, LP, 1e-13);  // pca.rs:712-713
+        Pcur = Y.f64();
         dev_set_tag(c.dev, TAG_XP);
         op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Y.f64(), LP, LP, nullptr, Z.p, LP, nullptr);  // pca.rs:714
         dev_set_tag(c.dev, TAG_NONE);
-        }
+    }
 
     // thin QR of Z (pca.rs:716) as Cholesky-QR2: Z1 = Z T1, Q = Z1 T2 with T2 folded into the small side
     op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP);

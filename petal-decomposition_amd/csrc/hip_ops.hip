@@ -1091,26 +1091,45 @@ __global__ void k_sum_parts_state(const double* __restrict__ part, int64_t npart
 // ================================================================================================
 // fp64 small-matrix kernels
 // ================================================================================================
-__global__ void k_dgemm(bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* __restrict__ A,
-                        int64_t lda, const double* __restrict__ B, int64_t ldb, double beta, double* __restrict__ C, int64_t ldc) {
-    __shared__ double sa[16][17], sb[16][17];
+// C[M x N] = alpha op(A) op(B) + beta C, fp64, 16 x 16 outputs per block, 32-deep K steps; the global loads are
+// coalesced for every transposition case (the transposed operand is read along its contiguous index and
+// transposed on the way into LDS).
+__global__ __launch_bounds__(256) void k_dgemm(bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha,
+                                               const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+                                               double beta, double* __restrict__ C, int64_t ldc) {
+    constexpr int BK = 32;
+    __shared__ double sa[16][BK + 1], sb[BK][17];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int64_t i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+    const int64_t i0 = (int64_t)blockIdx.y * 16, j0 = (int64_t)blockIdx.x * 16;
     double acc = 0;
-    for (int64_t k0 = 0; k0 < K; k0 += 16) {
-        {   // sa[ty][tx] = opA[i][k0 + tx]
-            const int64_t k = k0 + tx;
-            sa[ty][tx] = (i < M && k < K) ? (ta ? A[k * lda + i] : A[i * lda + k]) : 0.0;
-        }
-        {   // sb[ty][tx] = opB[k0 + ty][j]
-            const int64_t k = k0 + ty;
-            sb[ty][tx] = (j < N && k < K) ? (tb ? B[j * ldb + k] : B[k * ldb + j]) : 0.0;
+    for (int64_t k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (ta) {  // A is K x M: contiguous in i
+                const int kk = ty + 16 * h;
+                const int64_t k = k0 + kk, i = i0 + tx;
+                sa[tx][kk] = (i < M && k < K) ? A[k * lda + i] : 0.0;
+            } else {   // A is M x K: contiguous in k
+                const int kk = tx + 16 * h;
+                const int64_t k = k0 + kk, i = i0 + ty;
+                sa[ty][kk] = (i < M && k < K) ? A[i * lda + k] : 0.0;
+            }
+            if (tb) {  // B is N x K: contiguous in k
+                const int kk = tx + 16 * h;
+                const int64_t k = k0 + kk, j = j0 + ty;
+                sb[kk][ty] = (j < N && k < K) ? B[j * ldb + k] : 0.0;
+            } else {   // B is K x N: contiguous in j
+                const int kk = ty + 16 * h;
+                const int64_t k = k0 + kk, j = j0 + tx;
+                sb[kk][tx] = (j < N && k < K) ? B[k * ldb + j] : 0.0;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc += sa[ty][k] * sb[k][tx];
+        for (int k = 0; k < BK; ++k) acc += sa[ty][k] * sb[k][tx];
         __syncthreads();
     }
+    const int64_t i = i0 + ty, j = j0 + tx;
     if (i < M && j < N) C[i * ldc + j] = alpha * acc + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
 }
 
