@@ -285,3 +285,89 @@ def ica_par_parity(ctx, n, nc, seed, dtype=np.float32, tol=1e-4):
     w, ni = petal.ica_par(x1, 1e-4, 200, w0.astype(dtype), ctx=ctx)
     assert abs(ni - no) <= 1, (ni, no)
     assert np.abs(w @ wo.T - np.eye(nc)).max() <= (tol if ni == no else 10 * tol), np.abs(w @ wo.T - np.eye(nc)).max()
+
+
+# ---- edge cases the reference handles (ragged shapes, views, degenerate ranks) -----------------------
+def edge_cases(ctx, device=False):
+    rng = np.random.default_rng(123)
+
+    def dev(a):
+        if not device:
+            return a
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def host(a):
+        return a.cpu().numpy() if hasattr(a, "cpu") else a
+
+    # n < d (wide), odd shapes, l clipped to min(n, d)
+    x = rng.standard_normal((37, 101))
+    om = rng.standard_normal((101, 15))
+    o = po.RandomizedPcaOracle(5).fit(x, omega=om)
+    m = petal.RandomizedPca(5, ctx=ctx).fit(dev(x), omega=om)
+    assert rowwise_rel(m.components(), o.components).max() < 1e-6
+    assert np.allclose(m.singular_values(), o.singular, rtol=1e-8)
+    p = petal.Pca.new(5, ctx).fit(dev(x))
+    po_ = po.PcaOracle(5).fit(x)
+    assert rowwise_rel(p.components(), po_.components).max() < 1e-8
+    assert np.allclose(p.explained_variance_ratio(), po_.explained_variance_ratio(), rtol=1e-8)
+
+    # transposed (column-major) and strided views of a bigger buffer: ndarray accepts any strides
+    big = rng.standard_normal((64, 3000)).astype(np.float32)
+    xv = big.T[5:2905:2, 3:51]                      # 1450 x 48 view, row stride 2, column stride 3000
+    assert not xv.flags["C_CONTIGUOUS"]
+    om = rng.standard_normal((48, 14)).astype(np.float32)
+    o = po.RandomizedPcaOracle(4, n_iter=4).fit(np.ascontiguousarray(xv).astype(np.float64), omega=om.astype(np.float64))
+    xin = xv
+    if device:
+        import torch
+        xin = torch.from_numpy(big).cuda().T[5:2905:2, 3:51]
+    m = petal.RandomizedPca(4, ctx=ctx, n_iter=4).fit(xin, omega=om)
+    assert rowwise_rel(m.components().astype(np.float64), o.components).max() < 1e-5
+    y = host(m.transform(xin))
+    assert np.abs(np.abs(y) - np.abs(o.transform(np.ascontiguousarray(xv).astype(np.float64)))).max() < 1e-3
+
+    # exactly rank-deficient data (rank 3 in 20 dims), k beyond the rank: finite results, leading part exact
+    b = rng.standard_normal((500, 3)) @ rng.standard_normal((3, 20))
+    om = rng.standard_normal((20, 16))
+    o = po.RandomizedPcaOracle(6).fit(b, omega=om)
+    m = petal.RandomizedPca(6, ctx=ctx)
+    yb = host(m.fit_transform(dev(b), omega=om))
+    assert np.all(np.isfinite(m.components())) and np.all(np.isfinite(yb))
+    assert rowwise_rel(m.components()[:3], o.components[:3]).max() < 1e-7
+    assert np.allclose(m.singular_values()[:3], o.singular[:3], rtol=1e-9)
+    assert np.all(m.singular_values()[3:] < 1e-6 * m.singular_values()[0])
+    assert np.allclose(m.inverse_transform(m.transform(b)), b, atol=1e-8 * np.abs(b).max())
+
+    # constant columns / a zero matrix
+    z = np.zeros((50, 4))
+    m = petal.RandomizedPca(2, ctx=ctx).fit(dev(z), omega=rng.standard_normal((4, 12)))
+    assert np.all(np.isfinite(m.components())) and np.all(m.singular_values() == 0)
+    p = petal.Pca.new(2, ctx).fit(dev(z))
+    assert np.all(np.isfinite(p.components())) and np.all(p.singular_values() == 0)
+
+    # k == min(n, d) (nothing to oversample into), k = 0 with data, zero rows
+    x = rng.standard_normal((9, 4))
+    om = rng.standard_normal((4, 14))
+    o = po.RandomizedPcaOracle(4).fit(x, omega=om)
+    m = petal.RandomizedPca(4, ctx=ctx).fit(dev(x), omega=om)
+    assert rowwise_rel(m.components(), o.components).max() < 1e-8
+    y0 = petal.RandomizedPca(0, ctx=ctx).fit_transform(x)
+    assert y0.shape == (9, 0)
+    m = petal.RandomizedPca(2, ctx=ctx)
+    try:
+        m.fit(np.zeros((0, 4)))          # shape check first: 0 rows < k (src/pca.rs:513-518)
+        raise AssertionError("expected InvalidInput")
+    except petal.InvalidInput:
+        pass
+    petal.RandomizedPca(0, ctx=ctx).fit(np.zeros((0, 4)))       # Ok, model untouched (src/pca.rs:521-525)
+    petal.FastIca(ctx=ctx).fit(np.zeros((0, 3)))                # src/ica.rs:174-176
+
+    # FastICA with n == d-ish small problems and the default n_components = min(n, d)
+    xi = po.synth_ica(400, 3, 3, seed=3, dtype=np.float64)
+    w0 = rng.standard_normal((3, 3))
+    oi = po.FastIcaOracle(whiten="svd").fit(xi, w_init=w0)
+    mi = petal.FastIca(ctx=ctx)
+    yi = host(mi.fit_transform(dev(xi), w_init=w0))
+    c = np.abs(yi.T @ oi.transform(xi))
+    assert np.abs(np.sort(c.max(axis=1)) - 1).max() < 5e-3

@@ -68,3 +68,11 @@ def test_full_size_configs(ctx):
     """BASELINE configs[1] and configs[2] at full size: oracle parity where the oracle finishes in seconds."""
     pc.rpca_parity(ctx, 100000, 512, 64, 5, seed=2, tol=1e-5, device=True)          # configs[1]
     pc.ica_parity(ctx, 200000, 256, 32, seed=5, dtype=np.float32, n_components=32, device=True)   # configs[2]
+
+
+def test_edge_cases(ctx):
+    pc.edge_cases(ctx)
+
+
+def test_edge_cases_device_resident(ctx):
+    pc.edge_cases(ctx, device=True)

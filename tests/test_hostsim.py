@@ -48,3 +48,7 @@ def test_topk_subspace_eigensolver_paths(ctx):
     # d > 88 and k / n_components << d: whitening and exact Pca go through the block subspace iteration
     pc.pca_parity(ctx, 1500, 128, 6, seed=31, dtype=np.float64, tol=1e-8)
     pc.ica_parity(ctx, 3000, 100, 6, seed=32, dtype=np.float64, n_components=6)
+
+
+def test_edge_cases(ctx):
+    pc.edge_cases(ctx)
