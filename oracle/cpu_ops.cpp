@@ -143,7 +143,7 @@ void op_dgemm(Dev*, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double al
             C[i * ldc + j] = alpha * s + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
         }
 }
-void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol) {
+void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead) {
     std::vector<double> R(size_t(L) * L, 0.0);
     std::vector<char> dead(L, 0);
     for (int64_t j = 0; j < L; ++j) {  // row-by-row upper Cholesky, G = R^T R
@@ -159,6 +159,7 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
             R[j * L + c] = v / rjj;
         }
     }
+    if (ndead) { int c = 0; for (int64_t j = 0; j < L; ++j) c += dead[j]; *ndead = c; }
     // T = R^{-1} by back substitution per column; dead columns -> 0 (and are skipped as rows)
     for (int64_t i = 0; i < L; ++i)
         for (int64_t j = 0; j < L; ++j) T[i * ldt + j] = 0;

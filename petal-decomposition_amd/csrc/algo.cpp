@@ -326,10 +326,11 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z.p, LP, LP, nullptr, n, Yp, LP);  // Yp = Xc^T Z (pca.rs:711)
         dev_set_tag(c.dev, TAG_NONE);
         allreduce_f64(c, Yp, dp * LP, PETAL_SUM);
-        // re-base the tall iterate (stands for PL(LU(Z)), pca.rs:709-710): its Gram matrix needs no pass over Z, since
-        // Z = Xc P gives Z^T Z = P^T (Xc^T Z) = P^T Yp; T = chol(G)^-1 is applied on the small side,
-        // Xc^T (Z T) = Yp T, so the tall matrix is never rewritten either.
-        // (op_chol_inv reads the upper triangle only, which symmetrises the rounding-level asymmetry of P^T Yp)
+        // Re-base (stands for the two pivoted-LU re-basings of pca.rs:709-713).  Tall side first: Z = Xc P gives
+        // Z^T Z = P^T (Xc^T Z) = P^T Yp without a pass over Z (op_chol_inv reads the upper triangle only); T =
+        // chol(Z^T Z)^-1 is applied on the small side, Xc^T (Z T) = Yp T, so the tall matrix is never rewritten.  The now
+        // moderately conditioned Yp T then gets one fp64 Cholesky-QR.  (A single Cholesky-QR of Yp itself was tried: its
+        // Gram matrix has cond (s_1/s_l)^4 ~ 5e13 on the benchmark spectrum, beyond what fp64 pivots resolve.)
         op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Pcur, LP, Yp, LP, 0.0, G, LP);
         op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);
         op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);

@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_dgemm(bool ta, bool tb, int64_t M, int6
 constexpr int CHOL_THREADS = 512;
 __device__ __forceinline__ int pk(int r, int c, int L) { return r * L - (r * (r - 1)) / 2 + (c - r); }
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T,
-                                                           int64_t ldt, double rel_tol, int t_in_lds) {
+                                                           int64_t ldt, double rel_tol, int t_in_lds, int* __restrict__ ndead_out) {
     extern __shared__ __attribute__((aligned(16))) double sm_chol[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int np = L * (L + 1) / 2;
@@ -1225,6 +1225,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
             }
             __syncthreads();
         }
+        if (tid == 0 && ndead_out) { int cdead = 0; for (int j = 0; j < L; ++j) cdead += dead[j]; *ndead_out = cdead; }
         // dependent columns: zero the column above the (already zero) diagonal
         for (int e = tid; e < L * L; e += nt) {
             const int r = e / L, c = e % L;
@@ -2136,7 +2137,7 @@ void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double 
                        beta, C, ldc);
     launch_check();
 }
-void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol) {
+void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead) {
     if (L == 0) return;
     if (L > 144) throw std::runtime_error("chol_inv: matrix too large for the one-workgroup LDS kernel (L <= 144)");
     const size_t base = sizeof(double) * (L * (L + 1) / 2 + L + (L + 1) / 2);
@@ -2148,7 +2149,7 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_in_lds);
+    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_in_lds, ndead);
     launch_check();
 }
 void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w) {
