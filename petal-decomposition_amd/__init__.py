@@ -246,9 +246,11 @@ class Context:
         self.check(self.lib.petal_ctx_set_collective(self._h, self._cb, None, int(rank), int(world_size)))
         self.rank, self.world_size = rank, world_size
 
-    def use_torch_distributed(self, group=None):
-        """Sample-sharded multi-GPU: sum the small replicated buffers with torch.distributed
-        (backend "nccl" == RCCL over xGMI on ROCm; "gloo" for the host-simulation tests)."""
+    @staticmethod
+    def torch_allreduce_hook(group=None):
+        """The all-reduce hook as a Python callable ``hook(ptr, count, dtype, op, stream) -> 0``: wraps the raw
+        buffer zero-copy as a torch tensor and calls ``torch.distributed.all_reduce`` on ``group`` (backend "nccl" ==
+        RCCL over xGMI on ROCm, enqueued on the ctx stream; "gloo" for the host-simulation tests)."""
         import torch
         import torch.distributed as dist
         ops = {PETAL_SUM: dist.ReduceOp.SUM, PETAL_MAX: dist.ReduceOp.MAX, PETAL_MIN: dist.ReduceOp.MIN}
@@ -274,7 +276,12 @@ class Context:
                 dist.all_reduce(t, op=ops[op], group=group)
             return 0
 
-        self.set_collective(hook, dist.get_rank(group), dist.get_world_size(group))
+        return hook
+
+    def use_torch_distributed(self, group=None):
+        """Sample-sharded multi-GPU: sum the small replicated buffers with torch.distributed."""
+        import torch.distributed as dist
+        self.set_collective(self.torch_allreduce_hook(group), dist.get_rank(group), dist.get_world_size(group))
 
 
 _default_ctx = None

@@ -1983,7 +1983,8 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     }
     // split the rows so that about 1024 waves (one per SIMD) exist; chunk a multiple of 16 rows
     const int mslices = cdiv(M, 64);
-    int64_t nsplit = std::max<int64_t>(1, 1024 / mslices);
+    static const int waves_target = [] { const char* e = getenv("PETAL_K2_WAVES"); return e ? atoi(e) : 1024; }();
+    int64_t nsplit = std::max<int64_t>(1, waves_target / mslices);
     nsplit = std::min<int64_t>(nsplit, 256);  // bounds the partial-slab traffic of narrow (Gram) products
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 64));
     const int64_t chunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;

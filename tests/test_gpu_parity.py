@@ -76,3 +76,35 @@ def test_edge_cases(ctx):
 
 def test_edge_cases_device_resident(ctx):
     pc.edge_cases(ctx, device=True)
+
+
+def test_rccl_allreduce_hook_single_rank(ctx):
+    """The collective hook of the sharded path on the real backend: a one-rank RCCL ("nccl") group, the raw device
+    buffer wrapped zero-copy, the reduction enqueued on an external HIP stream.  (Multi-rank runs need several GPUs;
+    the sharded algorithm itself is covered by tests/test_sharded_gloo.py.)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    import petal_decomposition_amd as petal
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        hook = petal.Context.torch_allreduce_hook()
+        buf = torch.arange(1000, dtype=torch.float64, device="cuda")
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for op in (petal.PETAL_SUM, petal.PETAL_MAX, petal.PETAL_MIN):
+            assert hook(buf.data_ptr(), buf.numel(), petal.PETAL_F64, op, side.cuda_stream) == 0
+            assert hook(buf.data_ptr(), buf.numel(), petal.PETAL_F64, op, 0) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.float64))
+        c2 = petal.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        c2.use_torch_distributed()                      # world_size 1: installs the hook, fits stay single-GPU
+        x = np.random.default_rng(0).standard_normal((500, 16)).astype(np.float32)
+        petal.RandomizedPca(3, ctx=c2).fit(x)
+        c2.close()
+    finally:
+        dist.destroy_process_group()
