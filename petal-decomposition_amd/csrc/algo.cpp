@@ -317,7 +317,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     dev_set_tag(c.dev, TAG_NONE);
 
     DBuf GY(c.dev, sizeof(double) * (LP * LP + dp * LP));  // [ Z^T Z | Xc^T Z ]
-    DBuf T(c.dev, sizeof(double) * LP * LP), Y(c.dev, sizeof(double) * dp * LP);
+    DBuf T(c.dev, sizeof(double) * LP * LP), Y(c.dev, sizeof(double) * dp * LP), ndead(c.dev, sizeof(int));
     double* G = GY.f64();
     double* Yp = GY.f64() + LP * LP;
     double* Pcur = P.f64();  // the orthonormal basis the current Z was formed with
@@ -326,15 +326,27 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z.p, LP, LP, nullptr, n, Yp, LP);  // Yp = Xc^T Z (pca.rs:711)
         dev_set_tag(c.dev, TAG_NONE);
         allreduce_f64(c, Yp, dp * LP, PETAL_SUM);
-        // Re-base (stands for the two pivoted-LU re-basings of pca.rs:709-713).  Tall side first: Z = Xc P gives
-        // Z^T Z = P^T (Xc^T Z) = P^T Yp without a pass over Z (op_chol_inv reads the upper triangle only); T =
-        // chol(Z^T Z)^-1 is applied on the small side, Xc^T (Z T) = Yp T, so the tall matrix is never rewritten.  The now
-        // moderately conditioned Yp T then gets one fp64 Cholesky-QR.  (A single Cholesky-QR of Yp itself was tried: its
-        // Gram matrix has cond (s_1/s_l)^4 ~ 5e13 on the benchmark spectrum, beyond what fp64 pivots resolve.)
-        op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Pcur, LP, Yp, LP, 0.0, G, LP);
-        op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);
-        op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
-        orthonormalize_small(c, Y, dp, LP, 1e-13);  // pca.rs:712-713
+        // Re-base the d x l iterate (stands for the two pivoted-LU re-basings of pca.rs:709-713).  The next product only
+        // needs SOME well-conditioned basis of range(Yp): P = Yp T spans range(Yp) exactly for any invertible
+        // triangular T, so the accuracy of T only decides how well-conditioned P is, never which subspace it spans (the
+        // final thin QR restores orthonormality).  Fast path: one fp64 Cholesky of Yp^T Yp, accepted while every pivot
+        // stays positive (cond(Yp) <~ 3e7: errors of a few per cent in the weakest pivots merely leave cond(P) ~ 1.x).
+        op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Yp, LP, Yp, LP, 0.0, G, LP);
+        op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, 1e-15, ndead.as<int>());
+        int hdead = 0;
+        dev_d2h(c.dev, &hdead, ndead.p, sizeof(int));
+        dev_sync(c.dev);
+        if (hdead <= LP - L) {
+            op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
+        } else {
+            // ill-conditioned iterate: precondition with the tall side first.  Z = Xc P gives Z^T Z = P^T (Xc^T Z) =
+            // P^T Yp without a pass over Z (op_chol_inv reads the upper triangle only); T = chol(Z^T Z)^-1 is applied on
+            // the small side, Xc^T (Z T) = Yp T, and the now moderately conditioned Yp T gets its own Cholesky-QR.
+            op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Pcur, LP, Yp, LP, 0.0, G, LP);
+            op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);
+            op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
+            orthonormalize_small(c, Y, dp, LP, 1e-13);
+        }
         Pcur = Y.f64();
         dev_set_tag(c.dev, TAG_XP);
         op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Y.f64(), LP, LP, nullptr, Z.p, LP, nullptr);  // pca.rs:714
