@@ -159,7 +159,7 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
             R[j * L + c] = v / rjj;
         }
     }
-    if (ndead) { int c = 0; for (int64_t j = 0; j < L; ++j) c += dead[j]; *ndead = c; }
+    if (ndead) { int c = 0; for (int64_t j = 0; j < L; ++j) c += dead[j]; if (c > *ndead) *ndead = c; }
     // T = R^{-1} by back substitution per column; dead columns -> 0 (and are skipped as rows)
     for (int64_t i = 0; i < L; ++i)
         for (int64_t j = 0; j < L; ++j) T[i * ldt + j] = 0;

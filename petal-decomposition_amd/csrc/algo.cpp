@@ -306,18 +306,27 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         dev_h2d(c.dev, P.p, h.data(), P.bytes);
     }
     DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
-    DBuf tv(c.dev, sizeof(double));
-    dev_memset(c.dev, tv.p, 0, sizeof(double));
+    DBuf tv(c.dev, sizeof(double)), ndead(c.dev, sizeof(int));
     c.stats.pass_flops = 2.0 * double(n) * double(d) * double(l_req);
     c.stats.pass_bytes = double(esz) * (double(n) * d + double(n) * l_req + double(d) * l_req);
 
+    DBuf GY(c.dev, sizeof(double) * (LP * LP + dp * LP));  // [ Z^T Z | Xc^T Z ]
+    DBuf T(c.dev, sizeof(double) * LP * LP), Y(c.dev, sizeof(double) * dp * LP);
+    DBuf Bt(c.dev, sizeof(double) * dp * LP), S(c.dev, sizeof(double) * LP * LP), Uh(c.dev, sizeof(double) * LP * LP);
+    DBuf lam(c.dev, sizeof(double) * LP), sig(c.dev, sizeof(double) * LP), inv(c.dev, sizeof(double) * LP);
+    DBuf V(c.dev, sizeof(double) * dp * LP), M2(c.dev, sizeof(double) * LP * LP);
+    std::vector<double> sg;
+    // The whole device pipeline.  It runs OPTIMISTICALLY first (robust = false): every power iteration re-bases with
+    // the single-Cholesky fast path and no host round trip; the kernels record the worst pivot breakdown in `ndead`,
+    // which is read together with the results.  Only if a breakdown happened is the fit redone with robust = true.
+    auto pipeline = [&](bool robust) {
+    dev_memset(c.dev, tv.p, 0, sizeof(double));
+    dev_memset(c.dev, ndead.p, 0, sizeof(int));
     // Z = Xc . Omega (pca.rs:707), fused with total_variance = sum Xc^2 (pca.rs:533)
     dev_set_tag(c.dev, TAG_XP);
     op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv.f64());
     dev_set_tag(c.dev, TAG_NONE);
 
-    DBuf GY(c.dev, sizeof(double) * (LP * LP + dp * LP));  // [ Z^T Z | Xc^T Z ]
-    DBuf T(c.dev, sizeof(double) * LP * LP), Y(c.dev, sizeof(double) * dp * LP), ndead(c.dev, sizeof(int));
     double* G = GY.f64();
     double* Yp = GY.f64() + LP * LP;
     double* Pcur = P.f64();  // the orthonormal basis the current Z was formed with
@@ -329,14 +338,12 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         // Re-base the d x l iterate (stands for the two pivoted-LU re-basings of pca.rs:709-713).  The next product only
         // needs SOME well-conditioned basis of range(Yp): P = Yp T spans range(Yp) exactly for any invertible
         // triangular T, so the accuracy of T only decides how well-conditioned P is, never which subspace it spans (the
-        // final thin QR restores orthonormality).  Fast path: one fp64 Cholesky of Yp^T Yp, accepted while every pivot
-        // stays positive (cond(Yp) <~ 3e7: errors of a few per cent in the weakest pivots merely leave cond(P) ~ 1.x).
-        op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Yp, LP, Yp, LP, 0.0, G, LP);
-        op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, 1e-15, ndead.as<int>());
-        int hdead = 0;
-        dev_d2h(c.dev, &hdead, ndead.p, sizeof(int));
-        dev_sync(c.dev);
-        if (hdead <= LP - L) {
+        // final thin QR restores orthonormality).
+        if (!robust) {
+            // fast path: one fp64 Cholesky of Yp^T Yp, valid while every pivot stays positive (cond(Yp) <~ 3e7: errors
+            // of a few per cent in the weakest pivots merely leave cond(P) ~ 1.x); breakdowns are recorded in ndead
+            op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Yp, LP, Yp, LP, 0.0, G, LP);
+            op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, 1e-15, ndead.as<int>());
             op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
         } else {
             // ill-conditioned iterate: precondition with the tall side first.  Z = Xc P gives Z^T Z = P^T (Xc^T Z) =
@@ -365,12 +372,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     allreduce_f64(c, GY.f64(), LP * LP + dp * LP, PETAL_SUM);
     allreduce_f64(c, tv.f64(), 1, PETAL_SUM);
     op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);  // T2
-    DBuf Bt(c.dev, sizeof(double) * dp * LP);
     op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Bt.f64(), LP);
 
     // economy SVD of B (l x d) (svddc, pca.rs:682): eigen-decomposition of B B^T in fp64
-    DBuf S(c.dev, sizeof(double) * LP * LP), Uh(c.dev, sizeof(double) * LP * LP), lam(c.dev, sizeof(double) * LP);
-    DBuf sig(c.dev, sizeof(double) * LP), inv(c.dev, sizeof(double) * LP);
     op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Bt.f64(), LP, Bt.f64(), LP, 0.0, S.f64(), LP);
     // only the leading L x L block of S is non-zero (columns L..LP-1 of every iterate are exact zero padding)
     dev_memset(c.dev, Uh.p, 0, Uh.bytes);
@@ -378,15 +382,23 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam.f64());
     op_dvec(c.dev, 0, lam.f64(), sig.f64(), LP, 0.0);
     op_dvec(c.dev, 1, sig.f64(), inv.f64(), LP, dt == F32 ? 1e-7 : 1e-12);
-    DBuf V(c.dev, sizeof(double) * dp * LP);  // V[:, j] = B^T u_j / sigma_j
+    // V[:, j] = B^T u_j / sigma_j
     op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Bt.f64(), LP, Uh.f64(), LP, 0.0, V.f64(), LP);
     op_dscale_cols(c.dev, V.f64(), dp, LP, LP, inv.f64());
 
     // U = Q Uh = Z1 (T2 Uh) (pca.rs:683) and svd_flip (pca.rs:684)
-    DBuf M2(c.dev, sizeof(double) * LP * LP);
     op_dgemm(c.dev, false, false, LP, LP, LP, 1.0, T.f64(), LP, Uh.f64(), LP, 0.0, M2.f64(), LP);
     op_gemm_xp(c.dev, dt, Z1.p, n, LP, LP, nullptr, M2.f64(), LP, LP, nullptr, Z.p, LP, nullptr);  // Z now holds U
-    std::vector<double> sg = flip_signs(c, dt, Z.p, n, LP, LP, ri.row_offset);
+    sg = flip_signs(c, dt, Z.p, n, LP, LP, ri.row_offset);
+    };  // pipeline
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        pipeline(attempt == 1);
+        int hdead = 0;
+        dev_d2h(c.dev, &hdead, ndead.p, sizeof(int));
+        dev_sync(c.dev);
+        if (attempt == 1 || hdead <= LP - L) break;
+    }
 
     // results (pca.rs:543-547)
     std::vector<double> hV(size_t(dp) * LP), hs(LP), hmu(dp);

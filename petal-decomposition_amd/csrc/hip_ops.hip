@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
             }
             __syncthreads();
         }
-        if (tid == 0 && ndead_out) { int cdead = 0; for (int j = 0; j < L; ++j) cdead += dead[j]; *ndead_out = cdead; }
+        if (tid == 0 && ndead_out) { int cdead = 0; for (int j = 0; j < L; ++j) cdead += dead[j]; if (cdead > *ndead_out) *ndead_out = cdead; }
         // dependent columns: zero the column above the (already zero) diagonal
         for (int e = tid; e < L * L; e += nt) {
             const int r = e / L, c = e % L;
