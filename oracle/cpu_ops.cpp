@@ -183,7 +183,7 @@ void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, do
         for (int64_t i = 0; i < L; ++i)
             for (int64_t j = 0; j < L; ++j) (i == j ? diag : off) += A[i * lda + j] * A[i * lda + j];
         if (off <= 1e-30 * diag || off == 0 || last) break;
-        if (off <= 1e-22 * diag) last = true;
+        if (off <= 1e-14 * diag) last = true;
         for (int64_t p = 0; p < L - 1; ++p)
             for (int64_t q = p + 1; q < L; ++q) {
                 const double apq = A[p * lda + q];

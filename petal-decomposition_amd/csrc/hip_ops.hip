@@ -1323,7 +1323,7 @@ __device__ void wg_jacobi(double* A, int64_t lda, double* V, int64_t ldv, int L,
         __syncthreads();
         // quadratic convergence: once off/diag <= 1e-11 one more sweep brings it to rounding level
         if (!(toff > 1e-30 * tdg) || last) break;
-        if (!(toff > 1e-22 * tdg)) last = true;
+        if (!(toff > 1e-14 * tdg)) last = true;
         for (int rd = 0; rd < rounds; ++rd) {
             for (int k = tid; k < half; k += nt) {
                 int p, q;
@@ -1406,7 +1406,7 @@ __device__ void wg_jacobi_fast(double* A, double* V, int L, double* s_c, double*
         if (tid == 0) g_dbg[0] = sweep;
 #endif
         if (!(toff > 1e-30 * tdg) || last) break;
-        if (!(toff > 1e-17 * tdg)) last = true;  // quadratic convergence: one more sweep reaches rounding level
+        if (!(toff > 1e-14 * tdg)) last = true;  // off/diag <= 1e-7: quadratic convergence, one more sweep reaches rounding level
         for (int rd = 0; rd < rounds; ++rd) {
 #ifdef PETAL_DEBUG_COUNTERS
             long long _t0 = clock64();
