@@ -1369,14 +1369,23 @@ __device__ void wg_jacobi(double* A, int64_t lda, double* V, int64_t ldv, int L,
         }
     }
 }
-// LDS-resident variant for L <= 16 MB (MB <= 8): A and V are L x L with leading dimension L.  Threads form an
-// (L rows) x (8 pair-lanes) grid for the column phase and a (L/2 pairs) x (16 column-lanes) grid for the row phase;
-// every thread first gathers all its operands into registers, then scatters the rotated values, so the LDS round
-// trips of one phase overlap instead of serialising behind possibly-aliasing stores.
+// LDS-resident variant for L <= 16 MB: A and V are L x L with an odd leading dimension.  Two barriers per round:
+//   (1) one thread per pair computes its rotation (c, s) from A[p][p], A[q][q], A[p][q];
+//   (2) A <- J^T A J in ONE pass over 2 x 2 blocks -- the block at rows (p, q) of pair k and columns (p', q') of pair k'
+//       is read once, rotated from both sides in registers and written back in place (no other thread touches it) --
+//       and V <- V J column-wise in the same phase.
+// Every thread gathers all its operands into registers first and scatters afterwards, so the LDS round trips overlap
+// instead of serialising behind possibly-aliasing stores; (c, s) and (p, q) are packed for 16-B / 8-B loads.
 template <int MB>
 __device__ void wg_jacobi_fast(double* A, double* V, int L, double* s_c, double* s_s, int* s_p, int* s_q, double* s_red) {
+    constexpr int MB2 = (MB + 1) / 2;  // 16-wide groups of pairs: half <= 8 MB
     const int LD = L | 1;  // odd leading dimension: column accesses (stride LD doubles) spread over all LDS banks
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    f64x2* s_cs = reinterpret_cast<f64x2*>(s_c);  // [half] (c, s)   (s_s == s_c + half: the two arrays are contiguous)
+    i32x2* s_pq = reinterpret_cast<i32x2*>(s_p);  // [half] (p, q)   (s_q == s_p + half)
+    (void)s_s; (void)s_q;
     for (int e = tid; e < L * LD; e += nt) V[e] = 0.0;
     __syncthreads();
     for (int e = tid; e < L; e += nt) V[e * LD + e] = 1.0;
@@ -1426,33 +1435,63 @@ __device__ void wg_jacobi_fast(double* A, double* V, int L, double* s_c, double*
                         c = 1.0 / sqrt(t * t + 1.0);
                         sn = t * c;
                     }
-                } else { q = p; }  // bye
-                s_p[k] = p; s_q[k] = q; s_c[k] = c; s_s[k] = sn;
+                } else { q = p; }  // bye: identity rotation on a single index
+                s_pq[k] = i32x2{p, q};
+                s_cs[k] = f64x2{c, sn};
             }
             DBG_T(0);
             __syncthreads();
             DBG_T(1);
-            {   // columns: A <- A J, V <- V J
+            {   // A <- J^T A J, one 2 x 2 block per (pair k, pair k')
+                const int k0 = tid & 15;
+                for (int k = tid >> 4; k < half; k += nt >> 4) {
+                    const i32x2 pq = s_pq[k];
+                    const f64x2 cs = s_cs[k];
+                    double* rp = A + pq[0] * LD;
+                    double* rq = A + pq[1] * LD;
+                    double a[MB2], b[MB2], cc[MB2], d[MB2], c2[MB2], s2[MB2];
+                    int p2[MB2], q2[MB2];
+#pragma unroll
+                    for (int m = 0; m < MB2; ++m) {
+                        const int kp = min(k0 + 16 * m, half - 1);
+                        const i32x2 pq2 = s_pq[kp];
+                        const f64x2 cs2 = s_cs[kp];
+                        p2[m] = pq2[0]; q2[m] = (k0 + 16 * m < half) ? pq2[1] : -1;
+                        c2[m] = cs2[0]; s2[m] = cs2[1];
+                        a[m] = rp[pq2[0]]; b[m] = rp[pq2[1]]; cc[m] = rq[pq2[0]]; d[m] = rq[pq2[1]];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MB2; ++m) {
+                        if (q2[m] < 0) continue;
+                        // right rotation (columns p', q'), then left rotation (rows p, q)
+                        const double a1 = c2[m] * a[m] - s2[m] * b[m], b1 = s2[m] * a[m] + c2[m] * b[m];
+                        const double c1 = c2[m] * cc[m] - s2[m] * d[m], d1 = s2[m] * cc[m] + c2[m] * d[m];
+                        rp[p2[m]] = cs[0] * a1 - cs[1] * c1;
+                        rp[q2[m]] = cs[0] * b1 - cs[1] * d1;
+                        rq[p2[m]] = cs[1] * a1 + cs[0] * c1;
+                        rq[q2[m]] = cs[1] * b1 + cs[0] * d1;
+                    }
+                }
+            }
+            {   // V <- V J (columns)
                 const int kk = tid & 7;
                 for (int r = tid >> 3; r < L; r += nt >> 3) {
-                    double ap[MB], aq[MB], vp[MB], vq[MB], cc[MB], sn[MB];
+                    double vp[MB], vq[MB], cc[MB], sn[MB];
                     int pp[MB], qq[MB];
-                    double* ar = A + r * LD;
                     double* vr = V + r * LD;
 #pragma unroll
                     for (int m = 0; m < MB; ++m) {
                         const int k = min(kk + 8 * m, half - 1);
-                        const int p = s_p[k], q = s_q[k];
-                        pp[m] = p;
-                        qq[m] = (kk + 8 * m < half && p != q) ? q : -1;
-                        cc[m] = s_c[k]; sn[m] = s_s[k];
-                        ap[m] = ar[p]; aq[m] = ar[q]; vp[m] = vr[p]; vq[m] = vr[q];
+                        const i32x2 pq = s_pq[k];
+                        const f64x2 cs = s_cs[k];
+                        pp[m] = pq[0];
+                        qq[m] = (kk + 8 * m < half && pq[0] != pq[1]) ? pq[1] : -1;
+                        cc[m] = cs[0]; sn[m] = cs[1];
+                        vp[m] = vr[pq[0]]; vq[m] = vr[pq[1]];
                     }
 #pragma unroll
                     for (int m = 0; m < MB; ++m) {
                         if (qq[m] >= 0) {
-                            ar[pp[m]] = cc[m] * ap[m] - sn[m] * aq[m];
-                            ar[qq[m]] = sn[m] * ap[m] + cc[m] * aq[m];
                             vr[pp[m]] = cc[m] * vp[m] - sn[m] * vq[m];
                             vr[qq[m]] = sn[m] * vp[m] + cc[m] * vq[m];
                         }
@@ -1462,30 +1501,6 @@ __device__ void wg_jacobi_fast(double* A, double* V, int L, double* s_c, double*
             DBG_T(2);
             __syncthreads();
             DBG_T(3);
-            {   // rows: A <- J^T A
-                const int c0 = tid & 15;
-                for (int k = tid >> 4; k < half; k += nt >> 4) {
-                    const int p = s_p[k], q = s_q[k];
-                    if (p == q) continue;
-                    const double c = s_c[k], sn = s_s[k];
-                    double ap[MB], aq[MB];
-                    double* rp = A + p * LD;
-                    double* rq = A + q * LD;
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        const int col = min(c0 + 16 * m, L - 1);
-                        ap[m] = rp[col]; aq[m] = rq[col];
-                    }
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        const int col = c0 + 16 * m;
-                        if (col < L) { rp[col] = c * ap[m] - sn * aq[m]; rq[col] = sn * ap[m] + c * aq[m]; }
-                    }
-                }
-            }
-            DBG_T(4);
-            __syncthreads();
-            DBG_T(5);
         }
     }
 }
