@@ -79,6 +79,32 @@ std::vector<double> flip_signs(petal_ctx& c, int dtype, const void* U, int64_t n
     }
     DBuf g(c.dev, sizeof(double) * L);
     std::vector<double> gm(L), cand(L), win(L);
+    if (dtype == F32) {
+        // ONE all-reduce: |u| of an fp32 value leaves the low 29 mantissa bits of its fp64 image free, so
+        // key = |u| with (2^28 - 1 - row, sign) packed into those bits orders by |u| first, then by LOWEST row:
+        // MAX over the ranks picks exactly the element svd_flip would (pca.rs:826-839).  Rows < 2^28.
+        dev_d2h(c.dev, h.data(), r.p, r.bytes);
+        dev_sync(c.dev);
+        for (int64_t j = 0; j < L; ++j) {
+            uint64_t bits = 0;
+            const double a = h[j] < 0 ? 0.0 : h[j];
+            std::memcpy(&bits, &a, 8);
+            const uint64_t row = h[L + j] < double(1ll << 28) ? uint64_t(h[L + j]) : (uint64_t(1) << 28) - 1;
+            const uint64_t payload = (((uint64_t(1) << 28) - 1 - row) << 1) | (h[2 * L + j] < 0 ? 1u : 0u);
+            bits = (bits & ~((uint64_t(1) << 29) - 1)) | (h[j] < 0 ? 0 : payload);  // empty shard (absmax = -1): key 0 loses
+            std::memcpy(&cand[j], &bits, 8);
+        }
+        dev_h2d(c.dev, g.p, cand.data(), g.bytes);
+        allreduce_f64(c, g.f64(), L, PETAL_MAX);
+        dev_d2h(c.dev, win.data(), g.p, g.bytes);
+        dev_sync(c.dev);
+        for (int64_t j = 0; j < L; ++j) {
+            uint64_t bits = 0;
+            std::memcpy(&bits, &win[j], 8);
+            sg[j] = (bits & 1) ? -1.0 : 1.0;
+        }
+        return sg;
+    }
     dev_d2d(c.dev, g.p, r.p, g.bytes);
     allreduce_f64(c, g.f64(), L, PETAL_MAX);
     dev_d2h(c.dev, h.data(), r.p, r.bytes);
@@ -306,11 +332,12 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         dev_h2d(c.dev, P.p, h.data(), P.bytes);
     }
     DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
-    DBuf tv(c.dev, sizeof(double)), ndead(c.dev, sizeof(int));
+    DBuf ndead(c.dev, sizeof(int));
     c.stats.pass_flops = 2.0 * double(n) * double(d) * double(l_req);
     c.stats.pass_bytes = double(esz) * (double(n) * d + double(n) * l_req + double(d) * l_req);
 
-    DBuf GY(c.dev, sizeof(double) * (LP * LP + dp * LP));  // [ Z^T Z | Xc^T Z ]
+    DBuf GY(c.dev, sizeof(double) * (LP * LP + dp * LP + 1));  // [ Z^T Z | Xc^T Z | sum Xc^2 ]: one all-reduce
+    double* const tvp = GY.f64() + LP * LP + dp * LP;
     DBuf T(c.dev, sizeof(double) * LP * LP), Y(c.dev, sizeof(double) * dp * LP);
     DBuf Bt(c.dev, sizeof(double) * dp * LP), S(c.dev, sizeof(double) * LP * LP), Uh(c.dev, sizeof(double) * LP * LP);
     DBuf lam(c.dev, sizeof(double) * LP), sig(c.dev, sizeof(double) * LP), inv(c.dev, sizeof(double) * LP);
@@ -320,11 +347,11 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // the single-Cholesky fast path and no host round trip; the kernels record the worst pivot breakdown in `ndead`,
     // which is read together with the results.  Only if a breakdown happened is the fit redone with robust = true.
     auto pipeline = [&](bool robust) {
-    dev_memset(c.dev, tv.p, 0, sizeof(double));
+    dev_memset(c.dev, tvp, 0, sizeof(double));
     dev_memset(c.dev, ndead.p, 0, sizeof(int));
     // Z = Xc . Omega (pca.rs:707), fused with total_variance = sum Xc^2 (pca.rs:533)
     dev_set_tag(c.dev, TAG_XP);
-    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv.f64());
+    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tvp);
     dev_set_tag(c.dev, TAG_NONE);
 
     double* G = GY.f64();
@@ -369,8 +396,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     dev_set_tag(c.dev, TAG_ATB);
     op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z1.p, LP, LP, nullptr, n, Yp, LP);  // B^T = Xc^T Q (pca.rs:681)
     dev_set_tag(c.dev, TAG_NONE);
-    allreduce_f64(c, GY.f64(), LP * LP + dp * LP, PETAL_SUM);
-    allreduce_f64(c, tv.f64(), 1, PETAL_SUM);
+    allreduce_f64(c, GY.f64(), LP * LP + dp * LP + 1, PETAL_SUM);
     op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);  // T2
     op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Bt.f64(), LP);
 
@@ -406,7 +432,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     dev_d2h(c.dev, hV.data(), V.p, V.bytes);
     dev_d2h(c.dev, hs.data(), sig.p, sig.bytes);
     dev_d2h(c.dev, hmu.data(), mu64.p, mu64.bytes);
-    dev_d2h(c.dev, &htv, tv.p, sizeof(double));
+    dev_d2h(c.dev, &htv, tvp, sizeof(double));
     dev_sync(c.dev);
     for (int64_t j = 0; j < k; ++j) {
         for (int64_t i = 0; i < d; ++i) put_elem(components, dt, j * d + i, sg[j] * hV[size_t(i) * LP + j]);

@@ -498,11 +498,9 @@ __global__ __launch_bounds__(256, 2) void k_xp_mfma(const float* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1, "fat tile" form: ONE wave per SIMD with the whole register file.  Every wave owns a contiguous, balanced range
-// of 16-row tiles (6 or 7 of them at 100000 rows over 1024 SIMDs) and walks it as register tiles of 8 / 4 / 2 / 1
-// row-tiles x NT column tiles; each register tile is one pass over K with a three-stage register pipeline.  Against
-// the 64-row / two-waves-per-SIMD form above this (a) balances the SIMDs to within one 16-row tile instead of one
-// 64-row tile, (b) halves the re-reads of the packed P per row, (c) leaves nothing to arbitrate on the MFMA pipe.
+// One register tile of K1 as a device function (used by the persistent form below): RT row-tiles x NT column tiles,
+// one pass over K with a two- or three-stage register pipeline, 16-B epilogue stores.
+// (A one-wave-per-SIMD form with 128-row register tiles built on it was measured slower and removed.)
 template <int RT, int NT, bool CENTER, bool SUMSQ, int STAGES = 3>
 __device__ __forceinline__ void xp_tile(const float* __restrict__ X, int64_t n, int K, int64_t ldx, const float* __restrict__ mu,
                                         const f32x4* __restrict__ pb, int NTtot, int nt0, int N, const float* __restrict__ bias,
@@ -649,32 +647,6 @@ __global__ __launch_bounds__(512, 2) void k_xp_pers(const float* __restrict__ X,
         double sred = (double)ssq;
         for (int off = 32; off > 0; off >>= 1) sred += __shfl_down(sred, off, 64);
         if (lane == 0) ss_part[(int64_t)blockIdx.x * 8 + wave] = sred;
-    }
-}
-
-template <int NT, int RTMAX, bool CENTER, bool SUMSQ>
-__global__ __launch_bounds__(256, 1) void k_xp_fat(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
-                                                   const float* __restrict__ mu, const float* __restrict__ Ppk, int NTtot,
-                                                   int nt0, int N, const float* __restrict__ bias, float* __restrict__ Z,
-                                                   int64_t ldz, double* __restrict__ ss_part, int64_t ntiles16, int nwaves) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const f32x4* pb = reinterpret_cast<const f32x4*>(Ppk) + (int64_t)nt0 * 64 + lane;
-    float ssq = 0.f;
-    if (wid < nwaves) {
-        int64_t t = wid * ntiles16 / nwaves;
-        const int64_t t1 = (wid + 1) * ntiles16 / nwaves;
-#define XP_TILE(R) xp_tile<R, NT, CENTER, SUMSQ>(X, n, K, ldx, mu, pb, NTtot, nt0, N, bias, Z, ldz, 16 * t, lane, ssq)
-        if constexpr (RTMAX >= 8) { for (; t1 - t >= 8; t += 8) XP_TILE(8); }
-        for (; t1 - t >= 4; t += 4) XP_TILE(4);
-        for (; t1 - t >= 2; t += 2) XP_TILE(2);
-        for (; t1 - t >= 1; t += 1) XP_TILE(1);
-#undef XP_TILE
-    }
-    if (SUMSQ) {
-        double sred = (double)ssq;
-        for (int off = 32; off > 0; off >>= 1) sred += __shfl_down(sred, off, 64);
-        if (lane == 0) ss_part[wid] = sred;
     }
 }
 
@@ -1807,7 +1779,6 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
         hipLaunchKernelGGL(k_pack_p, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk, NTtot);
         launch_check();
     }
-    static const bool use_fat = [] { const char* e = getenv("PETAL_K1_FAT"); return e && e[0] == '1'; }();
     static const bool use_classic = [] { const char* e = getenv("PETAL_K1_CLASSIC"); return e && e[0] == '1'; }();
     static const bool force_pers = [] { const char* e = getenv("PETAL_K1_PERS"); return e && e[0] == '1'; }();
     static int num_cu = 0;
@@ -1816,7 +1787,7 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
     // a whole 64-row tile apart (100000 x 512: 74 TFLOP/s) and the balanced persistent form wins (84); with many tiles
     // per slot the hardware dispatcher balances the grid form dynamically and it is the faster one (1e6 x 512: 95 vs 76).
     const bool small = (n + 63) / 64 < (int64_t)num_cu * 8 * 2;
-    if (!use_fat && !use_classic && (small || force_pers)) {
+    if (!use_classic && (small || force_pers)) {
         // persistent form: one 512-thread workgroup per CU, balanced ranges of 16-row tiles, column panels of <= 5 tiles
         const int64_t ntiles16 = (n + 15) / 16;
         const int blocks = (int)std::min<int64_t>(num_cu, (ntiles16 + 7) / 8);
@@ -1857,17 +1828,8 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
         dev_free(d, Ppk);
         return;
     }
-    if (!use_fat) {
+    {
         // classic form: 64-row wave tiles, two waves per SIMD, column panels of <= 5 tiles
-        static const int rt_env = [] { const char* e = getenv("PETAL_K1_RT"); return e ? atoi(e) : 4; }();
-        if (rt_env == 2 && NTtot == 5) {  // experiment: 32-row wave tiles
-            const int blocks2 = cdiv(n, 128);
-            TagScope ts2(d);
-            launch_xp<2, 5>(d, (const float*)X, n, (int)K, ldx, (const float*)mu, Ppk, NTtot, 0, (int)N, (const float*)bias, (float*)Z, ldz, nullptr, blocks2);
-            ts2.stop();
-            dev_free(d, Ppk);
-            return;
-        }
         const int blocks = cdiv(n, 256);
         double* ssp = sumsq ? (double*)dev_alloc(d, sizeof(double) * blocks * 4) : nullptr;
         TagScope ts(d);
@@ -1894,50 +1856,6 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
         dev_free(d, Ppk);
         return;
     }
-    // fat-tile form (PETAL_K1_FAT=1; measured slower so far): 1024 waves (one per SIMD), balanced ranges of 16-row tiles
-    const int64_t ntiles16 = (n + 15) / 16;
-    const int nwaves = (int)std::min<int64_t>(1024, ntiles16);
-    const int blocks = cdiv(nwaves, 4);
-    double* ssp = sumsq ? (double*)dev_alloc(d, sizeof(double) * blocks * 4) : nullptr;
-    TagScope ts(d);
-    for (int nt0 = 0; nt0 < NTtot;) {
-        const int rem = NTtot - nt0;
-        const int w = rem >= 9 ? 9 : rem;
-        double* sp = nt0 == 0 ? ssp : nullptr;
-        const float* Xf = (const float*)X; const float* muf = (const float*)mu; const float* bf = (const float*)bias; float* Zf = (float*)Z;
-        const bool center = muf != nullptr, ss = sp != nullptr;
-#define XPF_ARGS Xf, n, (int)K, ldx, muf, Ppk, NTtot, nt0, (int)N, bf, Zf, ldz, sp, ntiles16, nwaves
-#define XPF_LAUNCH(NTv, RTv)                                                                                              \
-        do { /* the (rare, once per fit) sum-of-squares variants use half the register tile to stay out of scratch */   \
-            constexpr int RTs = RTv / 2;                                                                                  \
-            if (center && ss) hipLaunchKernelGGL((k_xp_fat<NTv, RTs, true, true>), dim3(blocks), dim3(256), 0, d->stream, XPF_ARGS);   \
-            else if (center) hipLaunchKernelGGL((k_xp_fat<NTv, RTv, true, false>), dim3(blocks), dim3(256), 0, d->stream, XPF_ARGS); \
-            else if (ss) hipLaunchKernelGGL((k_xp_fat<NTv, RTs, false, true>), dim3(blocks), dim3(256), 0, d->stream, XPF_ARGS);     \
-            else hipLaunchKernelGGL((k_xp_fat<NTv, RTv, false, false>), dim3(blocks), dim3(256), 0, d->stream, XPF_ARGS);            \
-        } while (0)
-        switch (w) {
-            case 9: XPF_LAUNCH(9, 4); break;
-            case 8: XPF_LAUNCH(8, 4); break;
-            case 7: XPF_LAUNCH(7, 4); break;
-            case 6: XPF_LAUNCH(6, 4); break;
-            case 5: XPF_LAUNCH(5, 8); break;
-            case 4: XPF_LAUNCH(4, 8); break;
-            case 3: XPF_LAUNCH(3, 8); break;
-            case 2: XPF_LAUNCH(2, 8); break;
-            default: XPF_LAUNCH(1, 8); break;
-        }
-#undef XPF_LAUNCH
-#undef XPF_ARGS
-        launch_check();
-        nt0 += w;
-    }
-    ts.stop();
-    if (sumsq) {
-        hipLaunchKernelGGL(k_add_scalar_parts, dim3(1), dim3(256), 0, d->stream, ssp, (int64_t)blocks * 4, sumsq);
-        launch_check();
-        dev_free(d, ssp);
-    }
-    dev_free(d, Ppk);
 }
 
 template <int NT>
