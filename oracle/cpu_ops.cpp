@@ -143,7 +143,8 @@ void op_dgemm(Dev*, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double al
             C[i * ldc + j] = alpha * s + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
         }
 }
-void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead) {
+void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz) {
+    if (Lz < L) Lz = L;
     std::vector<double> R(size_t(L) * L, 0.0);
     std::vector<char> dead(L, 0);
     for (int64_t j = 0; j < L; ++j) {  // row-by-row upper Cholesky, G = R^T R
@@ -161,8 +162,8 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
     }
     if (ndead) { int c = 0; for (int64_t j = 0; j < L; ++j) c += dead[j]; if (c > *ndead) *ndead = c; }
     // T = R^{-1} by back substitution per column; dead columns -> 0 (and are skipped as rows)
-    for (int64_t i = 0; i < L; ++i)
-        for (int64_t j = 0; j < L; ++j) T[i * ldt + j] = 0;
+    for (int64_t i = 0; i < Lz; ++i)
+        for (int64_t j = 0; j < Lz; ++j) T[i * ldt + j] = 0;
     for (int64_t j = 0; j < L; ++j) {
         if (dead[j]) continue;
         T[j * ldt + j] = 1.0 / R[j * L + j];

@@ -128,10 +128,10 @@ std::vector<double> flip_signs(petal_ctx& c, int dtype, const void* U, int64_t n
 // Y (M x LP, f64) <- orthonormal basis of range(Y) by Cholesky-QR in fp64 (stands where the reference re-bases
 // the small d x l iterate with pivoted LU, pca.rs:712-713).  One round leaves ||Y^T Y - I|| ~ 1e-16 cond(Y)^2,
 // far below the fp32 rounding the basis undergoes when it is packed for the MFMA kernel.
-void orthonormalize_small(petal_ctx& c, DBuf& Y, int64_t M, int64_t LP, double tol) {
+void orthonormalize_small(petal_ctx& c, DBuf& Y, int64_t M, int64_t L, int64_t LP, double tol) {
     DBuf G(c.dev, sizeof(double) * LP * LP), T(c.dev, sizeof(double) * LP * LP), Y2(c.dev, Y.bytes);
     op_dgemm(c.dev, true, false, LP, LP, M, 1.0, Y.f64(), LP, Y.f64(), LP, 0.0, G.f64(), LP);
-    op_chol_inv(c.dev, G.f64(), LP, LP, T.f64(), LP, tol);
+    op_chol_inv(c.dev, G.f64(), L, LP, T.f64(), LP, tol, nullptr, LP);
     op_dgemm(c.dev, false, false, M, LP, LP, 1.0, Y.f64(), LP, T.f64(), LP, 0.0, Y2.f64(), LP);
     std::swap(Y, Y2);
 }
@@ -143,7 +143,7 @@ void orthonormalize_small(petal_ctx& c, DBuf& Y, int64_t M, int64_t LP, double t
 // true is returned; otherwise the caller runs the full solver.  Convergence: ||C v - w v|| <= 1e-12 w_0 for every pair.
 bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc, double* V, double* w) {
     const int64_t p = std::min<int64_t>(round_up(nc + 16, 16), dp);
-    if (nc <= 0 || p >= d || d <= 88) return false;
+    if (nc <= 0 || p >= d || d <= 88 || p > 200) return false;  // p > 200: beyond the one-workgroup Cholesky kernel
     Dev* dv = c.dev;
     DBuf Q(dv, sizeof(double) * dp * p), Y(dv, sizeof(double) * dp * p), G(dv, sizeof(double) * p * p), T(dv, sizeof(double) * p * p);
     DBuf H(dv, sizeof(double) * p * p), S(dv, sizeof(double) * p * p), th(dv, sizeof(double) * p), R(dv, sizeof(double) * dp * p);
@@ -315,6 +315,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         return;
     }
     const int64_t LP = round_up(L, 16);
+    if (L > 200)  // the fp64 re-basing kernels keep the l x l triangular factor in one workgroup's LDS
+        invalid_input("n_components + n_oversample must be at most 200 on the device path");
     DevMat X = ingest(c, x);
     const int64_t n = X.n, dp = X.dp;
     const size_t esz = dtype_size(dt);
@@ -370,16 +372,16 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
             // fast path: one fp64 Cholesky of Yp^T Yp, valid while every pivot stays positive (cond(Yp) <~ 3e7: errors
             // of a few per cent in the weakest pivots merely leave cond(P) ~ 1.x); breakdowns are recorded in ndead
             op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Yp, LP, Yp, LP, 0.0, G, LP);
-            op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, 1e-15, ndead.as<int>());
+            op_chol_inv(c.dev, G, L, LP, T.f64(), LP, 1e-15, ndead.as<int>(), LP);
             op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
         } else {
             // ill-conditioned iterate: precondition with the tall side first.  Z = Xc P gives Z^T Z = P^T (Xc^T Z) =
             // P^T Yp without a pass over Z (op_chol_inv reads the upper triangle only); T = chol(Z^T Z)^-1 is applied on
             // the small side, Xc^T (Z T) = Yp T, and the now moderately conditioned Yp T gets its own Cholesky-QR.
             op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Pcur, LP, Yp, LP, 0.0, G, LP);
-            op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);
+            op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);
             op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
-            orthonormalize_small(c, Y, dp, LP, 1e-13);
+            orthonormalize_small(c, Y, dp, L, LP, 1e-13);
         }
         Pcur = Y.f64();
         dev_set_tag(c.dev, TAG_XP);
@@ -390,14 +392,14 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // thin QR of Z (pca.rs:716) as Cholesky-QR2: Z1 = Z T1, Q = Z1 T2 with T2 folded into the small side
     op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP);
     allreduce_f64(c, G, LP * LP, PETAL_SUM);
-    op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);
+    op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);
     op_gemm_xp(c.dev, dt, Z.p, n, LP, LP, nullptr, T.f64(), LP, LP, nullptr, Z1.p, LP, nullptr);
     op_gemm_atb(c.dev, dt, Z1.p, LP, LP, nullptr, Z1.p, LP, LP, nullptr, n, G, LP);
     dev_set_tag(c.dev, TAG_ATB);
     op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z1.p, LP, LP, nullptr, n, Yp, LP);  // B^T = Xc^T Q (pca.rs:681)
     dev_set_tag(c.dev, TAG_NONE);
     allreduce_f64(c, GY.f64(), LP * LP + dp * LP + 1, PETAL_SUM);
-    op_chol_inv(c.dev, G, LP, LP, T.f64(), LP, tol_drop);  // T2
+    op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);  // T2
     op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Bt.f64(), LP);
 
     // economy SVD of B (l x d) (svddc, pca.rs:682): eigen-decomposition of B B^T in fp64
@@ -423,7 +425,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         int hdead = 0;
         dev_d2h(c.dev, &hdead, ndead.p, sizeof(int));
         dev_sync(c.dev);
-        if (attempt == 1 || hdead <= LP - L) break;
+        if (attempt == 1 || hdead == 0) break;
     }
 
     // results (pca.rs:543-547)

@@ -1113,22 +1113,30 @@ __global__ __launch_bounds__(256) void k_dgemm(bool ta, bool tb, int64_t M, int6
 //   inverse:       blocked (16 x 16): diagonal blocks by substitution, then block super-diagonals
 //                  T_IJ = -T_II (sum_K R_IK T_KJ): 1 + 3 (L/16 - 1) barriers.
 constexpr int CHOL_THREADS = 512;
+constexpr int CHOL_MAXL = 200;
 __device__ __forceinline__ int pk(int r, int c, int L) { return r * L - (r * (r - 1)) / 2 + (c - r); }
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T,
-                                                           int64_t ldt, double rel_tol, int t_in_lds, int* __restrict__ ndead_out) {
+                                                           int64_t ldt, double rel_tol, int t_mode, int* __restrict__ ndead_out, int Lz) {
     extern __shared__ __attribute__((aligned(16))) double sm_chol[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int np = L * (L + 1) / 2;
     double* Rw = sm_chol;
     double* gd = Rw + np;
     int* dead = reinterpret_cast<int*>(gd + L);
-    double* Tl = t_in_lds ? (gd + L + (L + 1) / 2) : T;
-    const int64_t tl = t_in_lds ? L : ldt;
+    // T storage: 0 = the global output itself, 1 = full square in LDS, 2 = packed upper triangle in LDS (only entries
+    // on or above the diagonal are ever touched below)
+    double* Tl = t_mode ? (gd + L + (L + 1) / 2) : T;
+    const int64_t tl = t_mode ? L : ldt;
+#define TI(r, c) (t_mode == 2 ? (int64_t)pk((r), (c), L) : (int64_t)(r) * tl + (c))
     for (int e = tid; e < L * L; e += nt) {
         const int r = e / L, c = e % L;
         if (c >= r) Rw[pk(r, c, L)] = G[(int64_t)r * ldg + c];
         if (c == r) gd[r] = G[(int64_t)r * ldg + c];
-        Tl[(int64_t)r * tl + c] = 0.0;
+        if (c >= r || t_mode != 2) Tl[TI(r, c)] = 0.0;
+    }
+    for (int e = tid; e < Lz * Lz; e += nt) {  // zero padding of the output beyond the factored block
+        const int r = e / Lz, c = e % Lz;
+        if (r >= L || c >= L) T[(int64_t)r * ldt + c] = 0.0;
     }
     __syncthreads();
 #ifdef PETAL_DEBUG_COUNTERS
@@ -1211,12 +1219,12 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
     for (int t = tid; t < nb * 16; t += nt) {  // diagonal blocks: one thread per column, substitution inside the block
         const int bI = t / 16, j = t;
         if (j < L && !dead[j]) {
-            Tl[(int64_t)j * tl + j] = 1.0 / Rw[pk(j, j, L)];
+            Tl[TI(j, j)] = 1.0 / Rw[pk(j, j, L)];
             for (int r = j - 1; r >= 16 * bI; --r) {
                 if (dead[r]) continue;
                 double sacc = 0;
-                for (int k = r + 1; k <= j; ++k) sacc += Rw[pk(r, k, L)] * Tl[(int64_t)k * tl + j];
-                Tl[(int64_t)r * tl + j] = -sacc / Rw[pk(r, r, L)];
+                for (int k = r + 1; k <= j; ++k) sacc += Rw[pk(r, k, L)] * Tl[TI(k, j)];
+                Tl[TI(r, j)] = -sacc / Rw[pk(r, r, L)];
             }
         }
     }
@@ -1228,9 +1236,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
             const int bI = e / 256, r = 16 * bI + (e % 256) / 16, c = 16 * (bI + dl) + (e % 16);
             if (r < L && c < L) {
                 double w = 0;
-                const int k1 = min(L, 16 * (bI + dl + 1));
-                for (int k = 16 * (bI + 1); k < k1; ++k) w += Rw[pk(r, k, L)] * Tl[(int64_t)k * tl + c];
-                Tl[(int64_t)r * tl + c] = w;
+                const int k1 = min(c + 1, 16 * (bI + dl + 1));  // T is upper triangular: T[k][c] = 0 for k > c
+                for (int k = 16 * (bI + 1); k < k1; ++k) w += Rw[pk(r, k, L)] * Tl[TI(k, c)];
+                Tl[TI(r, c)] = w;
             }
         }
         __syncthreads();
@@ -1245,7 +1253,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
                 if (r < L && c < L) {
                     double t2 = 0;
                     const int m1 = min(L, 16 * (bI + 1));
-                    for (int m = r; m < m1; ++m) t2 += Tl[(int64_t)r * tl + m] * Tl[(int64_t)m * tl + c];
+                    for (int m = r; m < m1; ++m) t2 += Tl[TI(r, m)] * Tl[TI(m, c)];
                     res[it] = -t2;
                 }
             }
@@ -1256,14 +1264,18 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
             const int e = tid + it * nt;
             if (e < nel) {
                 const int bI = e / 256, r = 16 * bI + (e % 256) / 16, c = 16 * (bI + dl) + (e % 16);
-                if (r < L && c < L) Tl[(int64_t)r * tl + c] = res[it];
+                if (r < L && c < L) Tl[TI(r, c)] = res[it];
             }
         }
         __syncthreads();
     }
     DBG_T(7);
-    if (t_in_lds)
-        for (int e = tid; e < L * L; e += nt) T[(int64_t)(e / L) * ldt + (e % L)] = Tl[e];
+    if (t_mode)
+        for (int e = tid; e < L * L; e += nt) {
+            const int r = e / L, c = e % L;
+            T[(int64_t)r * ldt + c] = (t_mode == 2) ? (c >= r ? Tl[pk(r, c, L)] : 0.0) : Tl[e];
+        }
+#undef TI
 }
 
 // ---- workgroup-wide cyclic Jacobi eigen-solver (fp64) ----------------------------------------------
@@ -1533,6 +1545,181 @@ __global__ __launch_bounds__(MB > 0 ? 768 : 1024) void k_eigh(double* A, int L, 
     }
     wg_jacobi_any<MB>(Aw, la, Vw, la, L, ws.c, ws.s, ws.p, ws.q, ws.red);
     wg_sort_eig(Aw, la, Vw, la, L, V, ldv, w, ws.rank);
+}
+
+// ---- split eigen-solver: rotations on A in one workgroup, eigenvector accumulation spread over the chip --------------
+// The Jacobi rotations are decided by A alone; V <- V J only consumes (c, s, p, q).  k_jacobi_a keeps A in LDS (so L up
+// to 138 fits: no V beside it), runs the round-robin sweeps with the 2 x 2-block one-pass update and LOGS every round's
+// rotations to global memory; k_apply_rot then replays the log on the rows of V = I, one row per wave (rows are
+// independent, so the replay runs on L waves in parallel instead of inside the single Jacobi workgroup), and scatters
+// the columns into descending-eigenvalue order.
+typedef double jf64x2 __attribute__((ext_vector_type(2)));
+typedef int ji32x2 __attribute__((ext_vector_type(2)));
+constexpr int JACA_MAX_SWEEPS = 16;
+__host__ __device__ inline size_t jaca_lds_bytes(int L) {
+    const int half = ((L + 1) & ~1) / 2;
+    return sizeof(double) * ((size_t)L * (L | 1) + 2 * (size_t)half + 64) + sizeof(int) * 2 * (size_t)half;
+}
+template <int MB2>
+__global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ain, int L, int64_t lda, jf64x2* __restrict__ log_cs,
+                                                   ji32x2* __restrict__ log_pq, int* __restrict__ nrounds_out,
+                                                   double* __restrict__ w, int* __restrict__ rank_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm_ja[];
+    const int LD = L | 1;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    const int Le = (L + 1) & ~1, half = Le / 2, rounds = Le - 1;
+    jf64x2* s_cs = reinterpret_cast<jf64x2*>(sm_ja);
+    double* s_red = sm_ja + 2 * half;
+    double* A = s_red + 64;
+    ji32x2* s_pq = reinterpret_cast<ji32x2*>(A + (size_t)L * LD);
+    {
+        int r = tid / L, c = tid - r * L;
+        const int dr = nt / L, dc = nt - dr * L;
+        for (int e = tid; e < L * L; e += nt) {
+            A[r * LD + c] = Ain[(int64_t)r * lda + c];
+            r += dr; c += dc;
+            if (c >= L) { c -= L; ++r; }
+        }
+    }
+    __syncthreads();
+    int R = 0;  // rounds logged so far
+    bool last = false;
+    for (int sweep = 0; sweep < JACA_MAX_SWEEPS && L >= 2; ++sweep) {
+        double tot = 0, dg = 0;  // off-diagonal and diagonal energy, accumulated separately (no cancellation)
+        {
+            int r = tid / L, c = tid - r * L;
+            const int dr = nt / L, dc = nt - dr * L;
+            for (int e = tid; e < L * L; e += nt) {
+                const double v = A[r * LD + c];
+                if (r == c) dg += v * v; else tot += v * v;
+                r += dr; c += dc;
+                if (c >= L) { c -= L; ++r; }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) { tot += __shfl_down(tot, off, 64); dg += __shfl_down(dg, off, 64); }
+        if (lane == 0) { s_red[wv] = tot; s_red[32 + wv] = dg; }
+        __syncthreads();
+        double toff = 0, tdg = 0;
+        for (int x = 0; x < nw; ++x) { toff += s_red[x]; tdg += s_red[32 + x]; }
+        __syncthreads();
+        if (!(toff > 1e-30 * tdg) || last) break;
+        if (!(toff > 1e-14 * tdg)) last = true;  // quadratic convergence: one more sweep reaches rounding level
+        for (int rd = 0; rd < rounds; ++rd, ++R) {
+            if (tid < half) {
+                const int k = tid;
+                int p, q;
+                if (k == 0) { p = Le - 1; q = rd; }
+                else { p = rd + k; if (p >= Le - 1) p -= Le - 1; q = rd - k; if (q < 0) q += Le - 1; }
+                if (p > q) { const int t = p; p = q; q = t; }
+                double c = 1.0, sn = 0.0;
+                if (q < L) {
+                    const double apq = A[p * LD + q];
+                    if (apq != 0.0) {
+                        const double theta = (A[q * LD + q] - A[p * LD + p]) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(t * t + 1.0);
+                        sn = t * c;
+                    }
+                } else { q = p; }  // bye: identity rotation on a single index
+                s_pq[k] = ji32x2{p, q};
+                s_cs[k] = jf64x2{c, sn};
+                log_pq[(size_t)R * half + k] = ji32x2{p, q};
+                log_cs[(size_t)R * half + k] = jf64x2{c, sn};
+            }
+            __syncthreads();
+            {   // A <- J^T A J, one 2 x 2 block per (pair k, pair k'), gathered into registers before the scatter
+                const int k0 = tid & 15;
+                for (int k = tid >> 4; k < half; k += nt >> 4) {
+                    const ji32x2 pq = s_pq[k];
+                    const jf64x2 cs = s_cs[k];
+                    double* rp = A + pq[0] * LD;
+                    double* rq = A + pq[1] * LD;
+                    double a[MB2], b[MB2], cc[MB2], d[MB2], c2[MB2], s2[MB2];
+                    int p2[MB2], q2[MB2];
+#pragma unroll
+                    for (int m = 0; m < MB2; ++m) {
+                        const int kp = min(k0 + 16 * m, half - 1);
+                        const ji32x2 pq2 = s_pq[kp];
+                        const jf64x2 cs2 = s_cs[kp];
+                        p2[m] = pq2[0]; q2[m] = (k0 + 16 * m < half) ? pq2[1] : -1;
+                        c2[m] = cs2[0]; s2[m] = cs2[1];
+                        a[m] = rp[pq2[0]]; b[m] = rp[pq2[1]]; cc[m] = rq[pq2[0]]; d[m] = rq[pq2[1]];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MB2; ++m) {
+                        if (q2[m] < 0) continue;
+                        const double a1 = c2[m] * a[m] - s2[m] * b[m], b1 = s2[m] * a[m] + c2[m] * b[m];
+                        const double c1 = c2[m] * cc[m] - s2[m] * d[m], d1 = s2[m] * cc[m] + c2[m] * d[m];
+                        rp[p2[m]] = cs[0] * a1 - cs[1] * c1;
+                        rp[q2[m]] = cs[0] * b1 - cs[1] * d1;
+                        rq[p2[m]] = cs[1] * a1 + cs[0] * c1;
+                        rq[q2[m]] = cs[1] * b1 + cs[0] * d1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) *nrounds_out = R;
+    for (int j = tid; j < L; j += nt) {  // descending order: rank[j] = position of eigenvalue j
+        const double wj = A[j * LD + j];
+        int rank = 0;
+        for (int k = 0; k < L; ++k) {
+            const double wk = A[k * LD + k];
+            rank += (wk > wj || (wk == wj && k < j)) ? 1 : 0;
+        }
+        rank_out[j] = rank;
+        w[rank] = wj;
+    }
+}
+// replay of the rotation log on V = I: wave <-> row r of V (kept in LDS), lanes <-> the disjoint pairs of a round.
+// The parameters of JR rounds are fetched ahead (independent loads) so the global-memory latency is paid once per batch.
+constexpr int JR_WAVES = 4, JR_BATCH = 8;
+template <int HP>  // pairs per lane: half <= 64 HP
+__global__ __launch_bounds__(64 * JR_WAVES) void k_apply_rot(const jf64x2* __restrict__ log_cs, const ji32x2* __restrict__ log_pq,
+                                                             const int* __restrict__ nrounds, const int* __restrict__ rank, int L,
+                                                             double* __restrict__ V, int64_t ldv) {
+    extern __shared__ __attribute__((aligned(16))) double sm_jr[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int Le = (L + 1) & ~1, half = Le / 2;
+    const int r = blockIdx.x * JR_WAVES + wv;
+    double* row = sm_jr + (size_t)wv * Le;
+    for (int j = lane; j < Le; j += 64) row[j] = (j == r) ? 1.0 : 0.0;
+    const int nR = *nrounds;
+    for (int R0 = 0; R0 < nR; R0 += JR_BATCH) {
+        jf64x2 cs[JR_BATCH][HP];
+        ji32x2 pq[JR_BATCH][HP];
+#pragma unroll
+        for (int u = 0; u < JR_BATCH; ++u) {
+            const int Ru = min(R0 + u, nR - 1);
+#pragma unroll
+            for (int h = 0; h < HP; ++h) {
+                const int k = min(lane + 64 * h, half - 1);
+                cs[u][h] = log_cs[(size_t)Ru * half + k];
+                pq[u][h] = log_pq[(size_t)Ru * half + k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < JR_BATCH; ++u) {
+            if (R0 + u < nR) {
+                double vp[HP], vq[HP];
+#pragma unroll
+                for (int h = 0; h < HP; ++h) { vp[h] = row[pq[u][h][0]]; vq[h] = row[pq[u][h][1]]; }
+#pragma unroll
+                for (int h = 0; h < HP; ++h) {
+                    if (lane + 64 * h < half && pq[u][h][0] != pq[u][h][1]) {
+                        row[pq[u][h][0]] = cs[u][h][0] * vp[h] - cs[u][h][1] * vq[h];
+                        row[pq[u][h][1]] = cs[u][h][1] * vp[h] + cs[u][h][0] * vq[h];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    if (r < L)
+        for (int j = lane; j < L; j += 64) V[(int64_t)r * ldv + rank[j]] = row[j];
 }
 
 // Wout = symmetric_decorrelation(Win) (ica.rs:363-381).  S (= W W^T, then destroyed) and the eigenvector accumulator
@@ -2071,33 +2258,63 @@ void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double 
                        beta, C, ldc);
     launch_check();
 }
-void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead) {
+void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz) {
     if (L == 0) return;
-    if (L > 144) throw std::runtime_error("chol_inv: matrix too large for the one-workgroup LDS kernel (L <= 144)");
+    if (L > CHOL_MAXL) throw std::runtime_error("chol_inv: matrix too large for the one-workgroup LDS kernel (L <= 200)");
+    if (Lz < L) Lz = L;
     const size_t base = sizeof(double) * (L * (L + 1) / 2 + L + (L + 1) / 2);
-    const size_t with_t = base + sizeof(double) * L * L;
-    const int t_in_lds = with_t <= 150 * 1024 ? 1 : 0;
-    const size_t lds = t_in_lds ? with_t : base;
+    const size_t full = base + sizeof(double) * L * L, packed = base + sizeof(double) * (L * (L + 1) / 2);
+    const size_t cap = 160 * 1024 - 256;
+    const int t_mode = full <= cap ? 1 : (packed <= cap ? 2 : 0);
+    const size_t lds = t_mode == 1 ? full : (t_mode == 2 ? packed : base);
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_in_lds, ndead);
+    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_mode, ndead, (int)Lz);
     launch_check();
 }
 void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w) {
     if (L == 0) return;
     if (L > EIG_MAXL) throw std::runtime_error("eigh: matrix too large for the one-workgroup Jacobi solver");
-    const int mb = L <= 88 ? (int)((L + 15) / 16) : 0;
-    const int threads = mb ? (int)std::min<int64_t>(1024, std::max<int64_t>(64, (8 * L + 63) / 64 * 64)) : 1024;
+    if (jaca_lds_bytes((int)L) <= 160 * 1024 - 256) {
+        // split solver: A in LDS + rotation log, eigenvectors replayed on L waves
+        const int Le = (int)((L + 1) & ~1), half = Le / 2, rounds = Le - 1;
+        const size_t nlog = (size_t)JACA_MAX_SWEEPS * rounds * half;
+        char* buf = (char*)dev_alloc(d, nlog * 24 + 16 + sizeof(int) * (L + 4));
+        jf64x2* log_cs = reinterpret_cast<jf64x2*>(buf);
+        ji32x2* log_pq = reinterpret_cast<ji32x2*>(buf + nlog * 16);
+        int* nrounds = reinterpret_cast<int*>(buf + nlog * 24);
+        int* rank = nrounds + 4;
+        const int mb2 = (half + 15) / 16;
+        const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, (16 * half + 63) / 64 * 64));
+        const size_t lds = jaca_lds_bytes((int)L);
+#define JACA_CASE(M)                                                                                                     \
+    case M: {                                                                                                            \
+        static bool once = false;                                                                                        \
+        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_jacobi_a<M>)); once = true; }                           \
+        hipLaunchKernelGGL(k_jacobi_a<M>, dim3(1), dim3(threads), lds, d->stream, A, (int)L, lda, log_cs, log_pq, nrounds, w, rank); \
+    } break;
+        switch (mb2) { JACA_CASE(1) JACA_CASE(2) JACA_CASE(3) JACA_CASE(4) default: JACA_CASE(5) }
+#undef JACA_CASE
+        launch_check();
+        const int hp = (half + 63) / 64;
+        const dim3 grid((unsigned)cdiv(L, JR_WAVES));
+        const size_t lds2 = sizeof(double) * JR_WAVES * Le;
+        if (hp <= 1) hipLaunchKernelGGL(k_apply_rot<1>, grid, dim3(64 * JR_WAVES), lds2, d->stream, log_cs, log_pq, nrounds, rank, (int)L, V, ldv);
+        else hipLaunchKernelGGL(k_apply_rot<2>, grid, dim3(64 * JR_WAVES), lds2, d->stream, log_cs, log_pq, nrounds, rank, (int)L, V, ldv);
+        launch_check();
+        dev_free(d, buf);
+        return;
+    }
     double* Vtmp = (double*)dev_alloc(d, sizeof(double) * L * L);
-    const size_t lds = sizeof(double) * (jac_ws_doubles((int)L, threads) + (mb ? 2 * L * (L | 1) : 0));
-    MB_DISPATCH(mb, {
+    const size_t lds = sizeof(double) * jac_ws_doubles((int)L, 1024);
+    {
         static bool once = false;
-        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_eigh<MBv>)); once = true; }
-        hipLaunchKernelGGL(k_eigh<MBv>, dim3(1), dim3(threads), lds, d->stream, A, (int)L, lda, Vtmp, V, ldv, w);
-    });
+        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_eigh<0>)); once = true; }
+        hipLaunchKernelGGL(k_eigh<0>, dim3(1), dim3(1024), lds, d->stream, A, (int)L, lda, Vtmp, V, ldv, w);
+    }
     launch_check();
     dev_free(d, Vtmp);
 }

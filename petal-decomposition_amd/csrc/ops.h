@@ -94,8 +94,10 @@ void op_dgemm(Dev*, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double al
 // G (L x L, SPD up to rounding) = R^T R;  T = R^{-1} (upper triangular, L x L, ldt).
 // A pivot with r_jj^2 <= rel_tol * G_jj (or G_jj <= 0) marks column j as dependent: T[:, j] = 0.
 // Only the upper triangle of G is read.  ndead (nullable, device int): *ndead = max(*ndead, number of dependent columns).
-void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead = nullptr);
-// symmetric A (L x L) -> eigenvalues w (descending) and eigenvectors in the COLUMNS of V.  A is destroyed.
+// Lz > L: T is additionally zero-filled out to Lz x Lz (the padded extent of the caller's buffers).
+void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead = nullptr,
+                 int64_t Lz = 0);
+// symmetric A (L x L) -> eigenvalues w (descending) and eigenvectors in the COLUMNS of V.  A may be destroyed.
 void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w);
 // x[i] *= alpha
 void op_dscal(Dev*, double* x, int64_t count, double alpha);
