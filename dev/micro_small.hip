@@ -44,9 +44,11 @@ int main(int argc, char** argv) {
     printf("chol_inv: max |T^T S T - I| = %.3e\n", maxo);
 #ifdef PETAL_DEBUG_COUNTERS
     int h[4]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h)); printf("debug counters: sweeps=%d\n", h[0]);
-    long long cyc[8]; hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_cyc), sizeof(cyc));
+    long long cyc[16]; hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_cyc), sizeof(cyc));
     printf("thread-0 cycles: params=%lld bar=%lld colphase=%lld bar=%lld rowphase=%lld bar=%lld\n", cyc[0], cyc[1], cyc[2], cyc[3], cyc[4], cyc[5]);
     printf("chol: factor+scale cycles=%lld  inverse cycles=%lld (over 12 calls)\n", cyc[6], cyc[7]);
+    printf("chol phases: update=%lld diag=%lld panel=%lld | invdiag=%lld a=%lld b=%lld\n", cyc[8], cyc[9], cyc[10], cyc[11], cyc[12], cyc[13]);
+    printf("chol diag split: factor=%lld inverse=%lld barrier=%lld\n", cyc[14], cyc[15], cyc[9]);
 #endif
     return 0;
 }

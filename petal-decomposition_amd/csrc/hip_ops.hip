@@ -40,7 +40,7 @@ namespace petal {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef PETAL_DEBUG_COUNTERS
 __device__ int g_dbg[4];
-__device__ long long g_cyc[8];
+__device__ long long g_cyc[16];
 #define DBG_T(i) do { if (threadIdx.x == 0) { long long _t = clock64(); g_cyc[i] += _t - _t0; _t0 = _t; } } while (0)
 #else
 #define DBG_T(i) do {} while (0)
@@ -1159,6 +1159,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
                 }
             }
             __syncthreads();
+            DBG_T(8);
             // (2) diagonal block: one wave, column c of the block in the registers of lane c, pivots broadcast by readlane
             if (tid < 64) {
                 const int c = jb + tid;
@@ -1184,6 +1185,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
                 }
             }
             __syncthreads();
+            DBG_T(9);
             // (3) panel: R[jb.., c] = R_JJ^-T A[jb.., c] for every column right of the block (one thread per column)
             {
                 const int c = jb + 16 + tid;
@@ -1204,6 +1206,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
                 }
             }
             __syncthreads();
+            DBG_T(10);
         }
         if (tid == 0 && ndead_out) { int cdead = 0; for (int j = 0; j < L; ++j) cdead += dead[j]; if (cdead > *ndead_out) *ndead_out = cdead; }
         // dependent columns: zero the column above the (already zero) diagonal
@@ -1229,6 +1232,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
         }
     }
     __syncthreads();
+    DBG_T(11);
     for (int dl = 1; dl < nb; ++dl) {
         const int nblk = nb - dl, nel = nblk * 256;
         // (a) W_IJ = sum_{K = I+1 .. J} R_IK T_KJ, parked in T_IJ's (still zero) slot
@@ -1242,6 +1246,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
             }
         }
         __syncthreads();
+        DBG_T(12);
         // (b) T_IJ = -T_II W_IJ (results held in registers across the barrier: W is overwritten in place)
         double res[4];
 #pragma unroll
@@ -1268,6 +1273,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
             }
         }
         __syncthreads();
+        DBG_T(13);
     }
     DBG_T(7);
     if (t_mode)
@@ -1276,6 +1282,214 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restr
             T[(int64_t)r * ldt + c] = (t_mode == 2) ? (c >= r ? Tl[pk(r, c, L)] : 0.0) : Tl[e];
         }
 #undef TI
+}
+
+// ---- fast Cholesky-inverse for L <= 140: R and T both packed COLUMN-major in LDS (cp(k, c) = c (c + 1) / 2 + k, k <= c),
+// so every inner product below walks contiguous words with incremental addresses (no index arithmetic in the loops);
+// the 16 x 16 diagonal block is factored AND inverted in the registers of one wave (column c in lane c, pivots and
+// multipliers broadcast with v_readlane, reciprocal square roots instead of sqrt + divisions), and the panel solve
+// becomes a product with the inverted diagonal block.  Same contract as k_chol_inv.
+__device__ __forceinline__ double readlane_d(double x, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int cp(int k, int c) { return (c * (c + 1)) / 2 + k; }
+constexpr int CHOL2_MAXL = 140;
+__host__ __device__ inline size_t chol2_lds_bytes(int L) {
+    return sizeof(double) * ((size_t)L * (L + 1) + 2 * (size_t)L) + sizeof(int) * (size_t)L;
+}
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T,
+                                                            int64_t ldt, double rel_tol, int* __restrict__ ndead_out, int Lz) {
+    extern __shared__ __attribute__((aligned(16))) double sm_chol[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int np = L * (L + 1) / 2;
+    double* Rc = sm_chol;
+    double* Tc = Rc + np;
+    double* gd = Tc + np;
+    double* rinv = gd + L;
+    int* dead = reinterpret_cast<int*>(rinv + L);
+    for (int e = tid; e < L * L; e += nt) {
+        const int r = e / L, c = e - r * L;
+        if (c >= r) {
+            const double g = G[(int64_t)r * ldg + c];
+            Rc[cp(r, c)] = g;
+            Tc[cp(r, c)] = 0.0;
+            if (c == r) gd[r] = g;
+        }
+    }
+    for (int e = tid; e < Lz * Lz; e += nt) {  // zero padding of the output beyond the factored block
+        const int r = e / Lz, c = e - r * Lz;
+        if (r >= L || c >= L) T[(int64_t)r * ldt + c] = 0.0;
+    }
+    __syncthreads();
+#ifdef PETAL_DEBUG_COUNTERS
+    long long _t0 = clock64();
+#endif
+    const int nb = (L + 15) / 16;
+    for (int J = 0; J < nb; ++J) {
+        const int jb = 16 * J;
+        // (1) block row J -= (finished rows above)^T (finished rows above): 16 rows x 4 columns per wave
+        if (jb > 0) {
+            const int ncol = L - jb;
+            for (int e = tid; e < 16 * ncol; e += nt) {
+                const int r = jb + (e & 15), c = jb + (e >> 4);
+                if (r < L && c >= r) {
+                    const double* pr = Rc + (r * (r + 1)) / 2;
+                    const double* pc = Rc + (c * (c + 1)) / 2;
+                    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    for (int k = 0; k < jb; k += 4) {  // jb is a multiple of 16
+                        a0 += pr[k] * pc[k]; a1 += pr[k + 1] * pc[k + 1];
+                        a2 += pr[k + 2] * pc[k + 2]; a3 += pr[k + 3] * pc[k + 3];
+                    }
+                    Rc[cp(r, c)] -= (a0 + a1) + (a2 + a3);
+                }
+            }
+            __syncthreads();
+        }
+        DBG_T(8);
+        // (2) diagonal block in the registers of wave 0: lane c holds column jb + c; right-looking factorisation, then
+        //     the inverse of the block by back substitution (the multipliers R[i][k] are wave-uniform)
+        if (tid < 64) {
+            const int c = jb + tid;
+            double a[16], t[16], rv[16];
+            const double gv = (tid < 16 && c < L) ? gd[c] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] = (tid < 16 && i <= tid && c < L) ? Rc[cp(jb + i, c)] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double dii = readlane_d(a[i], i);
+                const double gi = readlane_d(gv, i);
+                const bool ok = (gi > 0.0) && (dii > rel_tol * gi);
+                const double inv = ok ? rsqrt(dii) : 0.0;
+                rv[i] = inv;
+                a[i] *= inv;
+#pragma unroll
+                for (int k = i + 1; k < 16; ++k) a[k] -= readlane_d(a[i], k) * a[i];
+            }
+            if (tid < 16 && c < L) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i <= tid) Rc[cp(jb + i, c)] = a[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            DBG_T(14);
+            // inverse of the block: the multipliers R[i][k] come back from LDS as broadcast reads (one instruction per
+            // value instead of two readlanes, and no scalar-register pressure)
+            const int kcl = min(jb + 15, L - 1);
+            double acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+#pragma unroll
+            for (int k = 15; k >= 0; --k) {  // right-looking: column k of R updates all the partial sums at once (ILP)
+                t[k] = (k == tid) ? rv[k] : (k < tid ? -rv[k] * acc[k] : 0.0);
+                const double* pk_ = Rc + cp(jb, min(jb + k, kcl));  // R[jb + i][jb + k], contiguous in i
+#pragma unroll
+                for (int i = 0; i < k; ++i) acc[i] += pk_[i] * t[k];
+            }
+            if (tid < 16 && c < L) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i <= tid) Tc[cp(jb + i, c)] = t[i];
+                double mine = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mine = (i == tid) ? rv[i] : mine;
+                rinv[c] = mine;
+                dead[c] = mine > 0.0 ? 0 : 1;
+            }
+            DBG_T(15);
+        }
+        __syncthreads();
+        DBG_T(9);
+        // (3) panel right of the block: R[jb.., c] = T_JJ^T A[jb.., c]; 4 threads per column, outputs i = q, q+4, q+8, q+12
+        if (jb + 16 < L) {
+            const int c = jb + 16 + (tid >> 2), q = tid & 3;
+            double o[4];
+            const bool on = c < L;
+            if (on) {
+                double v[16];
+                const double* pc = Rc + (c * (c + 1)) / 2 + jb;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = pc[k];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = q + 4 * u;
+                    const double* pt = Tc + ((jb + i) * (jb + i + 1)) / 2 + jb;  // column jb + i of T_JJ, rows jb ..
+                    double acc = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc += (k <= i) ? pt[k] * v[k] : 0.0;
+                    o[u] = acc;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (on) {
+                double* pc = Rc + (c * (c + 1)) / 2 + jb;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pc[q + 4 * u] = o[u];
+            }
+            __syncthreads();
+        }
+        DBG_T(10);
+    }
+    if (tid == 0 && ndead_out) { int cdead = 0; for (int j = 0; j < L; ++j) cdead += dead[j]; if (cdead > *ndead_out) *ndead_out = cdead; }
+    // ---- off-diagonal blocks of T = R^-1, block diagonal by block diagonal: T_IJ = -T_II sum_{K = I+1 .. J} R_IK T_KJ ----
+    for (int dl = 1; dl < nb; ++dl) {
+        const int nel = (nb - dl) * 256;
+        // (a) W_IJ parked in T_IJ's (still zero) slot
+        for (int e = tid; e < nel; e += nt) {
+            const int bI = e >> 8, r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
+            if (c < L) {  // r < c < L
+                const int k0 = 16 * (bI + 1);
+                const double* pt = Tc + (c * (c + 1)) / 2;  // T[k][c], contiguous in k
+                int ro = (k0 * (k0 + 1)) / 2 + r;           // R[r][k] = Rc[k (k + 1) / 2 + r]
+                double w0 = 0, w1 = 0;
+                int k = k0;
+                for (; k + 1 <= c; k += 2) {
+                    w0 += Rc[ro] * pt[k];
+                    w1 += Rc[ro + k + 1] * pt[k + 1];
+                    ro += 2 * k + 3;
+                }
+                if (k <= c) w0 += Rc[ro] * pt[k];
+                Tc[cp(r, c)] = w0 + w1;
+            }
+        }
+        __syncthreads();
+        DBG_T(12);
+        // (b) T_IJ = -T_II W_IJ (results held in registers across the barrier: W is overwritten in place)
+        double res[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = tid + it * nt;
+            res[it] = 0;
+            if (e < nel) {
+                const int bI = e >> 8, r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
+                if (c < L) {
+                    const double* pw = Tc + (c * (c + 1)) / 2;  // W[m][c]
+                    const int m1 = 16 * (bI + 1);
+                    int to = (r * (r + 1)) / 2 + r;             // T[r][m] = Tc[m (m + 1) / 2 + r]
+                    double t2 = 0;
+                    for (int m = r; m < m1; ++m) { t2 += Tc[to] * pw[m]; to += m + 1; }
+                    res[it] = -t2;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = tid + it * nt;
+            if (e < nel) {
+                const int bI = e >> 8, r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
+                if (c < L) Tc[cp(r, c)] = res[it];
+            }
+        }
+        __syncthreads();
+        DBG_T(13);
+    }
+    for (int e = tid; e < L * L; e += nt) {
+        const int r = e / L, c = e - r * L;
+        T[(int64_t)r * ldt + c] = c >= r ? Tc[cp(r, c)] : 0.0;
+    }
 }
 
 // ---- workgroup-wide cyclic Jacobi eigen-solver (fp64) ----------------------------------------------
@@ -2262,16 +2476,22 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     if (L == 0) return;
     if (L > CHOL_MAXL) throw std::runtime_error("chol_inv: matrix too large for the one-workgroup LDS kernel (L <= 200)");
     if (Lz < L) Lz = L;
+    static const bool force_old = getenv("PETAL_CHOL_OLD") != nullptr;
+    if (L <= CHOL2_MAXL && !force_old) {
+        static bool attr2 = false;
+        if (!attr2) { set_max_lds(reinterpret_cast<const void*>(k_chol_inv2)); attr2 = true; }
+        hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol,
+                           ndead, (int)Lz);
+        launch_check();
+        return;
+    }
     const size_t base = sizeof(double) * (L * (L + 1) / 2 + L + (L + 1) / 2);
     const size_t full = base + sizeof(double) * L * L, packed = base + sizeof(double) * (L * (L + 1) / 2);
     const size_t cap = 160 * 1024 - 256;
     const int t_mode = full <= cap ? 1 : (packed <= cap ? 2 : 0);
     const size_t lds = t_mode == 1 ? full : (t_mode == 2 ? packed : base);
     static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    if (!attr_set) { set_max_lds(reinterpret_cast<const void*>(k_chol_inv)); attr_set = true; }
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_mode, ndead, (int)Lz);
     launch_check();
 }
