@@ -77,7 +77,9 @@ void        petal_ctx_destroy(petal_ctx* ctx);
 const char* petal_last_error(const petal_ctx* ctx);
 const char* petal_version(void);
 int         petal_ctx_set_collective(petal_ctx* ctx, petal_allreduce_fn fn, void* user, int rank, int world_size);
-/* profiling != 0: bracket the hot kernels with hipEvents and fill petal_stats.*_ms */
+/* profiling: 0 off; 1 = bracket ONE launch of each hot kernel per fit with hipEvents (the launch index rotates from
+ * fit to fit, so K fits sample every launch position; keeps the event bubbles out of the fit time); 2 = every launch.
+ * petal_stats.*_ms / *_launches count the bracketed launches only. */
 int         petal_ctx_set_profiling(petal_ctx* ctx, int profiling);
 int         petal_get_stats(const petal_ctx* ctx, petal_stats* out);
 

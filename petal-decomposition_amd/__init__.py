@@ -225,8 +225,9 @@ class Context:
         msg = (self.lib.petal_last_error(self._h) or b"").decode()
         raise {PETAL_INVALID_INPUT: InvalidInput, PETAL_LINALG_ERROR: LinalgError}.get(rc, DeviceError)(msg)
 
-    def set_profiling(self, on: bool):
-        self.check(self.lib.petal_ctx_set_profiling(self._h, int(bool(on))))
+    def set_profiling(self, level):
+        """0/False off, 1/True one sampled launch of each hot kernel per fit, 2 every launch (petal_hip.h)."""
+        self.check(self.lib.petal_ctx_set_profiling(self._h, int(level)))
 
     def stats(self) -> dict:
         s = petal_stats()

@@ -65,17 +65,28 @@ void column_means(petal_ctx& c, const DevMat& X, double n_total, bool centering,
 
 // svd_flip's decision (pca.rs:826-839) for the columns of a row-sharded U: sign of the first
 // element of maximal magnitude over ALL ranks' rows.  Returns +1/-1 per column.
+// Single rank with `deferred` given: the (absmax, row, value) triple is only QUEUED for the host (no sync here); the
+// caller decodes it with signs_from_triple() after its own dev_sync, so a fit ends with one synchronisation.
+std::vector<double> signs_from_triple(const std::vector<double>& h, int64_t L) {
+    std::vector<double> sg(L, 1.0);
+    for (int64_t j = 0; j < L; ++j) sg[j] = h[2 * L + j] < 0 ? -1.0 : 1.0;
+    return sg;
+}
 std::vector<double> flip_signs(petal_ctx& c, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu,
-                               int64_t row_offset) {
+                               int64_t row_offset, std::vector<double>* deferred = nullptr) {
     std::vector<double> h(3 * L), sg(L, 1.0);
     if (L == 0) return sg;
     DBuf r(c.dev, sizeof(double) * 3 * L);
     op_col_absmax(c.dev, dtype, U, n, L, ldu, row_offset, r.f64(), r.f64() + L, r.f64() + 2 * L);
     if (c.world <= 1) {
+        if (deferred) {
+            deferred->assign(3 * L, 0.0);
+            dev_d2h(c.dev, deferred->data(), r.p, r.bytes);
+            return sg;
+        }
         dev_d2h(c.dev, h.data(), r.p, r.bytes);
         dev_sync(c.dev);
-        for (int64_t j = 0; j < L; ++j) sg[j] = h[2 * L + j] < 0 ? -1.0 : 1.0;
-        return sg;
+        return signs_from_triple(h, L);
     }
     DBuf g(c.dev, sizeof(double) * L);
     std::vector<double> gm(L), cand(L), win(L);
@@ -344,7 +355,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     DBuf Bt(c.dev, sizeof(double) * dp * LP), S(c.dev, sizeof(double) * LP * LP), Uh(c.dev, sizeof(double) * LP * LP);
     DBuf lam(c.dev, sizeof(double) * LP), sig(c.dev, sizeof(double) * LP), inv(c.dev, sizeof(double) * LP);
     DBuf V(c.dev, sizeof(double) * dp * LP), M2(c.dev, sizeof(double) * LP * LP);
-    std::vector<double> sg;
+    std::vector<double> sg, hflip;
     // The whole device pipeline.  It runs OPTIMISTICALLY first (robust = false): every power iteration re-bases with
     // the single-Cholesky fast path and no host round trip; the kernels record the worst pivot breakdown in `ndead`,
     // which is read together with the results.  Only if a breakdown happened is the fit redone with robust = true.
@@ -417,25 +428,24 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // U = Q Uh = Z1 (T2 Uh) (pca.rs:683) and svd_flip (pca.rs:684)
     op_dgemm(c.dev, false, false, LP, LP, LP, 1.0, T.f64(), LP, Uh.f64(), LP, 0.0, M2.f64(), LP);
     op_gemm_xp(c.dev, dt, Z1.p, n, LP, LP, nullptr, M2.f64(), LP, LP, nullptr, Z.p, LP, nullptr);  // Z now holds U
-    sg = flip_signs(c, dt, Z.p, n, LP, LP, ri.row_offset);
+    sg = flip_signs(c, dt, Z.p, n, LP, LP, ri.row_offset, &hflip);
     };  // pipeline
 
+    // results (pca.rs:543-547): queued behind the pipeline together with the breakdown flag, ONE synchronisation
+    std::vector<double> hV(size_t(dp) * LP), hs(LP), hmu(dp);
+    double htv = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
         int hdead = 0;
         dev_d2h(c.dev, &hdead, ndead.p, sizeof(int));
+        dev_d2h(c.dev, hV.data(), V.p, V.bytes);
+        dev_d2h(c.dev, hs.data(), sig.p, sig.bytes);
+        dev_d2h(c.dev, hmu.data(), mu64.p, mu64.bytes);
+        dev_d2h(c.dev, &htv, tvp, sizeof(double));
         dev_sync(c.dev);
         if (attempt == 1 || hdead == 0) break;
     }
-
-    // results (pca.rs:543-547)
-    std::vector<double> hV(size_t(dp) * LP), hs(LP), hmu(dp);
-    double htv = 0;
-    dev_d2h(c.dev, hV.data(), V.p, V.bytes);
-    dev_d2h(c.dev, hs.data(), sig.p, sig.bytes);
-    dev_d2h(c.dev, hmu.data(), mu64.p, mu64.bytes);
-    dev_d2h(c.dev, &htv, tvp, sizeof(double));
-    dev_sync(c.dev);
+    if (c.world <= 1) sg = signs_from_triple(hflip, LP);
     for (int64_t j = 0; j < k; ++j) {
         for (int64_t i = 0; i < d; ++i) put_elem(components, dt, j * d + i, sg[j] * hV[size_t(i) * LP + j]);
         put_elem(singular, dt, j, hs[j]);

@@ -19,15 +19,19 @@ int guarded(petal_ctx* ctx, F&& f) {
         return PETAL_OK;
     } catch (const Error& e) {
         ctx->err = e.what();
+        if (ctx->dev) dev_abort(ctx->dev);
         return e.code;
     } catch (const std::bad_alloc&) {
         ctx->err = "out of host memory";
+        if (ctx->dev) dev_abort(ctx->dev);
         return PETAL_DEVICE_ERROR;
     } catch (const std::exception& e) {
         ctx->err = e.what();
+        if (ctx->dev) dev_abort(ctx->dev);
         return PETAL_DEVICE_ERROR;
     } catch (...) {
         ctx->err = "unknown error";
+        if (ctx->dev) dev_abort(ctx->dev);
         return PETAL_DEVICE_ERROR;
     }
 }
@@ -79,7 +83,7 @@ int petal_ctx_set_collective(petal_ctx* ctx, petal_allreduce_fn fn, void* user, 
 
 int petal_ctx_set_profiling(petal_ctx* ctx, int profiling) {
     return guarded(ctx, [&] {
-        ctx->profiling = profiling != 0;
+        ctx->profiling = profiling < 0 ? 0 : (profiling > 2 ? 2 : profiling);
         dev_set_profiling(ctx->dev, ctx->profiling);
     });
 }

@@ -16,7 +16,7 @@ struct petal_ctx {
     petal_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
     int rank = 0, world = 1;
-    bool profiling = false;
+    int profiling = 0;
     petal_stats stats{};
 };
 

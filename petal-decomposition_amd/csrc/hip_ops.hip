@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -53,8 +54,17 @@ struct Dev {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 = time ONE launch per tag and fit (rotating over the launches), 2 = every launch
     int tag = 0;
+    int tag_seen[TAG_COUNT] = {};    // tagged launches so far in this fit
+    int tag_count[TAG_COUNT] = {};   // tagged launches of the previous fit (period of the rotation)
+    int tag_pick[TAG_COUNT] = {};    // index of the launch that is timed in this fit
+    // pinned staging for small device-to-host results: copies are queued back to back on the stream and handed to the
+    // caller's (pageable) buffers at the next dev_sync, instead of one blocking staged copy each
+    char* pin = nullptr;
+    size_t pin_cap = 0, pin_used = 0;
+    struct Pend { void* dst; size_t off, bytes; };
+    std::vector<Pend> pend;
     std::multimap<size_t, void*> free_list;
     std::unordered_map<void*, size_t> live;
     std::vector<hipEvent_t> ev_pool;
@@ -100,6 +110,7 @@ void dev_destroy(Dev* d) {
     for (auto& kv : d->live) (void)hipFree(kv.first);
     for (auto& r : d->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : d->ev_pool) (void)hipEventDestroy(ev);
+    if (d->pin) (void)hipHostFree(d->pin);
     if (d->own_stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -141,8 +152,35 @@ void dev_h2d(Dev* d, void* dst, const void* src, size_t bytes) {
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));  // callers pass short-lived pageable buffers
 }
+static void drain_pending(Dev* d) {
+    for (auto& p : d->pend) std::memcpy(p.dst, d->pin + p.off, p.bytes);
+    d->pend.clear();
+    d->pin_used = 0;
+}
+constexpr size_t PIN_MAX_COPY = size_t(8) << 20, PIN_RING = size_t(32) << 20;
 void dev_d2h(Dev* d, void* dst, const void* src, size_t bytes) {
-    if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
+    if (!bytes) return;
+    if (bytes > PIN_MAX_COPY) {  // large results go straight to the caller's buffer
+        HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
+        return;
+    }
+    if (!d->pin) {
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->pin), PIN_RING, hipHostMallocDefault));
+        d->pin_cap = PIN_RING;
+    }
+    const size_t need = (bytes + 63) / 64 * 64;
+    if (d->pin_used + need > d->pin_cap) {  // ring full: finish what is queued, hand it over, start again
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        drain_pending(d);
+    }
+    HIP_CHECK(hipMemcpyAsync(d->pin + d->pin_used, src, bytes, hipMemcpyDeviceToHost, d->stream));
+    d->pend.push_back({dst, d->pin_used, bytes});
+    d->pin_used += need;
+}
+void dev_abort(Dev* d) {  // error path: the destinations of queued copies may be gone
+    (void)hipStreamSynchronize(d->stream);
+    d->pend.clear();
+    d->pin_used = 0;
 }
 void dev_d2d(Dev* d, void* dst, const void* src, size_t bytes) {
     if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, d->stream));
@@ -153,8 +191,11 @@ void dev_copy2d(Dev* d, void* dst, size_t dpitch, const void* src, size_t spitch
     HIP_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, k, d->stream));
     if (kind == 0) HIP_CHECK(hipStreamSynchronize(d->stream));
 }
-void dev_sync(Dev* d) { HIP_CHECK(hipStreamSynchronize(d->stream)); }
-void dev_set_profiling(Dev* d, bool on) { d->profiling = on; }
+void dev_sync(Dev* d) {
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    drain_pending(d);
+}
+void dev_set_profiling(Dev* d, int level) { d->profiling = level; }
 void dev_set_tag(Dev* d, int tag) { d->tag = tag; }
 
 static hipEvent_t get_event(Dev* d) {
@@ -175,6 +216,11 @@ static void resolve_events(Dev* d) {
 void dev_reset_timing(Dev* d) {
     if (!d->recs.empty()) { (void)hipStreamSynchronize(d->stream); resolve_events(d); }
     d->acc = KernelTiming{};
+    for (int t = 0; t < TAG_COUNT; ++t) {  // next fit times the next launch index of every tag
+        if (d->tag_seen[t] > 0) d->tag_count[t] = d->tag_seen[t];
+        d->tag_pick[t] = d->tag_count[t] > 0 ? (d->tag_pick[t] + 1) % d->tag_count[t] : 0;
+        d->tag_seen[t] = 0;
+    }
 }
 KernelTiming dev_timing(Dev* d) {
     if (!d->recs.empty()) { HIP_CHECK(hipStreamSynchronize(d->stream)); resolve_events(d); }
@@ -183,7 +229,11 @@ KernelTiming dev_timing(Dev* d) {
 // brackets the dominant kernel of a tagged op with events on the launch stream
 struct TagScope {
     Dev* d; bool on; hipEvent_t a{}, b{};
-    explicit TagScope(Dev* dev) : d(dev), on(dev->profiling && dev->tag > 0 && dev->tag < TAG_COUNT) {
+    explicit TagScope(Dev* dev) : d(dev), on(false) {
+        if (d->profiling && d->tag > 0 && d->tag < TAG_COUNT) {
+            const int idx = d->tag_seen[d->tag]++;
+            on = d->profiling >= 2 || idx == d->tag_pick[d->tag];
+        }
         if (on) { a = get_event(d); b = get_event(d); HIP_CHECK(hipEventRecord(a, d->stream)); }
     }
     void stop() {
@@ -1066,15 +1116,20 @@ __global__ void k_sum_parts_state(const double* __restrict__ part, int64_t npart
 // C[M x N] = alpha op(A) op(B) + beta C, fp64, 16 x 16 outputs per block, 32-deep K steps; the global loads are
 // coalesced for every transposition case (the transposed operand is read along its contiguous index and
 // transposed on the way into LDS).
+// Split-K form (gridDim.z > 1, used when K is long and the output small): slice z covers K-range [z kchunk, (z+1) kchunk)
+// and writes its raw partial tile to part[z][M][N]; k_dgemm_reduce adds the slices in fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_dgemm(bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha,
                                                const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
-                                               double beta, double* __restrict__ C, int64_t ldc) {
+                                               double beta, double* __restrict__ C, int64_t ldc, int64_t kchunk,
+                                               double* __restrict__ part) {
     constexpr int BK = 32;
     __shared__ double sa[16][BK + 1], sb[BK][17];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int64_t i0 = (int64_t)blockIdx.y * 16, j0 = (int64_t)blockIdx.x * 16;
+    const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+    if (K > kbeg + kchunk) K = kbeg + kchunk;
     double acc = 0;
-    for (int64_t k0 = 0; k0 < K; k0 += BK) {
+    for (int64_t k0 = kbeg; k0 < K; k0 += BK) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (ta) {  // A is K x M: contiguous in i
@@ -1102,7 +1157,19 @@ __global__ __launch_bounds__(256) void k_dgemm(bool ta, bool tb, int64_t M, int6
         __syncthreads();
     }
     const int64_t i = i0 + ty, j = j0 + tx;
-    if (i < M && j < N) C[i * ldc + j] = alpha * acc + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
+    if (i < M && j < N) {
+        if (part) part[((int64_t)blockIdx.z * M + i) * N + j] = acc;
+        else C[i * ldc + j] = alpha * acc + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
+    }
+}
+__global__ __launch_bounds__(256) void k_dgemm_reduce(const double* __restrict__ part, int ks, int64_t M, int64_t N, double alpha,
+                                                      double beta, double* __restrict__ C, int64_t ldc) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * N) return;
+    double acc = 0;
+    for (int z = 0; z < ks; ++z) acc += part[(int64_t)z * M * N + e];
+    const int64_t i = e / N, j = e - i * N;
+    C[i * ldc + j] = alpha * acc + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
 }
 
 // One workgroup.  The working copy of G lives in LDS as a packed upper triangle (L (L+1) / 2 doubles, 83.5 KB at
@@ -1762,22 +1829,78 @@ __global__ __launch_bounds__(MB > 0 ? 768 : 1024) void k_eigh(double* A, int L, 
 }
 
 // ---- split eigen-solver: rotations on A in one workgroup, eigenvector accumulation spread over the chip --------------
-// The Jacobi rotations are decided by A alone; V <- V J only consumes (c, s, p, q).  k_jacobi_a keeps A in LDS (so L up
-// to 138 fits: no V beside it), runs the round-robin sweeps with the 2 x 2-block one-pass update and LOGS every round's
-// rotations to global memory; k_apply_rot then replays the log on the rows of V = I, one row per wave (rows are
-// independent, so the replay runs on L waves in parallel instead of inside the single Jacobi workgroup), and scatters
-// the columns into descending-eigenvalue order.
+// The Jacobi rotations are decided by A alone; V <- V J only consumes (c, s) (the pairs (p, q) of a round are a pure
+// function of the round number).  k_jacobi_a keeps A in LDS (so L up to 141 fits: no V beside it), runs the round-robin
+// sweeps and LOGS every round's (c, s) to global memory; k_apply_rot then replays the log on the rows of V = I, one row
+// per wave (rows are independent, so the replay runs on L waves in parallel instead of inside the single Jacobi
+// workgroup), and scatters the columns into descending-eigenvalue order.
 typedef double jf64x2 __attribute__((ext_vector_type(2)));
-typedef int ji32x2 __attribute__((ext_vector_type(2)));
 constexpr int JACA_MAX_SWEEPS = 16;
 __host__ __device__ inline size_t jaca_lds_bytes(int L) {
     const int half = ((L + 1) & ~1) / 2;
-    return sizeof(double) * ((size_t)L * (L | 1) + 2 * (size_t)half + 64) + sizeof(int) * 2 * (size_t)half;
+    return sizeof(double) * ((size_t)L * (L | 1) + 2 * (size_t)half + 64);
 }
-template <int MB2>
+// round-robin tournament: pair k of round rd (Le players, Le - 1 rounds); p < q, or p == q for a bye (odd L)
+__device__ __forceinline__ void pair_pq(int k, int rd, int Le, int L, int& p, int& q) {
+    if (k == 0) { p = Le - 1; q = rd; }
+    else { p = rd + k; if (p >= Le - 1) p -= Le - 1; q = rd - k; if (q < 0) q += Le - 1; }
+    if (p > q) { const int t = p; p = q; q = t; }
+    if (q >= L) q = p;
+}
+// the same pairs, advanced round by round without divisions: raw players (rd + k, rd - k) mod (Le - 1)
+struct PairIt {
+    int pr, qr;
+    __device__ __forceinline__ void init(int k, int rd, int Le) {
+        const int m = Le - 1;
+        pr = (rd + k) % m; qr = ((rd - k) % m + m) % m;
+    }
+    __device__ __forceinline__ void next(int Le) {
+        if (++pr >= Le - 1) pr = 0;
+        if (++qr >= Le - 1) qr = 0;
+    }
+    __device__ __forceinline__ void get(int k, int Le, int L, int& p, int& q) const {
+        p = (k == 0) ? Le - 1 : pr;
+        q = (k == 0) ? pr : qr;  // pair 0 is (Le - 1, rd) and pr == rd for k == 0
+        if (p > q) { const int t = p; p = q; q = t; }
+        if (q >= L) q = p;
+    }
+};
+__device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq, double& c, double& s, double& t) {
+    const double d = aqq - app;
+    const double m = fmax(fabs(d), fabs(apq));
+    if (m > 1e-140 && m < 1e140) {
+        // t = sgn(d) 2 apq / (|d| + sqrt(d^2 + 4 apq^2)); hardware rsq / rcp seeds with Newton steps instead of the
+        // IEEE sqrt / divide sequences (t only steers convergence; c is refined to full precision for orthogonality)
+        const double x = d * d + 4.0 * apq * apq;
+        double rs = __builtin_amdgcn_rsq(x);
+        rs = rs * (1.5 - 0.5 * x * rs * rs);
+        const double den = fabs(d) + x * rs;
+        double r = __builtin_amdgcn_rcp(den);
+        r = r * (2.0 - den * r);
+        t = (d >= 0.0 ? 2.0 : -2.0) * apq * r;
+    } else {
+        const double theta = d / (2.0 * apq);
+        t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    }
+    const double y = t * t + 1.0;  // in [1, 2]
+    double cr = __builtin_amdgcn_rsq(y);
+    cr = cr * (1.5 - 0.5 * y * cr * cr);
+    cr = cr * (1.5 - 0.5 * y * cr * cr);
+    c = cr;
+    s = t * cr;
+}
+// A is symmetric and stays symmetric, so only its UPPER triangle is kept and rotated: element {i, j} lives at
+// (min, max).  A round touches every unordered pair of rotation pairs {k, k'} once (a 2 x 2 block, rotated from the left
+// with k's and from the right with k''s angle), and the 2 x 2 diagonal block of each pair is updated in closed form by
+// the thread that computes its angle.  Two thread roles:
+//   angle threads (tid < half, the first PW threads): read (app, aqq, apq), compute (c, s), update the diagonal block;
+//   block threads (tid >= PW): 16-lane group g owns the row pairs k = g and k = half-1-g, which together have exactly
+//     half-1 partners k' > k.  Their operands do not depend on this round's angles, so addresses and the 2 x 2 blocks are
+//     fetched BEFORE the barrier, under the angle threads' latency chain; after it only (c, s) are read and applied.
+template <int MB2>  // 16-wide batches of partner pairs per lane: half - 1 <= 16 MB2
 __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ain, int L, int64_t lda, jf64x2* __restrict__ log_cs,
-                                                   ji32x2* __restrict__ log_pq, int* __restrict__ nrounds_out,
-                                                   double* __restrict__ w, int* __restrict__ rank_out) {
+                                                   int* __restrict__ nrounds_out, double* __restrict__ w,
+                                                   int* __restrict__ rank_out, int PW) {
     extern __shared__ __attribute__((aligned(16))) double sm_ja[];
     const int LD = L | 1;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
@@ -1785,17 +1908,20 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
     jf64x2* s_cs = reinterpret_cast<jf64x2*>(sm_ja);
     double* s_red = sm_ja + 2 * half;
     double* A = s_red + 64;
-    ji32x2* s_pq = reinterpret_cast<ji32x2*>(A + (size_t)L * LD);
     {
         int r = tid / L, c = tid - r * L;
         const int dr = nt / L, dc = nt - dr * L;
         for (int e = tid; e < L * L; e += nt) {
-            A[r * LD + c] = Ain[(int64_t)r * lda + c];
+            if (c >= r) A[r * LD + c] = Ain[(int64_t)r * lda + c];
             r += dr; c += dc;
             if (c >= L) { c -= L; ++r; }
         }
     }
     __syncthreads();
+    // this block thread's slots j = k0 + 16 m: slot j < n1 -> (k = g, k' = g + 1 + j), else (k = gb, k' = gb + 1 + j - n1)
+    const int bt = tid - PW, g = bt >> 4, k0 = bt & 15;
+    const int gb = half - 1 - g, n1 = half - 1 - g;
+    const int nslots = (bt < 0) ? 0 : ((g < gb) ? half - 1 : (g == gb ? n1 : 0));
     int R = 0;  // rounds logged so far
     bool last = false;
     for (int sweep = 0; sweep < JACA_MAX_SWEEPS && L >= 2; ++sweep) {
@@ -1804,8 +1930,10 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
             int r = tid / L, c = tid - r * L;
             const int dr = nt / L, dc = nt - dr * L;
             for (int e = tid; e < L * L; e += nt) {
-                const double v = A[r * LD + c];
-                if (r == c) dg += v * v; else tot += v * v;
+                if (c >= r) {
+                    const double v = A[r * LD + c];
+                    if (r == c) dg += v * v; else tot += 2.0 * v * v;
+                }
                 r += dr; c += dc;
                 if (c >= L) { c -= L; ++r; }
             }
@@ -1818,60 +1946,85 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
         __syncthreads();
         if (!(toff > 1e-30 * tdg) || last) break;
         if (!(toff > 1e-14 * tdg)) last = true;  // quadratic convergence: one more sweep reaches rounding level
+#ifdef PETAL_DEBUG_COUNTERS
+        if (tid == 0) g_dbg[0] = sweep + 1;
+        long long _t0 = clock64();
+#endif
+        PairIt ita, itb, itk[MB2], itme;
+        ita.init(max(g, 0), 0, Le); itb.init(max(gb, 0) % half, 0, Le); itme.init(min(tid, half - 1), 0, Le);
+#pragma unroll
+        for (int m = 0; m < MB2; ++m) {
+            const int j = k0 + 16 * m;
+            itk[m].init(min(max(j < n1 ? g + 1 + j : gb + 1 + (j - n1), 0), half - 1), 0, Le);
+        }
         for (int rd = 0; rd < rounds; ++rd, ++R) {
+            double e00[MB2], e01[MB2], e10[MB2], e11[MB2];
+            int i00[MB2], i01[MB2], i10[MB2], i11[MB2], kpv[MB2];
             if (tid < half) {
-                const int k = tid;
                 int p, q;
-                if (k == 0) { p = Le - 1; q = rd; }
-                else { p = rd + k; if (p >= Le - 1) p -= Le - 1; q = rd - k; if (q < 0) q += Le - 1; }
-                if (p > q) { const int t = p; p = q; q = t; }
+                itme.get(tid, Le, L, p, q);
                 double c = 1.0, sn = 0.0;
-                if (q < L) {
+                if (p != q) {
                     const double apq = A[p * LD + q];
                     if (apq != 0.0) {
-                        const double theta = (A[q * LD + q] - A[p * LD + p]) / (2.0 * apq);
-                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        c = 1.0 / sqrt(t * t + 1.0);
-                        sn = t * c;
-                    }
-                } else { q = p; }  // bye: identity rotation on a single index
-                s_pq[k] = ji32x2{p, q};
-                s_cs[k] = jf64x2{c, sn};
-                log_pq[(size_t)R * half + k] = ji32x2{p, q};
-                log_cs[(size_t)R * half + k] = jf64x2{c, sn};
-            }
-            __syncthreads();
-            {   // A <- J^T A J, one 2 x 2 block per (pair k, pair k'), gathered into registers before the scatter
-                const int k0 = tid & 15;
-                for (int k = tid >> 4; k < half; k += nt >> 4) {
-                    const ji32x2 pq = s_pq[k];
-                    const jf64x2 cs = s_cs[k];
-                    double* rp = A + pq[0] * LD;
-                    double* rq = A + pq[1] * LD;
-                    double a[MB2], b[MB2], cc[MB2], d[MB2], c2[MB2], s2[MB2];
-                    int p2[MB2], q2[MB2];
-#pragma unroll
-                    for (int m = 0; m < MB2; ++m) {
-                        const int kp = min(k0 + 16 * m, half - 1);
-                        const ji32x2 pq2 = s_pq[kp];
-                        const jf64x2 cs2 = s_cs[kp];
-                        p2[m] = pq2[0]; q2[m] = (k0 + 16 * m < half) ? pq2[1] : -1;
-                        c2[m] = cs2[0]; s2[m] = cs2[1];
-                        a[m] = rp[pq2[0]]; b[m] = rp[pq2[1]]; cc[m] = rq[pq2[0]]; d[m] = rq[pq2[1]];
-                    }
-#pragma unroll
-                    for (int m = 0; m < MB2; ++m) {
-                        if (q2[m] < 0) continue;
-                        const double a1 = c2[m] * a[m] - s2[m] * b[m], b1 = s2[m] * a[m] + c2[m] * b[m];
-                        const double c1 = c2[m] * cc[m] - s2[m] * d[m], d1 = s2[m] * cc[m] + c2[m] * d[m];
-                        rp[p2[m]] = cs[0] * a1 - cs[1] * c1;
-                        rp[q2[m]] = cs[0] * b1 - cs[1] * d1;
-                        rq[p2[m]] = cs[1] * a1 + cs[0] * c1;
-                        rq[q2[m]] = cs[1] * b1 + cs[0] * d1;
+                        const double app = A[p * LD + p], aqq = A[q * LD + q];
+                        double t;
+                        jacobi_angle(app, aqq, apq, c, sn, t);
+                        A[p * LD + p] = app - t * apq;
+                        A[q * LD + q] = aqq + t * apq;
+                        A[p * LD + q] = 0.0;
                     }
                 }
+                s_cs[tid] = jf64x2{c, sn};
+                log_cs[(size_t)R * half + tid] = jf64x2{c, sn};
+            } else if (nslots > 0) {
+                int pa, qa, pb, qb;
+                ita.get(g, Le, L, pa, qa);
+                itb.get(gb, Le, L, pb, qb);
+#pragma unroll
+                for (int m = 0; m < MB2; ++m) {
+                    const int j = k0 + 16 * m;
+                    const bool first = j < n1;
+                    const int kp = min(first ? g + 1 + j : gb + 1 + (j - n1), half - 1);
+                    kpv[m] = kp;
+                    const int p = first ? pa : pb, q = first ? qa : qb;
+                    int p2, q2;
+                    itk[m].get(kp, Le, L, p2, q2);
+                    i00[m] = min(p, p2) * LD + max(p, p2);
+                    i01[m] = min(p, q2) * LD + max(p, q2);
+                    i10[m] = min(q, p2) * LD + max(q, p2);
+                    i11[m] = min(q, q2) * LD + max(q, q2);
+                    e00[m] = A[i00[m]]; e01[m] = A[i01[m]]; e10[m] = A[i10[m]]; e11[m] = A[i11[m]];
+                }
             }
+            DBG_T(0);
             __syncthreads();
+            DBG_T(1);
+            if (nslots > 0) {
+                const jf64x2 csa = s_cs[g], csb = s_cs[gb];
+                jf64x2 cs2[MB2];
+#pragma unroll
+                for (int m = 0; m < MB2; ++m) cs2[m] = s_cs[kpv[m]];
+#pragma unroll
+                for (int m = 0; m < MB2; ++m) {
+                    const int j = k0 + 16 * m;
+                    if (j >= nslots) continue;
+                    const jf64x2 cs = (j < n1) ? csa : csb;
+                    // right rotation (columns p', q') with the partner's angle, then left rotation (rows p, q) with ours
+                    const double a1 = cs2[m][0] * e00[m] - cs2[m][1] * e01[m], b1 = cs2[m][1] * e00[m] + cs2[m][0] * e01[m];
+                    const double c1 = cs2[m][0] * e10[m] - cs2[m][1] * e11[m], d1 = cs2[m][1] * e10[m] + cs2[m][0] * e11[m];
+                    A[i00[m]] = cs[0] * a1 - cs[1] * c1;
+                    A[i01[m]] = cs[0] * b1 - cs[1] * d1;
+                    A[i10[m]] = cs[1] * a1 + cs[0] * c1;
+                    A[i11[m]] = cs[1] * b1 + cs[0] * d1;
+                }
+            }
+            DBG_T(2);
+            __syncthreads();
+            DBG_T(3);
+            ita.next(Le); itb.next(Le); itme.next(Le);
+#pragma unroll
+            for (int m = 0; m < MB2; ++m) itk[m].next(Le);
         }
     }
     if (tid == 0) *nrounds_out = R;
@@ -1887,43 +2040,45 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
     }
 }
 // replay of the rotation log on V = I: wave <-> row r of V (kept in LDS), lanes <-> the disjoint pairs of a round.
-// The parameters of JR rounds are fetched ahead (independent loads) so the global-memory latency is paid once per batch.
+// The angles of JR_BATCH rounds are fetched ahead (independent loads) so the global-memory latency is paid once per batch.
 constexpr int JR_WAVES = 4, JR_BATCH = 8;
 template <int HP>  // pairs per lane: half <= 64 HP
-__global__ __launch_bounds__(64 * JR_WAVES) void k_apply_rot(const jf64x2* __restrict__ log_cs, const ji32x2* __restrict__ log_pq,
-                                                             const int* __restrict__ nrounds, const int* __restrict__ rank, int L,
-                                                             double* __restrict__ V, int64_t ldv) {
+__global__ __launch_bounds__(64 * JR_WAVES) void k_apply_rot(const jf64x2* __restrict__ log_cs, const int* __restrict__ nrounds,
+                                                             const int* __restrict__ rank, int L, double* __restrict__ V, int64_t ldv) {
     extern __shared__ __attribute__((aligned(16))) double sm_jr[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int Le = (L + 1) & ~1, half = Le / 2;
+    const int Le = (L + 1) & ~1, half = Le / 2, rounds = Le - 1;
     const int r = blockIdx.x * JR_WAVES + wv;
     double* row = sm_jr + (size_t)wv * Le;
     for (int j = lane; j < Le; j += 64) row[j] = (j == r) ? 1.0 : 0.0;
     const int nR = *nrounds;
+    PairIt it[HP];
+#pragma unroll
+    for (int h = 0; h < HP; ++h) it[h].init(min(lane + 64 * h, half - 1), 0, Le);
     for (int R0 = 0; R0 < nR; R0 += JR_BATCH) {
         jf64x2 cs[JR_BATCH][HP];
-        ji32x2 pq[JR_BATCH][HP];
 #pragma unroll
         for (int u = 0; u < JR_BATCH; ++u) {
             const int Ru = min(R0 + u, nR - 1);
 #pragma unroll
-            for (int h = 0; h < HP; ++h) {
-                const int k = min(lane + 64 * h, half - 1);
-                cs[u][h] = log_cs[(size_t)Ru * half + k];
-                pq[u][h] = log_pq[(size_t)Ru * half + k];
-            }
+            for (int h = 0; h < HP; ++h) cs[u][h] = log_cs[(size_t)Ru * half + min(lane + 64 * h, half - 1)];
         }
 #pragma unroll
         for (int u = 0; u < JR_BATCH; ++u) {
             if (R0 + u < nR) {
                 double vp[HP], vq[HP];
-#pragma unroll
-                for (int h = 0; h < HP; ++h) { vp[h] = row[pq[u][h][0]]; vq[h] = row[pq[u][h][1]]; }
+                int p[HP], q[HP];
 #pragma unroll
                 for (int h = 0; h < HP; ++h) {
-                    if (lane + 64 * h < half && pq[u][h][0] != pq[u][h][1]) {
-                        row[pq[u][h][0]] = cs[u][h][0] * vp[h] - cs[u][h][1] * vq[h];
-                        row[pq[u][h][1]] = cs[u][h][1] * vp[h] + cs[u][h][0] * vq[h];
+                    it[h].get(min(lane + 64 * h, half - 1), Le, L, p[h], q[h]);
+                    it[h].next(Le);  // the sweeps restart at round 0 after Le - 1 rounds: the raw players wrap with them
+                    vp[h] = row[p[h]]; vq[h] = row[q[h]];
+                }
+#pragma unroll
+                for (int h = 0; h < HP; ++h) {
+                    if (lane + 64 * h < half && p[h] != q[h]) {
+                        row[p[h]] = cs[u][h][0] * vp[h] - cs[u][h][1] * vq[h];
+                        row[q[h]] = cs[u][h][1] * vp[h] + cs[u][h][0] * vq[h];
                     }
                 }
             }
@@ -2468,8 +2623,23 @@ void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode)
 void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
               const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
     if (M == 0 || N == 0) return;
+    const int64_t tiles = (int64_t)cdiv(N, 16) * cdiv(M, 16);
+    int ks = 1;
+    if (K >= 256 && tiles < 256) ks = (int)std::min<int64_t>(16, std::min<int64_t>(K / 64, (512 + tiles - 1) / tiles));
+    if (ks > 1) {  // long reduction, few output tiles: spread K over the chip, then add the slices in order
+        const int64_t kchunk = (cdiv(K, ks) + 31) / 32 * 32;
+        ks = cdiv(K, kchunk);
+        double* part = (double*)dev_alloc(d, sizeof(double) * ks * M * N);
+        hipLaunchKernelGGL(k_dgemm, dim3(cdiv(N, 16), cdiv(M, 16), ks), dim3(16, 16), 0, d->stream, ta, tb, M, N, K, alpha, A, lda, B,
+                           ldb, beta, C, ldc, kchunk, part);
+        launch_check();
+        hipLaunchKernelGGL(k_dgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, d->stream, part, ks, M, N, alpha, beta, C, ldc);
+        launch_check();
+        dev_free(d, part);
+        return;
+    }
     hipLaunchKernelGGL(k_dgemm, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(16, 16), 0, d->stream, ta, tb, M, N, K, alpha, A, lda, B, ldb,
-                       beta, C, ldc);
+                       beta, C, ldc, K, (double*)nullptr);
     launch_check();
 }
 void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz) {
@@ -2502,19 +2672,20 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         // split solver: A in LDS + rotation log, eigenvectors replayed on L waves
         const int Le = (int)((L + 1) & ~1), half = Le / 2, rounds = Le - 1;
         const size_t nlog = (size_t)JACA_MAX_SWEEPS * rounds * half;
-        char* buf = (char*)dev_alloc(d, nlog * 24 + 16 + sizeof(int) * (L + 4));
+        char* buf = (char*)dev_alloc(d, nlog * 16 + 16 + sizeof(int) * (L + 4));
         jf64x2* log_cs = reinterpret_cast<jf64x2*>(buf);
-        ji32x2* log_pq = reinterpret_cast<ji32x2*>(buf + nlog * 16);
-        int* nrounds = reinterpret_cast<int*>(buf + nlog * 24);
+        int* nrounds = reinterpret_cast<int*>(buf + nlog * 16);
         int* rank = nrounds + 4;
-        const int mb2 = (half + 15) / 16;
-        const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, (16 * half + 63) / 64 * 64));
+        const int mb2 = std::max(1, (half - 1 + 15) / 16);               // partner pairs per lane
+        const int groups = (half + 1) / 2;                                // 16-lane groups, two row pairs each
+        const int pw = (half + 63) / 64 * 64;                             // angle threads (whole waves)
+        const int threads = std::min(1024, (pw + 16 * groups + 63) / 64 * 64);
         const size_t lds = jaca_lds_bytes((int)L);
 #define JACA_CASE(M)                                                                                                     \
     case M: {                                                                                                            \
         static bool once = false;                                                                                        \
         if (!once) { set_max_lds(reinterpret_cast<const void*>(k_jacobi_a<M>)); once = true; }                           \
-        hipLaunchKernelGGL(k_jacobi_a<M>, dim3(1), dim3(threads), lds, d->stream, A, (int)L, lda, log_cs, log_pq, nrounds, w, rank); \
+        hipLaunchKernelGGL(k_jacobi_a<M>, dim3(1), dim3(threads), lds, d->stream, A, (int)L, lda, log_cs, nrounds, w, rank, pw); \
     } break;
         switch (mb2) { JACA_CASE(1) JACA_CASE(2) JACA_CASE(3) JACA_CASE(4) default: JACA_CASE(5) }
 #undef JACA_CASE
@@ -2522,8 +2693,8 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         const int hp = (half + 63) / 64;
         const dim3 grid((unsigned)cdiv(L, JR_WAVES));
         const size_t lds2 = sizeof(double) * JR_WAVES * Le;
-        if (hp <= 1) hipLaunchKernelGGL(k_apply_rot<1>, grid, dim3(64 * JR_WAVES), lds2, d->stream, log_cs, log_pq, nrounds, rank, (int)L, V, ldv);
-        else hipLaunchKernelGGL(k_apply_rot<2>, grid, dim3(64 * JR_WAVES), lds2, d->stream, log_cs, log_pq, nrounds, rank, (int)L, V, ldv);
+        if (hp <= 1) hipLaunchKernelGGL(k_apply_rot<1>, grid, dim3(64 * JR_WAVES), lds2, d->stream, log_cs, nrounds, rank, (int)L, V, ldv);
+        else hipLaunchKernelGGL(k_apply_rot<2>, grid, dim3(64 * JR_WAVES), lds2, d->stream, log_cs, nrounds, rank, (int)L, V, ldv);
         launch_check();
         dev_free(d, buf);
         return;

@@ -33,12 +33,13 @@ void* dev_alloc(Dev*, size_t bytes);      // cached; never returns nullptr (thro
 void  dev_free(Dev*, void*);
 void  dev_memset(Dev*, void* p, int v, size_t bytes);
 void  dev_h2d(Dev*, void* dst, const void* src, size_t bytes);
-void  dev_d2h(Dev*, void* dst, const void* src, size_t bytes);
+void  dev_d2h(Dev*, void* dst, const void* src, size_t bytes);  // dst is valid after the next dev_sync
 void  dev_d2d(Dev*, void* dst, const void* src, size_t bytes);
 // pitched copies (bytes); kind: 0 h2d, 1 d2h, 2 d2d
 void  dev_copy2d(Dev*, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int kind);
 void  dev_sync(Dev*);
-void  dev_set_profiling(Dev*, bool on);
+void  dev_set_profiling(Dev*, int level);   // 0 off, 1 one sampled launch per tag and fit, 2 every tagged launch
+void  dev_abort(Dev*);                     // error path: wait for the stream, drop queued device-to-host hand-overs
 void  dev_reset_timing(Dev*);
 void  dev_set_tag(Dev*, int tag);
 KernelTiming dev_timing(Dev*);            // resolves pending events (call after dev_sync)
