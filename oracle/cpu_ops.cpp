@@ -70,10 +70,14 @@ void op_unpack_strided(Dev*, int dt, const void* src, int64_t n, int64_t d, int6
     for (int64_t i = 0; i < n; ++i)
         for (int64_t j = 0; j < d; ++j) st(dst, dt, i * rs + j * cs, ld(src, dt, i * ld_src + j));
 }
-void op_colsum(Dev*, int dt, const void* X, int64_t n, int64_t d, int64_t ldx, double* out) {
-    for (int64_t j = 0; j < d; ++j) out[j] = 0;
+void op_colsum(Dev*, int dt, const void* X, int64_t n, int64_t d, int64_t ldx, double* out, bool with_sq) {
+    for (int64_t j = 0; j < (with_sq ? 2 * d : d); ++j) out[j] = 0;
     for (int64_t i = 0; i < n; ++i)
-        for (int64_t j = 0; j < d; ++j) out[j] += ld(X, dt, i * ldx + j);
+        for (int64_t j = 0; j < d; ++j) {
+            const double v = ld(X, dt, i * ldx + j);
+            out[j] += v;
+            if (with_sq) out[d + j] += v * v;
+        }
 }
 void op_gemm_xp(Dev*, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P,
                 int64_t N, int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq) {

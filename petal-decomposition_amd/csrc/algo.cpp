@@ -49,16 +49,19 @@ RankInfo rank_info(petal_ctx& c, int64_t n_local) {
 }
 
 // column means (pca.rs:520-528 / ica.rs:174): mu64 (device f64[dp]) and muT (device dtype[dp]); zeros if !centering
-void column_means(petal_ctx& c, const DevMat& X, double n_total, bool centering, DBuf& mu64, DBuf& muT) {
-    mu64 = DBuf(c.dev, sizeof(double) * X.dp);
+// with_sq (centering only): mu64 has 2 dp entries, the second half holds the column sums of squares over all ranks,
+// from the same pass over X (total variance = sum_j (sq_j - n mu_j^2), formed in fp64 by the caller).
+void column_means(petal_ctx& c, const DevMat& X, double n_total, bool centering, DBuf& mu64, DBuf& muT, bool with_sq = false) {
+    const int64_t w = (with_sq && centering) ? 2 * X.dp : X.dp;
+    mu64 = DBuf(c.dev, sizeof(double) * w);
     muT = DBuf(c.dev, dtype_size(X.dtype) * X.dp);
     if (!centering) {
         dev_memset(c.dev, mu64.p, 0, mu64.bytes);
         dev_memset(c.dev, muT.p, 0, muT.bytes);
         return;
     }
-    op_colsum(c.dev, X.dtype, X.p, X.n, X.dp, X.ld, mu64.f64());
-    allreduce_f64(c, mu64.f64(), X.dp, PETAL_SUM);
+    op_colsum(c.dev, X.dtype, X.p, X.n, X.dp, X.ld, mu64.f64(), w > X.dp);
+    allreduce_f64(c, mu64.f64(), w, PETAL_SUM);
     op_dscal(c.dev, mu64.f64(), X.dp, 1.0 / n_total);
     op_cvt_from_f64(c.dev, X.dtype, muT.p, mu64.f64(), X.dp);
 }
@@ -334,7 +337,11 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     const double tol_drop = (dt == F32 ? 1e-6 : 1e-13);
 
     DBuf mu64, muT;
-    column_means(c, X, ri.n_total, centering, mu64, muT);
+    // fp32 input: the total variance comes from column sums of squares gathered in the means pass (exact products, fp64
+    // sums: the cancellation in sum x^2 - n mu^2 costs (mu / sigma)^2 ulps of fp64, far below fp32 resolution); fp64 input
+    // keeps the centred sum fused into the first product
+    const bool tv_from_sq = centering && dt == F32;
+    column_means(c, X, ri.n_total, centering, mu64, muT, tv_from_sq);
 
     // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64
     DBuf P(c.dev, sizeof(double) * dp * LP);
@@ -362,9 +369,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     auto pipeline = [&](bool robust) {
     dev_memset(c.dev, tvp, 0, sizeof(double));
     dev_memset(c.dev, ndead.p, 0, sizeof(int));
-    // Z = Xc . Omega (pca.rs:707), fused with total_variance = sum Xc^2 (pca.rs:533)
+    // Z = Xc . Omega (pca.rs:707); total_variance = sum Xc^2 (pca.rs:533) is fused into this product unless tv_from_sq
     dev_set_tag(c.dev, TAG_XP);
-    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tvp);
+    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv_from_sq ? nullptr : tvp);
     dev_set_tag(c.dev, TAG_NONE);
 
     double* G = GY.f64();
@@ -432,7 +439,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     };  // pipeline
 
     // results (pca.rs:543-547): queued behind the pipeline together with the breakdown flag, ONE synchronisation
-    std::vector<double> hV(size_t(dp) * LP), hs(LP), hmu(dp);
+    std::vector<double> hV(size_t(dp) * LP), hs(LP), hmu(mu64.bytes / sizeof(double));
     double htv = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
@@ -446,6 +453,10 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         if (attempt == 1 || hdead == 0) break;
     }
     if (c.world <= 1) sg = signs_from_triple(hflip, LP);
+    if (tv_from_sq) {  // sum (x - mu)^2 = sum x^2 - n mu^2 per column, in fp64
+        htv = 0;
+        for (int64_t j = 0; j < d; ++j) htv += std::max(0.0, hmu[dp + j] - ri.n_total * hmu[j] * hmu[j]);
+    }
     for (int64_t j = 0; j < k; ++j) {
         for (int64_t i = 0; i < d; ++i) put_elem(components, dt, j * d + i, sg[j] * hV[size_t(i) * LP + j]);
         put_elem(singular, dt, j, hs[j]);

@@ -243,6 +243,7 @@ struct TagScope {
 
 static inline void launch_check() { HIP_CHECK(hipGetLastError()); }
 static inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ================================================================================================
 // generic kernels (any shape, T = float | double, fp64 accumulation)
@@ -264,15 +265,66 @@ __global__ void k_unpack_strided(const T* __restrict__ src, int64_t n, int64_t d
     dst[i * rs + j * cs] = src[i * ld + j];
 }
 
-constexpr int CS_ROWS = 128;  // rows per block of the column-sum / column-absmax first stage
+// Column scans over a tall row-major matrix, first stage: block = 64 column lanes x 4 row lanes over `rows` rows (the
+// loads of a thread are independent: many in flight), row lanes combined through LDS in fixed order.
+constexpr int SCAN_RY = 4;
+__host__ inline int64_t scan_rows_per_block(int64_t n) { return std::max<int64_t>(256, (cdiv64(n, 256) + 3) / 4 * 4); }
+template <class T, bool SQ>  // SQ: also the column sums of squares, part = [nparts][2 d] = [sums | sums of squares]
+__global__ __launch_bounds__(256) void k_colsum_part2(const T* __restrict__ X, int64_t n, int64_t d, int64_t ldx, int64_t rows,
+                                                      double* __restrict__ part) {
+    __shared__ double red[SCAN_RY][64], redq[SQ ? SCAN_RY : 1][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int64_t j = blockIdx.y * (int64_t)64 + cx;
+    const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = min(n, r0 + rows);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (j < d) {
+        int64_t i = r0 + ry;
+        for (; i + 3 * SCAN_RY < r1; i += 4 * SCAN_RY) {
+            const double v0 = (double)X[i * ldx + j], v1 = (double)X[(i + SCAN_RY) * ldx + j];
+            const double v2 = (double)X[(i + 2 * SCAN_RY) * ldx + j], v3 = (double)X[(i + 3 * SCAN_RY) * ldx + j];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+            if (SQ) { q0 += v0 * v0; q1 += v1 * v1; q2 += v2 * v2; q3 += v3 * v3; }
+        }
+        for (; i < r1; i += SCAN_RY) {
+            const double v0 = (double)X[i * ldx + j];
+            s0 += v0;
+            if (SQ) q0 += v0 * v0;
+        }
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
+    if (SQ) redq[ry][cx] = (q0 + q1) + (q2 + q3);
+    __syncthreads();
+    if (ry == 0 && j < d) {
+        const int64_t w = SQ ? 2 * d : d;
+        part[(int64_t)blockIdx.x * w + j] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        if (SQ) part[(int64_t)blockIdx.x * w + d + j] = (redq[0][cx] + redq[1][cx]) + (redq[2][cx] + redq[3][cx]);
+    }
+}
 template <class T>
-__global__ void k_colsum_part(const T* __restrict__ X, int64_t n, int64_t d, int64_t ldx, double* __restrict__ part) {
-    const int64_t j = blockIdx.y * (int64_t)blockDim.x + threadIdx.x;
-    if (j >= d) return;
-    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = min(n, r0 + CS_ROWS);
-    double s = 0;
-    for (int64_t i = r0; i < r1; ++i) s += (double)X[i * ldx + j];
-    part[(int64_t)blockIdx.x * d + j] = s;
+__global__ __launch_bounds__(256) void k_absmax_part2(const T* __restrict__ U, int64_t n, int64_t L, int64_t ldu, int64_t rows,
+                                                      double* __restrict__ pmax, double* __restrict__ pidx,
+                                                      double* __restrict__ psgn) {
+    __shared__ double rm[SCAN_RY][64], ri[SCAN_RY][64], rs[SCAN_RY][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int64_t j = blockIdx.y * (int64_t)64 + cx;
+    const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = min(n, r0 + rows);
+    double best = -1.0, bi = INFINITY, bs = 1.0;
+    if (j < L) {
+#pragma unroll 4
+        for (int64_t i = r0 + ry; i < r1; i += SCAN_RY) {  // ascending rows, strict '>' keeps the first maximum (pca.rs:830)
+            const double v = (double)U[i * ldu + j], a = fabs(v);
+            if (a > best) { best = a; bi = (double)i; bs = signbit(v) ? -1.0 : 1.0; }
+        }
+    }
+    rm[ry][cx] = best; ri[ry][cx] = bi; rs[ry][cx] = bs;
+    __syncthreads();
+    if (ry == 0 && j < L) {
+#pragma unroll
+        for (int k = 1; k < SCAN_RY; ++k)
+            if (rm[k][cx] > best || (rm[k][cx] == best && ri[k][cx] < bi)) { best = rm[k][cx]; bi = ri[k][cx]; bs = rs[k][cx]; }
+        const int64_t o = (int64_t)blockIdx.x * L + j;
+        pmax[o] = best; pidx[o] = bi; psgn[o] = bs;
+    }
 }
 // out[(e / N) * ldc + e % N] = sum_p part[p * count + e]  (fp64 accumulation, fixed order => deterministic).
 // block = 32 elements x 8 part-lanes.
@@ -342,20 +394,6 @@ __global__ void k_atb_simple(const T* __restrict__ A, int64_t lda, int64_t M, co
     double s = 0;
     for (int64_t i = r0; i < r1; ++i) s += (double)(T)(A[i * lda + m] - ma) * (double)(T)(B[i * ldb + j] - mb);
     part[((int64_t)blockIdx.x * M + m) * N + j] = s;
-}
-template <class T>
-__global__ void k_absmax_part(const T* __restrict__ U, int64_t n, int64_t L, int64_t ldu, double* __restrict__ pmax,
-                              double* __restrict__ pidx, double* __restrict__ psgn) {
-    const int64_t j = blockIdx.y * (int64_t)blockDim.x + threadIdx.x;
-    if (j >= L) return;
-    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = min(n, r0 + CS_ROWS);
-    double best = -1.0, bi = 0.0, bs = 1.0;
-    for (int64_t i = r0; i < r1; ++i) {
-        const double v = (double)U[i * ldu + j], a = fabs(v);
-        if (i == r0 || a > best) { best = a; bi = (double)i; bs = signbit(v) ? -1.0 : 1.0; }
-    }
-    const int64_t o = (int64_t)blockIdx.x * L + j;
-    pmax[o] = best; pidx[o] = bi; psgn[o] = bs;
 }
 // one wave per column: lanes scan the row chunks in order (strict '>' keeps the first maximum, pca.rs:830),
 // then a lexicographic (larger |u|, then smaller row) butterfly picks the winner.
@@ -1414,11 +1452,11 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
             __syncthreads();
         }
         DBG_T(8);
-        // (2) diagonal block in the registers of wave 0: lane c holds column jb + c; right-looking factorisation, then
-        //     the inverse of the block by back substitution (the multipliers R[i][k] are wave-uniform)
+        // (2) diagonal block in the registers of wave 0: lane c holds column jb + c; right-looking factorisation with the
+        //     pivots and multipliers broadcast by v_readlane, reciprocal square roots instead of sqrt + divisions
         if (tid < 64) {
             const int c = jb + tid;
-            double a[16], t[16], rv[16];
+            double a[16], rv[16];
             const double gv = (tid < 16 && c < L) ? gd[c] : 0.0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) a[i] = (tid < 16 && i <= tid && c < L) ? Rc[cp(jb + i, c)] : 0.0;
@@ -1437,79 +1475,108 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     if (i <= tid) Rc[cp(jb + i, c)] = a[i];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            DBG_T(14);
-            // inverse of the block: the multipliers R[i][k] come back from LDS as broadcast reads (one instruction per
-            // value instead of two readlanes, and no scalar-register pressure)
-            const int kcl = min(jb + 15, L - 1);
-            double acc[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-#pragma unroll
-            for (int k = 15; k >= 0; --k) {  // right-looking: column k of R updates all the partial sums at once (ILP)
-                t[k] = (k == tid) ? rv[k] : (k < tid ? -rv[k] * acc[k] : 0.0);
-                const double* pk_ = Rc + cp(jb, min(jb + k, kcl));  // R[jb + i][jb + k], contiguous in i
-#pragma unroll
-                for (int i = 0; i < k; ++i) acc[i] += pk_[i] * t[k];
-            }
-            if (tid < 16 && c < L) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (i <= tid) Tc[cp(jb + i, c)] = t[i];
                 double mine = 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) mine = (i == tid) ? rv[i] : mine;
                 rinv[c] = mine;
                 dead[c] = mine > 0.0 ? 0 : 1;
             }
-            DBG_T(15);
         }
         __syncthreads();
         DBG_T(9);
-        // (3) panel right of the block: R[jb.., c] = T_JJ^T A[jb.., c]; 4 threads per column, outputs i = q, q+4, q+8, q+12
+        // (3) panel right of the block by forward substitution, one thread per column (right-looking in registers; the
+        //     multipliers R[jb + k][jb + i] are broadcast LDS reads, independent of the dependency chain)
         if (jb + 16 < L) {
-            const int c = jb + 16 + (tid >> 2), q = tid & 3;
-            double o[4];
-            const bool on = c < L;
-            if (on) {
+            const int c = jb + 16 + tid;
+            if (c < L) {
                 double v[16];
-                const double* pc = Rc + (c * (c + 1)) / 2 + jb;
+                double* pc = Rc + (c * (c + 1)) / 2 + jb;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) v[k] = pc[k];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = q + 4 * u;
-                    const double* pt = Tc + ((jb + i) * (jb + i + 1)) / 2 + jb;  // column jb + i of T_JJ, rows jb ..
-                    double acc = 0;
+                for (int k = 0; k < 16; ++k) {
+                    v[k] *= rinv[jb + k];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) acc += (k <= i) ? pt[k] * v[k] : 0.0;
-                    o[u] = acc;
+                    for (int i = k + 1; i < 16; ++i) v[i] -= Rc[cp(jb + k, jb + i)] * v[k];
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (on) {
-                double* pc = Rc + (c * (c + 1)) / 2 + jb;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) pc[q + 4 * u] = o[u];
+                for (int k = 0; k < 16; ++k) pc[k] = v[k];
             }
             __syncthreads();
         }
         DBG_T(10);
     }
+    // inverses of all diagonal blocks at once, one wave per block: column c of T_JJ in lane c, back substitution
+    // right-looking (column k of R updates every partial sum: independent FMAs), multipliers as broadcast LDS reads
+    for (int J = tid >> 6; J < nb; J += nt >> 6) {
+        const int jb = 16 * J, ln = tid & 63, c = jb + ln;
+        const int kcl = min(jb + 15, L - 1);
+        double t[16], acc[16], rv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[i] = 0.0; rv[i] = rinv[min(jb + i, kcl)] * ((jb + i <= kcl) ? 1.0 : 0.0); }
+#pragma unroll
+        for (int k = 15; k >= 0; --k) {
+            t[k] = (k == ln) ? rv[k] : (k < ln ? -rv[k] * acc[k] : 0.0);
+            const double* pk_ = Rc + cp(jb, min(jb + k, kcl));  // R[jb + i][jb + k], contiguous in i
+#pragma unroll
+            for (int i = 0; i < k; ++i) acc[i] += pk_[i] * t[k];
+        }
+        if (ln < 16 && c < L) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i <= ln) Tc[cp(jb + i, c)] = t[i];
+        }
+    }
+    __syncthreads();
+    DBG_T(11);
     if (tid == 0 && ndead_out) { int cdead = 0; for (int j = 0; j < L; ++j) cdead += dead[j]; if (cdead > *ndead_out) *ndead_out = cdead; }
-    // ---- off-diagonal blocks of T = R^-1, block diagonal by block diagonal: T_IJ = -T_II sum_{K = I+1 .. J} R_IK T_KJ ----
+    // ---- off-diagonal blocks of T = R^-1: T_IJ = -T_II sum_{K = I+1 .. J} R_IK T_KJ.  The left factor is applied once to
+    //      every off-diagonal block of R (R~_IK = T_II R_IK, in place, through registers); after that each block
+    //      super-diagonal dl is ONE phase: T_IJ = -sum_K R~_IK T_KJ with all T_KJ (K > I) already final.
+    {
+        constexpr int ITMAX = 18;  // 36 off-diagonal blocks (nb <= 9) x 256 elements / 512 threads
+        const int nel = (nb * (nb - 1) / 2) * 256;
+        double res[ITMAX];
+#pragma unroll
+        for (int it = 0; it < ITMAX; ++it) {
+            const int e = tid + it * nt;
+            res[it] = 0;
+            if (e < nel) {
+                int bI = e >> 8, dl = 1;
+                while (bI >= nb - dl) { bI -= nb - dl; ++dl; }
+                const int r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
+                if (c < L) {
+                    const double* pr = Rc + (c * (c + 1)) / 2;  // R[m][c], contiguous in m
+                    const int m1 = 16 * (bI + 1);
+                    int to = (r * (r + 1)) / 2 + r;             // T[r][m] = Tc[m (m + 1) / 2 + r]
+                    double t2 = 0;
+                    for (int m = r; m < m1; ++m) { t2 += Tc[to] * pr[m]; to += m + 1; }
+                    res[it] = t2;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITMAX; ++it) {
+            const int e = tid + it * nt;
+            if (e < nel) {
+                int bI = e >> 8, dl = 1;
+                while (bI >= nb - dl) { bI -= nb - dl; ++dl; }
+                const int r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
+                if (c < L) Rc[cp(r, c)] = res[it];
+            }
+        }
+        __syncthreads();
+    }
+    DBG_T(12);
     for (int dl = 1; dl < nb; ++dl) {
         const int nel = (nb - dl) * 256;
-        // (a) W_IJ parked in T_IJ's (still zero) slot
         for (int e = tid; e < nel; e += nt) {
             const int bI = e >> 8, r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
             if (c < L) {  // r < c < L
                 const int k0 = 16 * (bI + 1);
                 const double* pt = Tc + (c * (c + 1)) / 2;  // T[k][c], contiguous in k
-                int ro = (k0 * (k0 + 1)) / 2 + r;           // R[r][k] = Rc[k (k + 1) / 2 + r]
+                int ro = (k0 * (k0 + 1)) / 2 + r;           // R~[r][k] = Rc[k (k + 1) / 2 + r]
                 double w0 = 0, w1 = 0;
                 int k = k0;
                 for (; k + 1 <= c; k += 2) {
@@ -1518,41 +1585,12 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
                     ro += 2 * k + 3;
                 }
                 if (k <= c) w0 += Rc[ro] * pt[k];
-                Tc[cp(r, c)] = w0 + w1;
+                Tc[cp(r, c)] = -(w0 + w1);
             }
         }
         __syncthreads();
-        DBG_T(12);
-        // (b) T_IJ = -T_II W_IJ (results held in registers across the barrier: W is overwritten in place)
-        double res[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int e = tid + it * nt;
-            res[it] = 0;
-            if (e < nel) {
-                const int bI = e >> 8, r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
-                if (c < L) {
-                    const double* pw = Tc + (c * (c + 1)) / 2;  // W[m][c]
-                    const int m1 = 16 * (bI + 1);
-                    int to = (r * (r + 1)) / 2 + r;             // T[r][m] = Tc[m (m + 1) / 2 + r]
-                    double t2 = 0;
-                    for (int m = r; m < m1; ++m) { t2 += Tc[to] * pw[m]; to += m + 1; }
-                    res[it] = -t2;
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int e = tid + it * nt;
-            if (e < nel) {
-                const int bI = e >> 8, r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
-                if (c < L) Tc[cp(r, c)] = res[it];
-            }
-        }
-        __syncthreads();
-        DBG_T(13);
     }
+    DBG_T(13);
     for (int e = tid; e < L * L; e += nt) {
         const int r = e / L, c = e - r * L;
         T[(int64_t)r * ldt + c] = c >= r ? Tc[cp(r, c)] : 0.0;
@@ -2281,15 +2319,20 @@ void op_unpack_strided(Dev* d, int dt, const void* src, int64_t n, int64_t dd, i
     launch_check();
 }
 
-void op_colsum(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx, double* out) {
+void op_colsum(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx, double* out, bool with_sq) {
     if (dd == 0) return;
-    if (n == 0) { dev_memset(d, out, 0, sizeof(double) * dd); return; }
-    const int64_t nparts = cdiv(n, CS_ROWS);
-    double* part = (double*)dev_alloc(d, sizeof(double) * nparts * dd);
-    DISPATCH_T(dt, hipLaunchKernelGGL(k_colsum_part<T>, dim3((unsigned)nparts, cdiv(dd, 256)), dim3(256), 0, d->stream,
-                                      (const T*)X, n, dd, ldx, part));
+    const int64_t w = with_sq ? 2 * dd : dd;
+    if (n == 0) { dev_memset(d, out, 0, sizeof(double) * w); return; }
+    const int64_t rows = scan_rows_per_block(n), nparts = cdiv(n, rows);
+    double* part = (double*)dev_alloc(d, sizeof(double) * nparts * w);
+    const dim3 grid((unsigned)nparts, cdiv(dd, 64));
+    if (with_sq) {
+        DISPATCH_T(dt, hipLaunchKernelGGL((k_colsum_part2<T, true>), grid, dim3(256), 0, d->stream, (const T*)X, n, dd, ldx, rows, part));
+    } else {
+        DISPATCH_T(dt, hipLaunchKernelGGL((k_colsum_part2<T, false>), grid, dim3(256), 0, d->stream, (const T*)X, n, dd, ldx, rows, part));
+    }
     launch_check();
-    hipLaunchKernelGGL(k_sum_parts2<double>, dim3(cdiv(dd, 32)), dim3(256), 0, d->stream, part, nparts, dd, out, dd, dd, false);
+    hipLaunchKernelGGL(k_sum_parts2<double>, dim3(cdiv(w, 32)), dim3(256), 0, d->stream, part, nparts, w, out, w, w, false);
     launch_check();
     dev_free(d, part);
 }
@@ -2504,7 +2547,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
 void op_col_absmax(Dev* d, int dt, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* absmax,
                    double* idx, double* sign) {
     if (L == 0) return;
-    const int64_t nparts = std::max<int64_t>(1, cdiv(n, CS_ROWS));
+    const int64_t rows = scan_rows_per_block(n), nparts = std::max<int64_t>(1, cdiv(n, rows));
     double* part = (double*)dev_alloc(d, sizeof(double) * 3 * nparts * L);
     double *pm = part, *pi = part + nparts * L, *ps = part + 2 * nparts * L;
     if (n == 0) {
@@ -2516,8 +2559,8 @@ void op_col_absmax(Dev* d, int dt, const void* U, int64_t n, int64_t L, int64_t 
         dev_free(d, part);
         return;
     }
-    DISPATCH_T(dt, hipLaunchKernelGGL(k_absmax_part<T>, dim3((unsigned)nparts, cdiv(L, 64)), dim3(64), 0, d->stream, (const T*)U,
-                                      n, L, ldu, pm, pi, ps));
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_absmax_part2<T>, dim3((unsigned)nparts, cdiv(L, 64)), dim3(256), 0, d->stream, (const T*)U,
+                                      n, L, ldu, rows, pm, pi, ps));
     launch_check();
     hipLaunchKernelGGL(k_absmax_final, dim3((unsigned)L), dim3(64), 0, d->stream, pm, pi, ps, nparts, L, row_offset, absmax, idx, sign);
     launch_check();

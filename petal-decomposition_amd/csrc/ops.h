@@ -52,7 +52,8 @@ void op_pack_strided(Dev*, int dtype, const void* src, int64_t n, int64_t d, int
 void op_unpack_strided(Dev*, int dtype, const void* src, int64_t n, int64_t d, int64_t ld_src,
                        void* dst, int64_t rs, int64_t cs);
 // out[j] = sum_i X[i][j]  (fp64, deterministic order)
-void op_colsum(Dev*, int dtype, const void* X, int64_t n, int64_t d, int64_t ldx, double* out);
+// with_sq: out has 2 d entries, [column sums | column sums of squares]
+void op_colsum(Dev*, int dtype, const void* X, int64_t n, int64_t d, int64_t ldx, double* out, bool with_sq = false);
 // Z[n x N] = (X[n x K] - mu) . P[K x N] * 1 + bias        (mu, bias nullable; mu/bias in dtype)
 // P is an f64 small matrix (ldp).  sumsq (nullable, fp64 scalar): += sum_ij (X_ij - mu_j)^2.
 // colscale (nullable, f64[N]): Z[:, j] *= colscale[j].
