@@ -28,6 +28,9 @@ PETAL_SUM, PETAL_MAX, PETAL_MIN = 0, 1, 2
 ICA_TEXTBOOK, ICA_REFERENCE_LITERAL = 0, 1
 
 
+from .pcg import Pcg  # noqa: E402  (rand_pcg::Mcg128Xsl64 + Ziggurat StandardNormal)
+
+
 class DecompositionError(Exception):
     """``DecompositionError`` (src/lib.rs:22-28)."""
 
@@ -295,6 +298,27 @@ def default_context() -> Context:
     return _default_ctx
 
 
+
+# ---- serde interchange (the crate's `serde` feature, Cargo.toml:41-47): models as the JSON serde_json writes for the
+# reference structs -- same field names and order (src/pca.rs:41-51, 317-329; src/ica.rs:41-50), ndarray's
+# {"v": 1, "dim": [...], "data": [...]} arrays, rand_pcg's {"state": u128} generator.
+def _nd_to_serde(a) -> dict:
+    a = np.asarray(a)
+    return {"v": 1, "dim": list(a.shape), "data": [float(v) for v in a.reshape(-1)]}
+
+
+def _nd_from_serde(obj: dict, dtype) -> np.ndarray:
+    if obj.get("v") != 1:
+        raise InvalidInput("unknown ndarray serde version")
+    return np.asarray(obj["data"], dtype=dtype).reshape([int(v) for v in obj["dim"]])
+
+
+def _rng_to_serde(rng):
+    if isinstance(rng, Pcg):
+        return rng.to_serde()
+    raise InvalidInput("only the crate's Pcg generator has a serde form: build the model with seed()/with_seed() or a Pcg")
+
+
 # ------------------------------------------------------------------------------------------------
 class _PcaModel:
     """State shared by Pca and RandomizedPca (src/pca.rs:41-51, 317-329)."""
@@ -330,6 +354,27 @@ class _PcaModel:
 
     def explained_variance_ratio(self):
         return self._singular * self._singular / self._total_variance
+
+    def _serde_fields(self) -> dict:
+        dt = self._components.dtype if self._components.size or self._means.size else np.dtype(_np_dtype(self._dt))
+        return {"components": _nd_to_serde(self._components), "n_samples": int(self.n_samples),
+                "means": _nd_to_serde(self._means), "total_variance": float(np.asarray(self._total_variance, dtype=dt)),
+                "singular": _nd_to_serde(self._singular), "centering": bool(self.centering)}
+
+    def _load_serde_fields(self, obj: dict, dtype):
+        self._components = _nd_from_serde(obj["components"], dtype)
+        self.n_samples = int(obj["n_samples"])
+        self._means = _nd_from_serde(obj["means"], dtype)
+        self._total_variance = np.asarray(obj["total_variance"], dtype=dtype)[()]
+        self._singular = _nd_from_serde(obj["singular"], dtype)
+        self.centering = bool(obj["centering"])
+        self._k = int(self._components.shape[0])
+        self._dt = PETAL_F32 if np.dtype(dtype) == np.float32 else PETAL_F64
+
+    def to_json(self) -> str:
+        """The JSON ``serde_json::to_string(&model)`` writes for the reference struct (src/pca.rs:941, 1035)."""
+        import json
+        return json.dumps(self._serde_fields())
 
     def _store(self, comp, means, sing, tv, n):
         self._components, self._means, self._singular = comp, means, sing
@@ -375,6 +420,15 @@ class Pca(_PcaModel):
     @classmethod
     def new(cls, n_components: int, ctx: Optional[Context] = None):
         return cls(n_components, True, ctx)
+
+    @classmethod
+    def from_json(cls, text: str, dtype=np.float32, ctx: Optional[Context] = None):
+        """``serde_json::from_str::<Pca<A>>`` (A = ``dtype``)."""
+        import json
+        obj = json.loads(text)
+        m = cls(int(obj["components"]["dim"][0]), ctx=ctx)
+        m._load_serde_fields(obj, dtype)
+        return m
 
     def _inner_fit(self, x, want_y: bool):
         keep = []
@@ -430,9 +484,9 @@ class PcaBuilder:
 
 class RandomizedPca(_PcaModel):
     """``RandomizedPca<A, R>`` (src/pca.rs:317-551).  The model owns an RNG that advances on every
-    fit (src/pca.rs:532); here ``rng`` is a ``numpy.random.Generator`` whose ``standard_normal``
-    fills Omega in row-major order like src/pca.rs:701-705 (the crate's PCG/ziggurat STREAM is not
-    reproduced -- "stream parity unpinned")."""
+    fit (src/pca.rs:532); ``rng`` is anything with ``standard_normal(shape)`` filling in row-major order
+    like src/pca.rs:701-705: the crate's ``Pcg`` (``with_seed`` / builder ``seed()``; restated PCG + Ziggurat,
+    "stream parity unpinned") or a ``numpy.random.Generator`` (the default)."""
 
     N_OVERSAMPLE = 10  # src/pca.rs:679
     N_ITER = 7         # src/pca.rs:680
@@ -449,7 +503,20 @@ class RandomizedPca(_PcaModel):
 
     @classmethod
     def with_seed(cls, n_components: int, seed: int, ctx=None):
-        return cls(n_components, rng=np.random.default_rng(seed), ctx=ctx)
+        """``Pcg::from_seed(seed.to_be_bytes())`` (src/pca.rs:356-359)."""
+        return cls(n_components, rng=Pcg.from_seed_be_bytes(seed), ctx=ctx)
+
+    def _serde_fields(self) -> dict:
+        return {"rng": _rng_to_serde(self.rng), **super()._serde_fields()}
+
+    @classmethod
+    def from_json(cls, text: str, dtype=np.float32, ctx=None):
+        """``serde_json::from_str::<RandomizedPca<A, Pcg>>``."""
+        import json
+        obj = json.loads(text)
+        m = cls(int(obj["components"]["dim"][0]), rng=Pcg.from_serde(obj["rng"]), ctx=ctx)
+        m._load_serde_fields(obj, dtype)
+        return m
 
     @classmethod
     def with_rng(cls, n_components: int, rng, ctx=None):
@@ -506,7 +573,8 @@ class RandomizedPcaBuilder:
         return cls(n_components, rng)
 
     def seed(self, seed: int):
-        self._rng = np.random.default_rng(seed)
+        """``Pcg::from_seed(seed.to_be_bytes())`` like the crate's builders (src/pca.rs:599-602, src/ica.rs:274-277)."""
+        self._rng = Pcg.from_seed_be_bytes(seed)
         return self
 
     def centering(self, centering: bool):
@@ -551,7 +619,25 @@ class FastIca:
 
     @classmethod
     def with_seed(cls, seed: int, ctx=None):
-        return cls(np.random.default_rng(seed), ctx)
+        """``Pcg::from_seed(seed.to_be_bytes())`` (src/ica.rs:75-78)."""
+        return cls(Pcg.from_seed_be_bytes(seed), ctx)
+
+    def to_json(self) -> str:
+        """The JSON ``serde_json::to_string(&ica)`` writes for the reference struct (src/ica.rs:41-50, 428)."""
+        import json
+        return json.dumps({"rng": _rng_to_serde(self.rng), "components": _nd_to_serde(self.components),
+                           "means": _nd_to_serde(self.means), "n_iter": int(self.n_iter)})
+
+    @classmethod
+    def from_json(cls, text: str, dtype=np.float64, ctx=None):
+        """``serde_json::from_str::<FastIca<A>>``."""
+        import json
+        obj = json.loads(text)
+        m = cls(Pcg.from_serde(obj["rng"]), ctx)
+        m.components = _nd_from_serde(obj["components"], dtype)
+        m.means = _nd_from_serde(obj["means"], dtype)
+        m.n_iter = int(obj["n_iter"])
+        return m
 
     @classmethod
     def with_rng(cls, rng, ctx=None):
@@ -625,7 +711,8 @@ class FastIcaBuilder:
         return cls(rng)
 
     def seed(self, seed: int):
-        self._rng = np.random.default_rng(seed)
+        """``Pcg::from_seed(seed.to_be_bytes())`` like the crate's builders (src/pca.rs:599-602, src/ica.rs:274-277)."""
+        self._rng = Pcg.from_seed_be_bytes(seed)
         return self
 
     def context(self, ctx: Context):

@@ -11,7 +11,7 @@ const MAX_ITER: i64 = 200; // src/ica.rs:216
 /// 0 = textbook (W W^T)^(-1/2) W, 1 = the reference's literal arithmetic.
 const MODE: i32 = 0;
 
-#[cfg_attr(feature = "serialization", derive(serde::Serialize, serde::Deserialize))]
+#[cfg_attr(feature = "serde", derive(serde::Serialize, serde::Deserialize))]
 #[derive(Debug, Clone)]
 pub struct FastIca<A: HipScalar, R = Pcg> {
     rng: R,

@@ -10,7 +10,7 @@ const N_OVERSAMPLE: usize = 10; // src/pca.rs:679
 const N_ITER: i64 = 7; // src/pca.rs:680
 
 /// Exact PCA.  Field names follow the reference so serialized models interchange.
-#[cfg_attr(feature = "serialization", derive(serde::Serialize, serde::Deserialize))]
+#[cfg_attr(feature = "serde", derive(serde::Serialize, serde::Deserialize))]
 #[derive(Debug, Clone)]
 pub struct Pca<A: HipScalar> {
     components: Array2<A>,
@@ -96,7 +96,7 @@ impl PcaBuilder {
 }
 
 /// Randomized truncated SVD (Halko range finder with power iterations, src/pca.rs:668-718).
-#[cfg_attr(feature = "serialization", derive(serde::Serialize, serde::Deserialize))]
+#[cfg_attr(feature = "serde", derive(serde::Serialize, serde::Deserialize))]
 #[derive(Debug, Clone)]
 pub struct RandomizedPca<A: HipScalar, R = Pcg> {
     rng: R,

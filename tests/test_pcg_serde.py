@@ -1,0 +1,104 @@
+"""The crate's RNG (Mcg128Xsl64 + Ziggurat) in Python vs its C++ twin, and the serde JSON interchange of the models
+(the reference's `serde` feature: src/pca.rs:935-946, 1029-1040; src/ica.rs:422-431).  CPU only."""
+import json
+import os
+import subprocess
+
+import numpy as np
+
+import petal_decomposition_amd as petal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CPP = r"""
+#include "petal_decomposition.hpp"
+#include <cstdio>
+int main() {
+    petal_decomposition::Pcg r = petal_decomposition::Pcg::from_seed_be_bytes((unsigned __int128)0x0123456789abcdefULL << 64 | 0xfedcba9876543210ULL);
+    for (int i = 0; i < 4; ++i) std::printf("%llu\n", (unsigned long long)r.next_u64());
+    for (int i = 0; i < 3000; ++i) std::printf("%.17g\n", r.standard_normal());
+    return 0;
+}
+"""
+
+
+def test_python_pcg_matches_cpp_facade():
+    import hostsim
+    lib = hostsim.build()
+    bdir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(bdir, exist_ok=True)
+    src, out = os.path.join(bdir, "pcg_dump.cpp"), os.path.join(bdir, "pcg_dump")
+    with open(src, "w") as f:
+        f.write(CPP)
+    libdir, libname = os.path.split(lib)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", out, "-L", libdir,
+                           f"-l:{libname}", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    lines = subprocess.run([out], capture_output=True, text=True, check=True).stdout.split()
+    r = petal.Pcg.from_seed_be_bytes((0x0123456789ABCDEF << 64) | 0xFEDCBA9876543210)
+    assert [r.next_u64() for _ in range(4)] == [int(v) for v in lines[:4]]
+    got = r.standard_normal(3000)
+    want = np.array([float(v) for v in lines[4:]])
+    assert np.array_equal(got, want)  # same tables, same rejection path: bit-identical draws
+    assert abs(got.mean()) < 0.1 and abs(got.std() - 1.0) < 0.1
+
+
+def test_pcg_seed_is_byte_swapped_state():
+    # Pcg::from_seed(seed.to_be_bytes()): from_seed reads little-endian, so seed 1 -> state 1 << 120 (| 1 for the MCG)
+    assert petal.Pcg.from_seed_be_bytes(1).state == (1 << 120) | 1
+    assert petal.Pcg(6).state == 7  # the MCG state is always odd
+
+
+def _filled_pca(cls, **kw):
+    m = cls(2, **kw)
+    m._components = np.array([[0.6, 0.8, 0.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+    m._means = np.array([1.0, 2.0, 3.0], dtype=np.float32)
+    m._singular = np.array([5.0, 0.5], dtype=np.float32)
+    m._total_variance = np.float32(25.25)
+    m.n_samples = 17
+    return m
+
+
+def test_pca_json_has_the_reference_field_names_and_round_trips():
+    m = _filled_pca(petal.Pca)
+    obj = json.loads(m.to_json())
+    assert list(obj) == ["components", "n_samples", "means", "total_variance", "singular", "centering"]  # src/pca.rs:45-50
+    assert obj["components"] == {"v": 1, "dim": [2, 3], "data": [float(np.float32(v)) for v in (0.6, 0.8, 0.0, 0.0, 0.0, 1.0)]}
+    assert obj["means"]["dim"] == [3] and obj["n_samples"] == 17 and obj["centering"] is True
+    back = petal.Pca.from_json(m.to_json(), dtype=np.float32)
+    assert back.components().dtype == np.float32 and np.array_equal(back.components(), m.components())
+    assert np.array_equal(back.mean(), m.mean()) and np.array_equal(back.singular_values(), m.singular_values())
+    assert back.n_components() == 2 and back.n_samples == 17 and back.centering
+    np.testing.assert_allclose(back.explained_variance_ratio(), m.explained_variance_ratio())
+
+
+def test_randomized_pca_json_carries_the_generator_state():
+    m = _filled_pca(petal.RandomizedPca, rng=petal.Pcg.from_seed_be_bytes(42))
+    m.rng.standard_normal(5)  # the model's generator advances per fit (src/pca.rs:532)
+    obj = json.loads(m.to_json())
+    assert list(obj)[0] == "rng" and list(obj["rng"]) == ["state"]  # src/pca.rs:321-328; rand_pcg Mcg128Xsl64 { state }
+    assert obj["rng"]["state"] == m.rng.state and obj["rng"]["state"] > (1 << 64)  # a genuine u128
+    back = petal.RandomizedPca.from_json(m.to_json())
+    assert np.array_equal(back.rng.standard_normal(8), m.rng.standard_normal(8))  # the streams continue identically
+    assert np.array_equal(back.components(), m.components())
+
+
+def test_fastica_json_round_trip():
+    ica = petal.FastIca.with_seed(7)
+    ica.components = np.arange(6, dtype=np.float64).reshape(2, 3) / 7.0
+    ica.means = np.array([0.5, -0.25, 4.0])
+    ica.n_iter = 9
+    obj = json.loads(ica.to_json())
+    assert list(obj) == ["rng", "components", "means", "n_iter"]  # src/ica.rs:46-49
+    back = petal.FastIca.from_json(ica.to_json())
+    assert np.array_equal(back.components, ica.components) and np.array_equal(back.means, ica.means) and back.n_iter == 9
+    assert back.rng.state == ica.rng.state
+
+
+def test_numpy_generator_has_no_serde_form():
+    m = _filled_pca(petal.RandomizedPca)  # default rng: numpy Generator
+    try:
+        m.to_json()
+    except petal.InvalidInput as e:
+        assert "Pcg" in str(e)
+    else:
+        raise AssertionError("expected InvalidInput")
