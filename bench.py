@@ -40,6 +40,12 @@ def main():
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--n-iter", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collective", choices=["auto", "rccl", "torch"], default="auto",
+                    help="N > 1: the library's built-in RCCL all-reduce (petal_ctx_init_rccl), or the torch.distributed "
+                         "hook; auto = built-in, falling back to the hook if RCCL cannot be bound")
+    ap.add_argument("--single-rank-group", action="store_true",
+                    help="development: at N = 1 still create a one-rank process group and run the sharded code path "
+                         "(PETAL_FORCE_COLLECTIVE) to time its overhead")
     ap.add_argument("--no-northstar", action="store_true")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass "
@@ -54,11 +60,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.single_rank_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        if args.single_rank_group:
+            os.environ["PETAL_FORCE_COLLECTIVE"] = "1"
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -73,8 +83,19 @@ def main():
     omega = np.random.default_rng(3).standard_normal((d, l)).astype(np.float32)
 
     ctx = petal.Context(dev.index or 0, stream=torch.cuda.current_stream(dev).cuda_stream)
-    if world > 1:
-        ctx.use_torch_distributed()
+    collective = "none"
+    if dist is not None:
+        collective = "torch.distributed hook"
+        if args.collective in ("auto", "rccl"):
+            try:  # every rank binds the same librccl, so success / failure is uniform across the group
+                ctx.use_rccl()
+                collective = "built-in RCCL (petal_ctx_init_rccl)"
+            except Exception as e:
+                if args.collective == "rccl":
+                    raise
+                print(f"[bench] built-in RCCL unavailable ({e}); using the torch.distributed hook", file=sys.stderr)
+        if collective.startswith("torch"):
+            ctx.use_torch_distributed()
     ctx.set_profiling(True)
     model = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter)
 
@@ -137,7 +158,8 @@ def main():
             "config": {"workload": f"RandomizedPca.fit k={k} n_iter={n_iter} oversample=10 on {n}x{d} fp32 per GPU "
                                    f"(BASELINE configs[1]), X resident in HBM",
                        "rows_per_gpu": n, "features": d, "n_components": k, "n_iter": n_iter,
-                       "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU",
+                       "collective": collective},
             "roofline": roofline,
         }
 

@@ -77,6 +77,12 @@ void        petal_ctx_destroy(petal_ctx* ctx);
 const char* petal_last_error(const petal_ctx* ctx);
 const char* petal_version(void);
 int         petal_ctx_set_collective(petal_ctx* ctx, petal_allreduce_fn fn, void* user, int rank, int world_size);
+/* Built-in collective ("RCCL ncclAllReduce on one communicator"): rank 0 obtains a 128-byte ncclUniqueId,
+ * the host distributes it (MPI / torch.distributed / a file), then EVERY rank calls petal_ctx_init_rccl collectively;
+ * from then on the ctx all-reduces with ncclAllReduce on its own stream, no host callback in the loop.  RCCL is bound
+ * with dlopen at the first call (the copy already loaded in the process wins), error 3 when it cannot be found. */
+int         petal_rccl_unique_id(void* out128);
+int         petal_ctx_init_rccl(petal_ctx* ctx, const void* unique_id128, int rank, int world_size);
 /* profiling: 0 off; 1 = bracket ONE launch of each hot kernel per fit with hipEvents (the launch index rotates from
  * fit to fit, so K fits sample every launch position; keeps the event bubbles out of the fit time); 2 = every launch.
  * petal_stats.*_ms / *_launches count the bracketed launches only. */

@@ -111,6 +111,17 @@ void op_gemm_atb(Dev*, int dt, const void* A, int64_t lda, int64_t M, const void
         }
     }
 }
+void op_flip_key(Dev*, const double* t, double* key, int64_t L) {
+    for (int64_t j = 0; j < L; ++j) {
+        uint64_t bits = 0;
+        const double a = t[j] < 0 ? 0.0 : t[j];
+        std::memcpy(&bits, &a, 8);
+        const uint64_t row = t[L + j] < double(1ll << 28) ? uint64_t(t[L + j]) : (uint64_t(1) << 28) - 1;
+        const uint64_t payload = (((uint64_t(1) << 28) - 1 - row) << 1) | (t[2 * L + j] < 0 ? 1u : 0u);
+        bits = (bits & ~((uint64_t(1) << 29) - 1)) | (t[j] < 0 ? 0 : payload);
+        std::memcpy(&key[j], &bits, 8);
+    }
+}
 void op_col_absmax(Dev*, int dt, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* absmax,
                    double* idx, double* sign) {
     for (int64_t j = 0; j < L; ++j) {

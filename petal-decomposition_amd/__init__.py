@@ -80,6 +80,8 @@ ABI = [
     ("petal_version", C.c_char_p, []),
     ("petal_ctx_set_collective", C.c_int, [_P, ALLREDUCE_FN, _P, C.c_int, C.c_int]),
     ("petal_ctx_set_profiling", C.c_int, [_P, C.c_int]),
+    ("petal_rccl_unique_id", C.c_int, [_P]),
+    ("petal_ctx_init_rccl", C.c_int, [_P, _P, C.c_int, C.c_int]),
     ("petal_get_stats", C.c_int, [_P, C.POINTER(petal_stats)]),
     ("petal_pca_fit", C.c_int, [_P, _M, C.c_int64, C.c_int, _P, _P, _P, _P, _M]),
     ("petal_rpca_fit", C.c_int, [_P, _M, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _M]),
@@ -281,6 +283,23 @@ class Context:
             return 0
 
         return hook
+
+    def use_rccl(self, group=None):
+        """Sample-sharded multi-GPU with the library's BUILT-IN collective: ncclAllReduce issued by the library on the ctx
+        stream (petal_ctx_init_rccl).  torch.distributed is only used once, to hand rank 0's ncclUniqueId to the others.
+        Collective: every rank of ``group`` must call it."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            rc = self.lib.petal_rccl_unique_id(uid)
+            if rc != 0:
+                raise DeviceError("petal_rccl_unique_id failed: RCCL could not be loaded")
+        box = [uid.raw if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        buf = C.create_string_buffer(box[0], 128)
+        self.check(self.lib.petal_ctx_init_rccl(self._h, buf, rank, world))
+        self.rank, self.world_size = rank, world
 
     def use_torch_distributed(self, group=None):
         """Sample-sharded multi-GPU: sum the small replicated buffers with torch.distributed."""

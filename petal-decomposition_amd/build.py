@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpetal_hip.so")
-SOURCES = ["hip_ops.hip", "algo.cpp", "api.cpp"]
+SOURCES = ["hip_ops.hip", "algo.cpp", "api.cpp", "rccl.cpp"]
 HEADERS = ["ops.h", "ctx.h", os.path.join("..", "..", "include", "petal_hip.h")]
 
 
@@ -17,7 +17,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = OUT + f".{os.getpid()}.tmp"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + srcs
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + srcs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -36,7 +36,7 @@ struct RankInfo { double n_total = 0; int64_t row_offset = 0; };
 
 RankInfo rank_info(petal_ctx& c, int64_t n_local) {
     RankInfo r;
-    if (c.world <= 1) { r.n_total = double(n_local); return r; }
+    if (!sharded(c)) { r.n_total = double(n_local); return r; }
     std::vector<double> h(c.world, 0.0);
     h[c.rank] = double(n_local);
     DBuf b(c.dev, sizeof(double) * c.world);
@@ -68,20 +68,28 @@ void column_means(petal_ctx& c, const DevMat& X, double n_total, bool centering,
 
 // svd_flip's decision (pca.rs:826-839) for the columns of a row-sharded U: sign of the first
 // element of maximal magnitude over ALL ranks' rows.  Returns +1/-1 per column.
-// Single rank with `deferred` given: the (absmax, row, value) triple is only QUEUED for the host (no sync here); the
-// caller decodes it with signs_from_triple() after its own dev_sync, so a fit ends with one synchronisation.
 std::vector<double> signs_from_triple(const std::vector<double>& h, int64_t L) {
     std::vector<double> sg(L, 1.0);
+    if (int64_t(h.size()) == L) {  // sharded fp32 path: the winning packed keys, sign in bit 0
+        for (int64_t j = 0; j < L; ++j) {
+            uint64_t bits = 0;
+            std::memcpy(&bits, &h[j], 8);
+            sg[j] = (bits & 1) ? -1.0 : 1.0;
+        }
+        return sg;
+    }
     for (int64_t j = 0; j < L; ++j) sg[j] = h[2 * L + j] < 0 ? -1.0 : 1.0;
     return sg;
 }
+// `deferred` given (single rank, or sharded fp32): the decision data is only QUEUED for the host (no sync here); the
+// caller decodes it with signs_from_triple() after its own dev_sync, so a fit ends with one synchronisation.
 std::vector<double> flip_signs(petal_ctx& c, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu,
                                int64_t row_offset, std::vector<double>* deferred = nullptr) {
     std::vector<double> h(3 * L), sg(L, 1.0);
-    if (L == 0) return sg;
+    if (L == 0) { if (deferred) deferred->assign(3 * L, 0.0); return sg; }
     DBuf r(c.dev, sizeof(double) * 3 * L);
     op_col_absmax(c.dev, dtype, U, n, L, ldu, row_offset, r.f64(), r.f64() + L, r.f64() + 2 * L);
-    if (c.world <= 1) {
+    if (!sharded(c)) {
         if (deferred) {
             deferred->assign(3 * L, 0.0);
             dev_d2h(c.dev, deferred->data(), r.p, r.bytes);
@@ -96,28 +104,18 @@ std::vector<double> flip_signs(petal_ctx& c, int dtype, const void* U, int64_t n
     if (dtype == F32) {
         // ONE all-reduce: |u| of an fp32 value leaves the low 29 mantissa bits of its fp64 image free, so
         // key = |u| with (2^28 - 1 - row, sign) packed into those bits orders by |u| first, then by LOWEST row:
-        // MAX over the ranks picks exactly the element svd_flip would (pca.rs:826-839).  Rows < 2^28.
-        dev_d2h(c.dev, h.data(), r.p, r.bytes);
-        dev_sync(c.dev);
-        for (int64_t j = 0; j < L; ++j) {
-            uint64_t bits = 0;
-            const double a = h[j] < 0 ? 0.0 : h[j];
-            std::memcpy(&bits, &a, 8);
-            const uint64_t row = h[L + j] < double(1ll << 28) ? uint64_t(h[L + j]) : (uint64_t(1) << 28) - 1;
-            const uint64_t payload = (((uint64_t(1) << 28) - 1 - row) << 1) | (h[2 * L + j] < 0 ? 1u : 0u);
-            bits = (bits & ~((uint64_t(1) << 29) - 1)) | (h[j] < 0 ? 0 : payload);  // empty shard (absmax = -1): key 0 loses
-            std::memcpy(&cand[j], &bits, 8);
-        }
-        dev_h2d(c.dev, g.p, cand.data(), g.bytes);
+        // MAX over the ranks picks exactly the element svd_flip would (pca.rs:826-839).  Rows < 2^28.  The key is
+        // packed on the device (op_flip_key), so nothing here waits for the host.
+        op_flip_key(c.dev, r.f64(), g.f64(), L);
         allreduce_f64(c, g.f64(), L, PETAL_MAX);
+        if (deferred) {
+            deferred->assign(L, 0.0);
+            dev_d2h(c.dev, deferred->data(), g.p, g.bytes);
+            return sg;
+        }
         dev_d2h(c.dev, win.data(), g.p, g.bytes);
         dev_sync(c.dev);
-        for (int64_t j = 0; j < L; ++j) {
-            uint64_t bits = 0;
-            std::memcpy(&bits, &win[j], 8);
-            sg[j] = (bits & 1) ? -1.0 : 1.0;
-        }
-        return sg;
+        return signs_from_triple(win, L);
     }
     dev_d2d(c.dev, g.p, r.p, g.bytes);
     allreduce_f64(c, g.f64(), L, PETAL_MAX);
@@ -232,7 +230,7 @@ void finish_stats(petal_ctx& c, const Timer& t) {
 }  // namespace
 
 void allreduce_f64(petal_ctx& c, double* dev_buf, int64_t count, int op) {
-    if (c.world <= 1 || count == 0) return;
+    if (!sharded(c) || count == 0) return;
     if (!c.allreduce) device_error("world_size > 1 but no collective hook installed (petal_ctx_set_collective)");
     int rc = c.allreduce(c.allreduce_user, dev_buf, count, PETAL_F64, op, dev_stream(c.dev));
     if (rc != 0) device_error("collective all-reduce failed with code " + std::to_string(rc));
@@ -452,7 +450,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         dev_sync(c.dev);
         if (attempt == 1 || hdead == 0) break;
     }
-    if (c.world <= 1) sg = signs_from_triple(hflip, LP);
+    if (!hflip.empty()) sg = signs_from_triple(hflip, LP);  // deferred svd_flip decision (single rank / sharded fp32)
     if (tv_from_sq) {  // sum (x - mu)^2 = sum x^2 - n mu^2 per column, in fp64
         htv = 0;
         for (int64_t j = 0; j < d; ++j) htv += std::max(0.0, hmu[dp + j] - ri.n_total * hmu[j] * hmu[j]);

@@ -64,8 +64,18 @@ int petal_ctx_create(int device, void* stream, petal_ctx** out) {
 
 void petal_ctx_destroy(petal_ctx* ctx) {
     if (!ctx) return;
+    try { rccl_release(*ctx); } catch (...) {}
     if (ctx->dev) dev_destroy(ctx->dev);
     delete ctx;
+}
+
+int petal_rccl_unique_id(void* out128) {
+    if (!out128) return PETAL_INVALID_INPUT;
+    try { rccl_unique_id(out128); return PETAL_OK; } catch (const Error& e) { return e.code; } catch (...) { return PETAL_DEVICE_ERROR; }
+}
+
+int petal_ctx_init_rccl(petal_ctx* ctx, const void* unique_id128, int rank, int world_size) {
+    return guarded(ctx, [&] { rccl_init(*ctx, unique_id128, rank, world_size); });
 }
 
 const char* petal_last_error(const petal_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
@@ -74,6 +84,7 @@ int petal_ctx_set_collective(petal_ctx* ctx, petal_allreduce_fn fn, void* user, 
     return guarded(ctx, [&] {
         if (world_size < 1 || rank < 0 || rank >= world_size) invalid_input("bad rank / world_size");
         if (world_size > 1 && !fn) invalid_input("world_size > 1 needs an all-reduce hook");
+        rccl_release(*ctx);
         ctx->allreduce = fn;
         ctx->allreduce_user = user;
         ctx->rank = rank;

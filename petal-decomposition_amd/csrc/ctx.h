@@ -1,6 +1,7 @@
 // ctx.h -- petal_ctx and small host-side helpers shared by algo.cpp / api.cpp.
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -18,6 +19,7 @@ struct petal_ctx {
     int rank = 0, world = 1;
     int profiling = 0;
     petal_stats stats{};
+    void* rccl = nullptr;  // the built-in RCCL communicator (rccl.cpp), when petal_ctx_init_rccl installed it
 };
 
 namespace petal {
@@ -31,6 +33,17 @@ struct Error : std::runtime_error {
 [[noreturn]] inline void device_error(const std::string& m) { throw Error(PETAL_DEVICE_ERROR, m); }
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// true when the fit must take the sharded code path: several ranks, or PETAL_FORCE_COLLECTIVE=1 with a collective
+// installed (runs the complete multi-rank path -- packing kernels, all-reduces -- on a one-rank group: test / timing aid)
+inline bool sharded(const petal_ctx& c) {
+    return c.world > 1 || (c.allreduce != nullptr && std::getenv("PETAL_FORCE_COLLECTIVE") != nullptr);
+}
+
+// rccl.cpp: the built-in collective
+void rccl_unique_id(void* out128);
+void rccl_init(petal_ctx& c, const void* unique_id128, int rank, int world);
+void rccl_release(petal_ctx& c);
 
 // RAII device buffer from the ctx's caching allocator
 struct DBuf {

@@ -2544,6 +2544,22 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     dev_free(d, part);
 }
 
+__global__ void k_flip_key(const double* __restrict__ t, double* __restrict__ key, int64_t L) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= L) return;
+    const double a = t[j] < 0 ? 0.0 : t[j];
+    unsigned long long bits = (unsigned long long)__double_as_longlong(a);
+    const double rw = t[L + j];
+    const unsigned long long row = rw < (double)(1ll << 28) ? (unsigned long long)rw : (1ull << 28) - 1;
+    const unsigned long long payload = ((((1ull << 28) - 1) - row) << 1) | (t[2 * L + j] < 0 ? 1ull : 0ull);
+    bits = (bits & ~((1ull << 29) - 1)) | (t[j] < 0 ? 0ull : payload);
+    key[j] = __longlong_as_double((long long)bits);
+}
+void op_flip_key(Dev* d, const double* triple, double* key, int64_t L) {
+    if (L == 0) return;
+    hipLaunchKernelGGL(k_flip_key, dim3(cdiv(L, 256)), dim3(256), 0, d->stream, triple, key, L);
+    launch_check();
+}
 void op_col_absmax(Dev* d, int dt, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* absmax,
                    double* idx, double* sign) {
     if (L == 0) return;

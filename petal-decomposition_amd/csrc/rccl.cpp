@@ -1,0 +1,107 @@
+// rccl.cpp -- the built-in collective: RCCL all-reduce on the ctx stream, bound at run time.
+//
+// The sample-sharded path only ever all-reduces small replicated fp64 buffers.  A host that does
+// not want a callback in that loop hands the library a ncclUniqueId instead: every rank calls petal_ctx_init_rccl()
+// collectively and the library issues ncclAllReduce itself, in place, on the ctx stream (no host hop, no Python).
+// RCCL is dlopen()ed -- first the copy already mapped into the process (PyTorch-ROCm ships its own librccl next to its
+// own HIP runtime, and two RCCL/HIP runtimes must not be mixed), then the system one -- so libpetal_hip.so carries no
+// link-time dependency on it and the host-simulation build of the same sources loads on a CPU-only machine.
+#include <dlfcn.h>
+
+#include <mutex>
+
+#include "ctx.h"
+
+namespace petal {
+namespace {
+
+struct NcclUniqueId { char internal[128]; };  // ncclUniqueId (nccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+typedef void* NcclComm;
+enum { kNcclFloat32 = 7, kNcclFloat64 = 8 };                 // ncclDataType_t
+enum { kNcclSum = 0, kNcclMax = 2, kNcclMin = 3 };           // ncclRedOp_t
+
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+    int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, void*) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+
+RcclApi& api() {
+    static RcclApi a;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names)  // the copy the process already uses (e.g. PyTorch's), if any
+            if (!a.handle) a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : paths)
+            if (!a.handle) a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!a.handle) { a.why = "librccl.so not found"; return; }
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.handle, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.handle, "ncclCommInitRank"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.handle, "ncclAllReduce"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
+        if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy) a.why = "librccl.so lacks the nccl* entry points";
+    });
+    return a;
+}
+
+std::string nccl_error(int rc) {
+    RcclApi& a = api();
+    return std::string("RCCL error ") + std::to_string(rc) + (a.GetErrorString ? std::string(": ") + a.GetErrorString(rc) : "");
+}
+
+struct RcclComm { NcclComm comm = nullptr; };
+
+// petal_allreduce_fn: in place on the ctx stream
+int rccl_allreduce(void* user, void* buf, int64_t count, int dtype, int op, void* stream) {
+    RcclComm* c = static_cast<RcclComm*>(user);
+    const int dt = dtype == F32 ? kNcclFloat32 : kNcclFloat64;
+    const int rop = op == PETAL_MAX ? kNcclMax : (op == PETAL_MIN ? kNcclMin : kNcclSum);
+    return api().AllReduce(buf, buf, size_t(count), dt, rop, c->comm, stream);
+}
+
+}  // namespace
+
+void rccl_unique_id(void* out128) {
+    RcclApi& a = api();
+    if (!a.why.empty()) device_error("built-in collective unavailable: " + a.why);
+    NcclUniqueId id;
+    const int rc = a.GetUniqueId(&id);
+    if (rc != 0) device_error(nccl_error(rc));
+    std::memcpy(out128, id.internal, sizeof(id.internal));
+}
+
+void rccl_release(petal_ctx& c) {
+    if (!c.rccl) return;
+    RcclComm* rc = static_cast<RcclComm*>(c.rccl);
+    if (rc->comm && api().CommDestroy) (void)api().CommDestroy(rc->comm);
+    delete rc;
+    c.rccl = nullptr;
+    if (c.allreduce == &rccl_allreduce) { c.allreduce = nullptr; c.allreduce_user = nullptr; c.rank = 0; c.world = 1; }
+}
+
+void rccl_init(petal_ctx& c, const void* unique_id128, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) invalid_input("bad rank / world_size");
+    if (!unique_id128) invalid_input("unique id must not be null");
+    RcclApi& a = api();
+    if (!a.why.empty()) device_error("built-in collective unavailable: " + a.why);
+    rccl_release(c);
+    NcclUniqueId id;
+    std::memcpy(id.internal, unique_id128, sizeof(id.internal));
+    RcclComm* rc = new RcclComm();
+    const int e = a.CommInitRank(&rc->comm, world, id, rank);  // collective: every rank is in here together
+    if (e != 0) { delete rc; device_error(nccl_error(e)); }
+    c.rccl = rc;
+    c.allreduce = &rccl_allreduce;
+    c.allreduce_user = rc;
+    c.rank = rank;
+    c.world = world;
+}
+
+}  // namespace petal

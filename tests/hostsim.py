@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "_build", "libpetal_hostsim.so")
 SRCS = [os.path.join(ROOT, "petal-decomposition_amd", "csrc", "api.cpp"),
         os.path.join(ROOT, "petal-decomposition_amd", "csrc", "algo.cpp"),
+        os.path.join(ROOT, "petal-decomposition_amd", "csrc", "rccl.cpp"),
         os.path.join(ROOT, "oracle", "cpu_ops.cpp")]
 HDRS = [os.path.join(ROOT, "petal-decomposition_amd", "csrc", h) for h in ("ops.h", "ctx.h")] + \
        [os.path.join(ROOT, "include", "petal_hip.h")]
@@ -19,7 +20,7 @@ def build() -> str:
     newest = max(os.path.getmtime(p) for p in SRCS + HDRS)
     if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
         tmp = OUT + f".{os.getpid()}.tmp"
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + SRCS)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + SRCS + ["-ldl"])
         os.replace(tmp, OUT)
     return OUT
 

@@ -108,3 +108,45 @@ def test_rccl_allreduce_hook_single_rank(ctx):
         c2.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_builtin_rccl_collective_single_rank(ctx):
+    """The library's own collective (petal_ctx_init_rccl: ncclAllReduce on the ctx stream, RCCL bound with dlopen) on a
+    one-rank communicator, with PETAL_FORCE_COLLECTIVE routing the fit through the complete sharded code path (rank
+    info, fused [G | Yp] all-reduces, device-packed svd_flip key).  A one-rank all-reduce is the identity, so the
+    sharded path must reproduce the plain fit."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    import petal_decomposition_amd as petal
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        x = pc.po.synth_pca(4000, 64, 8, seed=11, dtype=np.float32)
+        omega = np.random.default_rng(5).standard_normal((64, 18)).astype(np.float32)
+        ref = petal.RandomizedPca(8, ctx=ctx, n_iter=3)
+        ref.fit(x, omega=omega)
+        for how in ("rccl", "torch"):
+            c2 = petal.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+            if how == "rccl":
+                c2.use_rccl()
+            else:
+                c2.use_torch_distributed()
+            os.environ["PETAL_FORCE_COLLECTIVE"] = "1"
+            try:
+                m = petal.RandomizedPca(8, ctx=c2, n_iter=3)
+                m.fit(x, omega=omega)
+                ica = petal.FastIca(np.random.default_rng(1), c2, n_components=4)
+                ica.fit(x)
+            finally:
+                del os.environ["PETAL_FORCE_COLLECTIVE"]
+            np.testing.assert_allclose(m.components(), ref.components(), rtol=0, atol=2e-6)
+            np.testing.assert_allclose(m.singular_values(), ref.singular_values(), rtol=1e-6)
+            np.testing.assert_allclose(m.explained_variance_ratio(), ref.explained_variance_ratio(), rtol=1e-5)
+            assert ica.n_iter >= 1
+            c2.close()
+    finally:
+        dist.destroy_process_group()
