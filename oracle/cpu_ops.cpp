@@ -40,6 +40,7 @@ void dev_copy2d(Dev*, void* dst, size_t dpitch, const void* src, size_t spitch, 
 void dev_sync(Dev*) {}
 void dev_set_profiling(Dev*, int) {}
 void dev_abort(Dev*) {}
+void dev_make_current(Dev*) {}
 void dev_reset_timing(Dev*) {}
 void dev_set_tag(Dev* d, int tag) { d->tag = tag; }
 KernelTiming dev_timing(Dev*) { return KernelTiming{}; }

@@ -116,6 +116,7 @@ void dev_destroy(Dev* d) {
 }
 
 void* dev_stream(Dev* d) { return d->stream; }
+void dev_make_current(Dev* d) { HIP_CHECK(hipSetDevice(d->device)); }
 
 void* dev_alloc(Dev* d, size_t bytes) {
     const size_t sz = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;

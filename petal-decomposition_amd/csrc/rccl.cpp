@@ -7,7 +7,9 @@
 // own HIP runtime, and two RCCL/HIP runtimes must not be mixed), then the system one -- so libpetal_hip.so carries no
 // link-time dependency on it and the host-simulation build of the same sources loads on a CPU-only machine.
 #include <dlfcn.h>
+#include <link.h>
 
+#include <cstdio>
 #include <mutex>
 
 #include "ctx.h"
@@ -27,19 +29,29 @@ struct RcclApi {
     int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, void*) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
-    std::string why;
+    std::string why, path;
 };
+
+// the librccl the process has ALREADY mapped (e.g. the one PyTorch-ROCm bundles), by walking the loaded objects
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+    if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl.so")) {
+        *static_cast<std::string*>(out) = info->dlpi_name;
+        return 1;
+    }
+    return 0;
+}
 
 RcclApi& api() {
     static RcclApi a;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {"librccl.so.1", "librccl.so"};
-        for (const char* n : names)  // the copy the process already uses (e.g. PyTorch's), if any
-            if (!a.handle) a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        std::string loaded;
+        dl_iterate_phdr(find_loaded_rccl, &loaded);
+        if (!loaded.empty()) a.handle = dlopen(loaded.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (a.handle) a.path = loaded;
         const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char* n : paths)
-            if (!a.handle) a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!a.handle) { a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (a.handle) a.path = n; }
         if (!a.handle) { a.why = "librccl.so not found"; return; }
         a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.handle, "ncclGetUniqueId"));
         a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.handle, "ncclCommInitRank"));
@@ -92,6 +104,7 @@ void rccl_init(petal_ctx& c, const void* unique_id128, int rank, int world) {
     RcclApi& a = api();
     if (!a.why.empty()) device_error("built-in collective unavailable: " + a.why);
     rccl_release(c);
+    dev_make_current(c.dev);  // the communicator binds to the calling thread's current device
     NcclUniqueId id;
     std::memcpy(id.internal, unique_id128, sizeof(id.internal));
     RcclComm* rc = new RcclComm();
@@ -102,6 +115,7 @@ void rccl_init(petal_ctx& c, const void* unique_id128, int rank, int world) {
     c.allreduce_user = rc;
     c.rank = rank;
     c.world = world;
+    if (std::getenv("PETAL_DEBUG")) std::fprintf(stderr, "[petal] rank %d/%d: built-in collective on %s\n", rank, world, a.path.c_str());
 }
 
 }  // namespace petal
