@@ -8,11 +8,12 @@ tail -- over one synthetic batch that is already resident in HBM.  Workload at N
 exchange is the all-reduce of the small replicated matrices (RCCL through torch.distributed).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant power-iteration GEMM kernel: algorithmic flops per launch / average launch
-                duration measured with HIP events on the launch stream inside the timed region
+  roofline      the dominant power-iteration GEMM kernel: algorithmic bytes (default split-product mode: the kernel
+                is paced by the X stream, bound "hbm") or flops (--gemm fp32: bound "mfma") per launch / average
+                launch duration measured with HIP events on the launch stream inside the timed region
   cpu_baseline  the numpy/LAPACK oracle ("port") timed on this box's host cores on the same workload
-and two informational ones (northstar_gemm: the two GEMM kernels alone at 1e6 x 512; host_in: fit() fed a
-host ndarray, PCIe included -- never `value`).
+and informational ones (fp32_mfma_mode: the same fit on the fp32-MFMA kernels; northstar_gemm: the two GEMM kernels
+alone at 1e6 x 512 in both modes; fastica_cfg3; host_in: fit() fed a host ndarray, PCIe included -- never `value`).
 """
 import argparse
 import json
@@ -27,6 +28,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 HBM_PEAK_GBS = 8000.0
 
 
@@ -40,6 +42,9 @@ def main():
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--n-iter", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="how the X-streaming GEMM kernels form fp32 products: exact 3-way bf16 split on the bf16 matrix "
+                         "cores with fp32 accumulation (default, fp32-equivalent) or fp32 MFMA (petal_ctx_set_gemm_mode)")
     ap.add_argument("--collective", choices=["auto", "rccl", "torch"], default="auto",
                     help="N > 1: the library's built-in RCCL all-reduce (petal_ctx_init_rccl), or the torch.distributed "
                          "hook; auto = built-in, falling back to the hook if RCCL cannot be bound")
@@ -97,6 +102,7 @@ def main():
         if collective.startswith("torch"):
             ctx.use_torch_distributed()
     ctx.set_profiling(True)
+    ctx.set_gemm_mode(args.gemm)
     model = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter)
 
     def sync_all():
@@ -125,28 +131,11 @@ def main():
     out = None
     if rank == 0:
         # dominant kernel = the power-iteration GEMM kind with the larger summed time
-        kinds = {"K1 k_xp_* (Z = Xc.P)": (acc["xp_ms"], acc["xp_launches"]),
-                 "K2 k_atb_mfma (Y = Xc^T.Z)": (acc["atb_ms"], acc["atb_launches"])}
+        kinds = {"K1 (Z = Xc.P)": (acc["xp_ms"], acc["xp_launches"]),
+                 "K2 (Y = Xc^T.Z)": (acc["atb_ms"], acc["atb_launches"])}
         per = {kname: (ms / max(cnt, 1)) for kname, (ms, cnt) in kinds.items()}
         dom = max(kinds, key=lambda kname: kinds[kname][0])
-        avg_ms = per[dom]
-        achieved = pass_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = args.pmc_traffic
-        if traffic is None:  # PMC passes cannot run inside the timed bench: use the committed rocprofv3 measurement
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                    pmc = json.load(f)
-                traffic = pmc[f"{n}x{d} l={l}"][dom.split(" ")[0]]["hbm_bytes_corrected"]
-            except Exception:
-                traffic = None
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4),
-                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
-                    "flops_per_launch": pass_flops, "bytes_per_launch": pass_bytes,
-                    "hbm_GBps_algorithmic": round(pass_bytes / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
-                    "other_kernel": {kname: {"avg_launch_ms": round(v, 5),
-                                             "TFLOP/s": round(pass_flops / (v * 1e-3) / 1e12, 3) if v > 0 else 0.0}
-                                     for kname, v in per.items() if kname != dom}}
+        roofline = roofline_entry(dom, per, pass_flops, pass_bytes, args.gemm, args.pmc_traffic, n, d, l)
         out = {
             "metric": "samples/sec for RandomizedPca.fit() on n x d fp32",
             "value": round(world * n * args.steps / elapsed, 1),
@@ -158,6 +147,9 @@ def main():
             "config": {"workload": f"RandomizedPca.fit k={k} n_iter={n_iter} oversample=10 on {n}x{d} fp32 per GPU "
                                    f"(BASELINE configs[1]), X resident in HBM",
                        "rows_per_gpu": n, "features": d, "n_components": k, "n_iter": n_iter,
+                       "gemm_mode": ("bf16x3: fp32 operands split exactly into 3 bf16 pieces, 6 piece products on the bf16 "
+                                     "matrix cores, fp32 accumulation (fp32-equivalent)") if args.gemm == "bf16x3"
+                                    else "fp32 MFMA (v_mfma_f32_16x16x4_f32)",
                        "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU",
                        "collective": collective},
             "roofline": roofline,
@@ -173,8 +165,12 @@ def main():
             out["host_in"] = {"value": round(n * reps / (time.perf_counter() - t1), 1), "unit": "samples/s",
                               "note": "fit() fed a pageable host ndarray: PCIe H2D inside the timed region"}
 
+        if world == 1 and args.gemm == "bf16x3" and not args.no_northstar:
+            out["fp32_mfma_mode"] = fp32_mode_extra(petal, ctx, model, x, omega)
+
         if world == 1 and not args.no_northstar:
             out["northstar_gemm"] = northstar(petal, ctx, torch, dev)
+            ctx.set_gemm_mode(args.gemm)
 
         if world == 1 and not args.no_northstar:
             out["fastica_cfg3"] = fastica_cfg3(petal, ctx, torch, dev)
@@ -187,6 +183,63 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(n, d, l, mode, kind):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (PMC passes cannot run inside the timed bench)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)[f"{n}x{d} l={l}"][mode][kind]["hbm_bytes_corrected"]
+    except Exception:
+        return None
+
+
+def roofline_entry(dom, per, pass_flops, pass_bytes, mode, traffic_override, n, d, l):
+    """The `roofline` object of the bench line for the dominant kernel `dom`.
+    fp32 mode: the kernels issue v_mfma_f32_16x16x4_f32 -> bound "mfma", achieved = algorithmic flops / duration vs the
+    157.3 TFLOP/s fp32-MFMA peak.  bf16x3 (split-product) mode: the same products take 2.7x less matrix-pipe time on the
+    bf16 cores and the kernels are paced by the X stream -> bound "hbm", achieved = algorithmic bytes / duration vs
+    8 TB/s; the fp32-equivalent flop rate is kept alongside for comparison with the fp32 mode."""
+    avg_ms = per[dom]
+    tf = pass_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    gbs = pass_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = traffic_override if traffic_override is not None else pmc_traffic(n, d, l, mode, dom.split(" ")[0])
+    other = {kname: {"avg_launch_ms": round(v, 5), "GB/s_algorithmic": round(pass_bytes / (v * 1e-3) / 1e9, 1) if v > 0 else 0.0,
+                     "fp32_equivalent_TFLOP/s": round(pass_flops / (v * 1e-3) / 1e12, 3) if v > 0 else 0.0}
+             for kname, v in per.items() if kname != dom}
+    common = {"kernel": dom + (" k_xp3 / k_atb3 (bf16x3 split-product, fp32 accumulate)" if mode == "bf16x3"
+                               else " k_xp_* / k_atb_mfma (fp32 MFMA)"),
+              "traffic": traffic, "avg_launch_ms": round(avg_ms, 5), "flops_per_launch": pass_flops,
+              "bytes_per_launch": pass_bytes, "other_kernel": other}
+    if mode == "bf16x3":
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                **common, "fp32_equivalent_TFLOP/s": round(tf, 3),
+                "fp32_equivalent_frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TF, 4)}
+    return {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(tf / FP32_MFMA_PEAK_TF, 4), **common, "hbm_GBps_algorithmic": round(gbs, 1)}
+
+
+def fp32_mode_extra(petal, ctx, model, x, omega, steps=10):
+    """The same fit with the fp32-MFMA kernels (petal_ctx_set_gemm_mode): informational, next to the default mode."""
+    ctx.set_gemm_mode("fp32")
+    try:
+        for _ in range(3):
+            model.fit(x, omega=omega)
+        acc = {"xp_ms": 0.0, "xp_launches": 0, "atb_ms": 0.0, "atb_launches": 0}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.fit(x, omega=omega)
+            st = ctx.stats()
+            for key in acc:
+                acc[key] += st[key]
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        ctx.set_gemm_mode("bf16x3")
+    k1, k2 = acc["xp_ms"] / max(acc["xp_launches"], 1), acc["atb_ms"] / max(acc["atb_launches"], 1)
+    fl = st["pass_flops"]
+    return {"ms_per_step": round(ms, 4), "samples_per_s": round(x.shape[0] / (ms * 1e-3), 1),
+            "K1": {"avg_launch_ms": round(k1, 5), "TFLOP/s": round(fl / (k1 * 1e-3) / 1e12, 2), "frac_of_fp32_mfma_peak": round(fl / (k1 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)},
+            "K2": {"avg_launch_ms": round(k2, 5), "TFLOP/s": round(fl / (k2 * 1e-3) / 1e12, 2), "frac_of_fp32_mfma_peak": round(fl / (k2 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}}
+
+
 def northstar(petal, ctx, torch, dev, n=1_000_000, d=512, l=74, reps=5):
     """The north-star point: the two power-iteration GEMM kernels alone on a 1e6 x 512 fp32 matrix
     (2.05 GB, beyond the 256 MiB Infinity Cache), l = 74."""
@@ -197,20 +250,28 @@ def northstar(petal, ctx, torch, dev, n=1_000_000, d=512, l=74, reps=5):
     z[:, l:] = 0
     p = np.random.default_rng(7).standard_normal((d, l)).astype(np.float32)
     mu = np.random.default_rng(8).standard_normal(d).astype(np.float32)
-    res = {"shape": f"{n}x{d} fp32, l={l}", "flops_per_launch": 2.0 * n * d * l}
-    for name, fn, key in (("K1", lambda: petal.gemm_xp(x, p, mu, ctx=ctx), "xp"),
-                          ("K2", lambda: petal.gemm_atb(x, z, mu, ctx=ctx), "atb")):
-        fn()
-        ms, cnt = 0.0, 0
-        for _ in range(reps):
+    res = {"shape": f"{n}x{d} fp32, l={l}", "flops_per_launch": 2.0 * n * d * l,
+           "bytes_per_launch": 4.0 * (n * d + n * l + d * l)}
+    for mode in ("bf16x3", "fp32"):
+        ctx.set_gemm_mode(mode)
+        res[mode] = {}
+        for name, fn, key in (("K1", lambda: petal.gemm_xp(x, p, mu, ctx=ctx), "xp"),
+                              ("K2", lambda: petal.gemm_atb(x, z, mu, ctx=ctx), "atb")):
             fn()
-            st = ctx.stats()
-            ms += st[key + "_ms"]
-            cnt += st[key + "_launches"]
-        avg = ms / max(cnt, 1)
-        tf = 2.0 * n * d * l / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
-        res[name] = {"avg_launch_ms": round(avg, 4), "TFLOP/s": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TF, 4),
-                     "GB/s_algorithmic": round(4.0 * (n * d + n * l + d * l) / (avg * 1e-3) / 1e9, 1) if avg > 0 else 0.0}
+            ms, cnt = 0.0, 0
+            for _ in range(reps):
+                fn()
+                st = ctx.stats()
+                ms += st[key + "_ms"]
+                cnt += st[key + "_launches"]
+            avg = ms / max(cnt, 1)
+            tf = 2.0 * n * d * l / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+            gbs = 4.0 * (n * d + n * l + d * l) / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+            res[mode][name] = {"avg_launch_ms": round(avg, 4), "GB/s_algorithmic": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                               "fp32_equivalent_TFLOP/s" if mode == "bf16x3" else "TFLOP/s": round(tf, 2),
+                               "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TF, 4),
+                               "hbm_bytes_pmc": pmc_traffic(n, d, l, mode, name)}
+    ctx.set_gemm_mode("bf16x3")
     del x, z
     torch.cuda.empty_cache()
     return res

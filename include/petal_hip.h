@@ -87,6 +87,14 @@ int         petal_ctx_init_rccl(petal_ctx* ctx, const void* unique_id128, int ra
  * fit to fit, so K fits sample every launch position; keeps the event bubbles out of the fit time); 2 = every launch.
  * petal_stats.*_ms / *_launches count the bracketed launches only. */
 int         petal_ctx_set_profiling(petal_ctx* ctx, int profiling);
+/* How the two X-streaming GEMM kernels of fp32 fits form their products (results agree to fp32 accumulation noise):
+ *   PETAL_GEMM_SPLIT_BF16X3 (default): every fp32 operand is split exactly into three bf16 pieces and the product is the
+ *     sum of the six piece products of weight >= 2^-16, on the bf16 matrix cores with fp32 accumulation (dropped terms
+ *     <= 2^-24 relative, below one fp32 rounding); 2.7x less matrix-pipe time, the kernels become HBM-bound;
+ *   PETAL_GEMM_FP32_MFMA: v_mfma_f32_16x16x4_f32, exact fp32 products.  Env PETAL_GEMM=fp32 selects it at ctx creation. */
+#define PETAL_GEMM_SPLIT_BF16X3 0
+#define PETAL_GEMM_FP32_MFMA 1
+int         petal_ctx_set_gemm_mode(petal_ctx* ctx, int mode);
 int         petal_get_stats(const petal_ctx* ctx, petal_stats* out);
 
 /* ---- Pca<A>::fit / fit_transform  (src/pca.rs:116-122, 153-167, 195-231) ---------------------- */

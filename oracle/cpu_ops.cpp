@@ -41,6 +41,8 @@ void dev_sync(Dev*) {}
 void dev_set_profiling(Dev*, int) {}
 void dev_abort(Dev*) {}
 void dev_make_current(Dev*) {}
+void dev_set_gemm_mode(Dev*, int) {}
+int dev_gemm_mode(const Dev*) { return 1; }
 void dev_reset_timing(Dev*) {}
 void dev_set_tag(Dev* d, int tag) { d->tag = tag; }
 KernelTiming dev_timing(Dev*) { return KernelTiming{}; }

@@ -25,6 +25,7 @@ PETAL_OK, PETAL_INVALID_INPUT, PETAL_LINALG_ERROR, PETAL_DEVICE_ERROR = 0, 1, 2,
 PETAL_F32, PETAL_F64 = 0, 1
 PETAL_HOST, PETAL_DEVICE = 0, 1
 PETAL_SUM, PETAL_MAX, PETAL_MIN = 0, 1, 2
+GEMM_SPLIT_BF16X3, GEMM_FP32_MFMA = 0, 1
 ICA_TEXTBOOK, ICA_REFERENCE_LITERAL = 0, 1
 
 
@@ -80,6 +81,7 @@ ABI = [
     ("petal_version", C.c_char_p, []),
     ("petal_ctx_set_collective", C.c_int, [_P, ALLREDUCE_FN, _P, C.c_int, C.c_int]),
     ("petal_ctx_set_profiling", C.c_int, [_P, C.c_int]),
+    ("petal_ctx_set_gemm_mode", C.c_int, [_P, C.c_int]),
     ("petal_rccl_unique_id", C.c_int, [_P]),
     ("petal_ctx_init_rccl", C.c_int, [_P, _P, C.c_int, C.c_int]),
     ("petal_get_stats", C.c_int, [_P, C.POINTER(petal_stats)]),
@@ -233,6 +235,12 @@ class Context:
     def set_profiling(self, level):
         """0/False off, 1/True one sampled launch of each hot kernel per fit, 2 every launch (petal_hip.h)."""
         self.check(self.lib.petal_ctx_set_profiling(self._h, int(level)))
+
+    def set_gemm_mode(self, mode):
+        """GEMM_SPLIT_BF16X3 (default) or GEMM_FP32_MFMA; also accepts "bf16x3" / "fp32" (petal_hip.h)."""
+        if isinstance(mode, str):
+            mode = {"bf16x3": GEMM_SPLIT_BF16X3, "fp32": GEMM_FP32_MFMA}[mode]
+        self.check(self.lib.petal_ctx_set_gemm_mode(self._h, int(mode)))
 
     def stats(self) -> dict:
         s = petal_stats()

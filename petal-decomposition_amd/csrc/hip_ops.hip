@@ -54,6 +54,7 @@ struct Dev {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    int gemm_mode = [] { const char* e = getenv("PETAL_GEMM"); return (e && std::string(e) == "fp32") ? 1 : 0; }();
     int profiling = 0;  // 0 off, 1 = time ONE launch per tag and fit (rotating over the launches), 2 = every launch
     int tag = 0;
     int tag_seen[TAG_COUNT] = {};    // tagged launches so far in this fit
@@ -197,6 +198,8 @@ void dev_sync(Dev* d) {
     drain_pending(d);
 }
 void dev_set_profiling(Dev* d, int level) { d->profiling = level; }
+void dev_set_gemm_mode(Dev* d, int mode) { d->gemm_mode = mode; }
+int dev_gemm_mode(const Dev* d) { return d->gemm_mode; }
 void dev_set_tag(Dev* d, int tag) { d->tag = tag; }
 
 static hipEvent_t get_event(Dev* d) {
@@ -740,6 +743,189 @@ __global__ __launch_bounds__(512, 2) void k_xp_pers(const float* __restrict__ X,
 }
 
 // ================================================================================================
+// K1, split-product form ("bf16x3"): every fp32 operand is split EXACTLY into three bf16 pieces, x = x_h + x_m + x_l
+// (8 + 8 + 8 significant bits), and the product x p is formed from the six piece products of weight >= 2^-16,
+//   x_h p_h + (x_h p_m + x_m p_h) + (x_h p_l + x_m p_m + x_l p_h),
+// on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16: exact bf16 x bf16 products, fp32 accumulation).  The three dropped
+// terms are <= 2^-24 |x p| relative -- below the rounding of ONE fp32 multiply -- so the result matches the fp32-MFMA
+// kernel to within fp32 accumulation noise (measured: 4e-8 of the mean |z| vs 3e-6 accumulation error of a plain fp32
+// GEMM at K = 512), while the matrix pipe does 6 bf16 MFMAs of 16 cycles per 16 x 16 x 32 block instead of 8 fp32 MFMAs of
+// 32: 2.7x less matrix time, which turns K1 from MFMA-bound into HBM-bound.
+// Layout: one wave = 64 rows x NT column tiles, K in 32-deep chunks.  X goes HBM -> VGPR (two 16-B loads per lane and
+// row tile: X[row][32 c + 8 q .. + 7], which IS the 16x16x32 operand layout), is centred and split in registers; the
+// three planes of P are pre-split by k_pack_p3 and staged chunk by chunk through LDS by the workgroup (double buffered,
+// one barrier per chunk) so the four waves share them.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // one v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+// written pair-wise so hipcc emits packed converts (12), shifts / masks (16) and packed subtracts (8) per 8 elements;
+// the generic vector conversion costs one convert per ELEMENT
+__device__ __forceinline__ void split3(const f32x8 x, bf16x8& h, bf16x8& m, bf16x8& l) {
+    u32x4 hh, mm, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = x[2 * e], x1 = x[2 * e + 1];
+        hh[e] = cvt_pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(hh[e] << 16), r1 = x1 - __uint_as_float(hh[e] & 0xffff0000u);
+        mm[e] = cvt_pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(mm[e] << 16), s1 = r1 - __uint_as_float(mm[e] & 0xffff0000u);
+        ll[e] = cvt_pk_bf16(s0, s1);
+    }
+    h = __builtin_bit_cast(bf16x8, hh);
+    m = __builtin_bit_cast(bf16x8, mm);
+    l = __builtin_bit_cast(bf16x8, ll);
+}
+// Ppk3[((c NTtot + nt) 3 + plane) 64 + lane][e] = plane of (float)P[32 c + 8 (lane >> 4) + e][16 nt + (lane & 15)]
+__global__ __launch_bounds__(256) void k_pack_p3(const double* __restrict__ P, int64_t K, int64_t N, int64_t ldp,
+                                                 bf16x8* __restrict__ out, int NTtot, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int64_t tile = idx >> 6;
+    const int nt = (int)(tile % NTtot);
+    const int64_t c = tile / NTtot;
+    const int64_t col = 16 * nt + (lane & 15), k0 = 32 * c + 8 * (lane >> 4);
+    f32x8 x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (k0 + e < K && col < N) ? (float)P[(k0 + e) * ldp + col] : 0.f;
+    bf16x8 h, m, l;
+    split3(x, h, m, l);
+    out[(tile * 3 + 0) * 64 + lane] = h;
+    out[(tile * 3 + 1) * 64 + lane] = m;
+    out[(tile * 3 + 2) * 64 + lane] = l;
+}
+#ifndef PETAL_XP3_RT
+#define PETAL_XP3_RT 4      // row tiles per wave
+#define PETAL_XP3_DEPTH 1   // raw X chunks in flight per wave (2 measured slower)
+#define PETAL_XP3_OCC 2     // waves per SIMD the register budget is cut for
+#endif
+template <int RT, int NT, int DEPTH, bool CENTER>
+__global__ __launch_bounds__(256, PETAL_XP3_OCC) void k_xp3(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
+                                                            const float* __restrict__ mu, const bf16x8* __restrict__ Ppk3,
+                                                            int NTtot, int nt0, int N, const float* __restrict__ bias,
+                                                            float* __restrict__ Z, int64_t ldz) {
+    constexpr int PITEMS = NT * 192;               // 16-B items of one P chunk (NT tiles x 3 planes x 64 lanes)
+    constexpr int PI = (PITEMS + 255) / 256;       // per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_xp3[];
+    bf16x8* sP = reinterpret_cast<bf16x8*>(sm_xp3);                        // [2][PITEMS]
+    float* sMu = reinterpret_cast<float*>(sm_xp3 + sizeof(bf16x8) * 2 * PITEMS);  // [32 nchunk] (zero padded)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+    const int nchunk = (K + 31) >> 5;
+    if (CENTER)
+        for (int k = tid; k < 32 * nchunk; k += 256) sMu[k] = k < K ? mu[k] : 0.f;
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xrow[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int64_t r = row0 + 16 * t + i;
+        xrow[t] = X + (r < n ? r : (n - 1)) * ldx + 8 * q;
+    }
+    const bf16x8* psrc = Ppk3 + (int64_t)nt0 * 192 + tid;
+    auto load_a = [&](int c, f32x8(&a)[RT]) {
+        const bool in = 32 * c + 8 * q < K;  // K % 32 == 16: the upper half of the last chunk does not exist
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+            if (in) { lo = ld_stream(xrow[t] + 32 * c); hi = ld_stream(xrow[t] + 32 * c + 4); }
+            a[t] = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+    auto load_p = [&](int c, bf16x8(&pn)[PI]) {
+#pragma unroll
+        for (int it = 0; it < PI; ++it)
+            if (tid + 256 * it < PITEMS) pn[it] = psrc[(int64_t)c * NTtot * 192 + 256 * it];
+    };
+    auto store_p = [&](int buf, const bf16x8(&pn)[PI]) {
+#pragma unroll
+        for (int it = 0; it < PI; ++it)
+            if (tid + 256 * it < PITEMS) sP[buf * PITEMS + tid + 256 * it] = pn[it];
+    };
+    f32x8 a[DEPTH][RT];
+    bf16x8 pn[PI];
+    load_p(0, pn);
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) load_a(s < nchunk ? s : nchunk - 1, a[s]);
+    store_p(0, pn);
+    for (int c0 = 0; c0 < nchunk; c0 += DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            const int c = c0 + s;
+            if (c >= nchunk) break;
+            const int buf = c & 1;
+            __syncthreads();  // chunk c is in sP[buf]; nobody still reads sP[buf ^ 1]
+            // the raw fragments are dead once split: their registers take the loads of chunk c + DEPTH, which then fly
+            // under the MFMAs of DEPTH chunks
+            bf16x8 ah[RT], am[RT], al[RT];
+            {
+                f32x8 m = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (CENTER) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(sMu + 32 * c + 8 * q), hi = *reinterpret_cast<const f32x4*>(sMu + 32 * c + 8 * q + 4);
+                    m = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    if (CENTER) a[s][t] -= m;
+                    split3(a[s][t], ah[t], am[t], al[t]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // P first: its registers are waited for at the end of this chunk, and vmcnt retires in order -- X loads issued
+            // BEFORE it would be drained by that wait, the ones issued after it stay in flight
+            if (c + 1 < nchunk) load_p(c + 1, pn);
+            if (c + DEPTH < nchunk) load_a(c + DEPTH, a[s]);
+            __builtin_amdgcn_sched_barrier(0);
+            // P fragments one tile ahead of the MFMAs that use them (pinned: hoisting all 15 reads costs 48 more registers)
+            const bf16x8* sPb = sP + buf * PITEMS + lane;
+            bf16x8 bh = sPb[0], bm = sPb[64], bl = sPb[128];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                bf16x8 nh = bh, nm = bm, nl = bl;
+                if (u + 1 < NT) { nh = sPb[(u * 3 + 3) * 64]; nm = sPb[(u * 3 + 4) * 64]; nl = sPb[(u * 3 + 5) * 64]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {  // P fragment as the A operand: the accumulator tile is Z^T (16-B stores below)
+                    f32x4 c4 = acc[t][u];
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[t], c4, 0, 0, 0);   // smallest terms first
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[t], c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[t], c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[t], c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[t], c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[t], c4, 0, 0, 0);
+                    acc[t][u] = c4;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bh = nh; bm = nm; bl = nl;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < nchunk) store_p(buf ^ 1, pn);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int col = 16 * (nt0 + u) + 4 * q;
+        if (col >= N) continue;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int64_t row = row0 + 16 * t + i;
+            if (row < n) *reinterpret_cast<f32x4*>(Z + row * ldz + col) = acc[t][u] + bv;
+        }
+    }
+}
+
+// ================================================================================================
 // K2: C = (A - muA)^T . (B - muB)  -- split-K fp32 MFMA over row chunks, fp32 partial slabs
 // ================================================================================================
 // A wave owns 64 columns of A (4 m-tiles) x 16*NT columns of B and a contiguous row chunk.  One 16-B load
@@ -888,6 +1074,130 @@ __global__ __launch_bounds__(256, 2) void k_atb_mfma(const float* __restrict__ A
             for (int e = 0; e < R1; ++e) {
                 const int col = n0col + 64 * G4 + 16 * e + i;
                 if (col < N) out[(int64_t)m * Npart + col] = acc[t][4 * G4 + e][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2, split-product form (see k_xp3 for the arithmetic): C = (A - muA)^T B over a row chunk, K = rows in 32-row stages.
+// A wave owns 64 columns of A (4 m-tiles; lane (i, q) loads A[r0 + 8 q + e][m0 + 4 i .. + 3], e < 8: eight 16-B loads
+// feed the eight k-values of all four tiles) and ALL NT column tiles of B.  The 32 x 16 NT stage of B is shared by the
+// four waves: the workgroup converts it once -- thread <-> one operand item (tile u, lane (j, q): B[r0 + 8 q + e][16 u + j],
+// e < 8), split into three bf16 planes -- into a double-buffered LDS image in MFMA operand order, one barrier per stage.
+// n must be a multiple of 32 here: the host gives the ragged remainder to the fp32 kernel as one more slab.
+template <int NT, bool CA>
+__global__ __launch_bounds__(256, 2) void k_atb3(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
+                                                 const float* __restrict__ B, int64_t ldb, int N, int n0col, int64_t n,
+                                                 int64_t chunk, float* __restrict__ part, int Npart) {
+    constexpr int BITEMS = NT * 64;                       // operand items of one B stage (8 elements each)
+    constexpr bool Z2 = BITEMS > 256;                     // wave 0 carries a second item when NT = 5
+    __shared__ bf16x8 sB[2][NT * 192];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int m0 = (blockIdx.x * 4 + wave) * 64;
+    const int64_t rbeg = (int64_t)blockIdx.y * chunk, rend = min(n, rbeg + chunk);
+    const int nstage = (int)((rend - rbeg) >> 5);
+    // uniform row bases (advance 32 rows per stage) + ONE 32-bit per-lane offset each: no per-load address arithmetic
+    const float* abase = A + rbeg * lda;
+    const float* zbase = B + rbeg * ldb;
+    const unsigned aoff = (unsigned)((int64_t)(8 * q) * lda + min(m0 + 4 * i, M - 4));  // columns beyond M are never stored
+    const int zcol0 = n0col + 16 * (tid >> 6) + i, zcol1 = n0col + 64 + 16 * (tid >> 6) + i;  // items tid and 256 + tid
+    const bool zon0 = (tid >> 6) < NT && zcol0 < N, zon1 = Z2 && wave == 0 && (n0col + 64 + i) < N;
+    const unsigned zoff0 = (unsigned)((int64_t)(8 * q) * ldb + min(zcol0, N - 1));
+    const unsigned zoff1 = (unsigned)((int64_t)(8 * q) * ldb + min(n0col + 64 + i, N - 1));
+    (void)zcol1;
+    f32x4 ma = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (CA) ma = *reinterpret_cast<const f32x4*>(muA + min(m0 + 4 * i, M - 4));
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // every chunk is a whole number of 32-row stages (the host hands the < 32 ragged rows of the matrix to the fp32 kernel)
+    auto load_a = [&](int st, f32x4(&av)[8]) {
+        const float* p = abase + (int64_t)st * 32 * lda;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = ld_stream(p + (int64_t)e * lda + aoff);
+    };
+    auto load_z1 = [&](int st, f32x8& zr, bool on, unsigned zoff) {
+        const float* p = zbase + (int64_t)st * 32 * ldb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zr[e] = p[(int64_t)e * ldb + zoff];  // always a valid address (column clamped)
+        (void)on;
+    };
+    auto stage_z1 = [&](int buf, f32x8 zr, int u, bool on) {
+        if (!on) zr = f32x8{0, 0, 0, 0, 0, 0, 0, 0};  // columns beyond N contribute zeros
+        bf16x8 h, m, l;
+        split3(zr, h, m, l);
+        sB[buf][(u * 3 + 0) * 64 + lane] = h;
+        sB[buf][(u * 3 + 1) * 64 + lane] = m;
+        sB[buf][(u * 3 + 2) * 64 + lane] = l;
+    };
+    f32x4 av[8];
+    f32x8 zr0, zr1 = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (nstage > 0) {
+        if (wave < NT) load_z1(0, zr0, zon0, zoff0);
+        if (Z2 && wave == 0) load_z1(0, zr1, zon1, zoff1);
+        load_a(0, av);
+        if (wave < NT) stage_z1(0, zr0, wave, zon0);
+        if (Z2 && wave == 0) stage_z1(0, zr1, 4, zon1);
+    }
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        __syncthreads();  // stage st of B is in sB[buf]; nobody still reads sB[buf ^ 1]
+        bf16x8 ah[4], am[4], al[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x8 x = f32x8{av[0][t], av[1][t], av[2][t], av[3][t], av[4][t], av[5][t], av[6][t], av[7][t]};
+            if (CA) x -= ma[t];
+            split3(x, ah[t], am[t], al[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < nstage) {  // fly under this stage's MFMAs; B first (vmcnt retires in order, see k_xp3)
+            if (wave < NT) load_z1(st + 1, zr0, zon0, zoff0);
+            if (Z2 && wave == 0) load_z1(st + 1, zr1, zon1, zoff1);
+            load_a(st + 1, av);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // B fragments one tile ahead of the MFMAs that use them (pinned: hoisting all 15 reads costs 48 more registers)
+        bf16x8 bh = sB[buf][0 * 64 + lane], bm = sB[buf][1 * 64 + lane], bl = sB[buf][2 * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            bf16x8 nh = bh, nm = bm, nl = bl;
+            if (u + 1 < NT) { nh = sB[buf][(u * 3 + 3) * 64 + lane]; nm = sB[buf][(u * 3 + 4) * 64 + lane]; nl = sB[buf][(u * 3 + 5) * 64 + lane]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 c4 = acc[t][u];
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bh, c4, 0, 0, 0);   // smallest terms first
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bm, c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bl, c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bh, c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bm, c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bh, c4, 0, 0, 0);
+                acc[t][u] = c4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bh = nh; bm = nm; bl = nl;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < nstage) {
+            if (wave < NT) stage_z1(buf ^ 1, zr0, wave, zon0);
+            if (Z2 && wave == 0) stage_z1(buf ^ 1, zr1, 4, zon1);
+        }
+    }
+    // D[row = 4 q + r][col = i] of tile (t, u):  m = m0 + 4 (4 q + r) + t,  col = n0col + 16 u + i
+    float* out = part + (int64_t)blockIdx.y * M * Npart;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * (4 * q + r) + t;
+            if (m >= M) continue;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int col = n0col + 16 * u + i;
+                if (col < N) out[(int64_t)m * Npart + col] = acc[t][u][r];
             }
         }
 }
@@ -2339,6 +2649,9 @@ void op_colsum(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// split-product (bf16x3, see k_xp3) kernels unless the ctx asks for the fp32-MFMA ones (petal_ctx_set_gemm_mode /
+// PETAL_GEMM=fp32)
+static bool gemm_split_product(const Dev* d) { return d->gemm_mode == 0; }
 
 template <int RT, int NT>
 static void launch_xp(Dev* d, const float* X, int64_t n, int K, int64_t ldx, const float* mu, const float* Ppk, int NTtot,
@@ -2373,6 +2686,40 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
         return;
     }
     const int NTtot = cdiv(N, 16);
+    if (gemm_split_product(d) && !sumsq) {
+        // split-product (bf16x3) form: grid of 64-row wave tiles, column panels of <= 5 tiles
+        const int64_t nch = (K + 31) / 32, total = nch * NTtot * 64;
+        bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
+        hipLaunchKernelGGL(k_pack_p3, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk3, NTtot, total);
+        launch_check();
+        constexpr int RTv = PETAL_XP3_RT, DPv = PETAL_XP3_DEPTH;
+        const int blocks = cdiv(n, 64 * RTv);
+        const float* Xf = (const float*)X; const float* muf = (const float*)mu; const float* bf = (const float*)bias; float* Zf = (float*)Z;
+        TagScope ts(d);
+        for (int nt0 = 0; nt0 < NTtot;) {
+            const int rem = NTtot - nt0;
+            const int w = rem >= 5 ? 5 : rem;
+            const size_t lds = sizeof(bf16x8) * 2 * w * 192 + sizeof(float) * 32 * nch;
+#define XP3_LAUNCH(NTv)                                                                                                                     \
+            do {                                                                                                                            \
+                if (muf) hipLaunchKernelGGL((k_xp3<RTv, NTv, DPv, true>), dim3(blocks), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
+                else hipLaunchKernelGGL((k_xp3<RTv, NTv, DPv, false>), dim3(blocks), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
+            } while (0)
+            switch (w) {
+                case 5: XP3_LAUNCH(5); break;
+                case 4: XP3_LAUNCH(4); break;
+                case 3: XP3_LAUNCH(3); break;
+                case 2: XP3_LAUNCH(2); break;
+                default: XP3_LAUNCH(1); break;
+            }
+#undef XP3_LAUNCH
+            launch_check();
+            nt0 += w;
+        }
+        ts.stop();
+        dev_free(d, Ppk3);
+        return;
+    }
     float* Ppk = (float*)dev_alloc(d, sizeof(float) * (K / 16) * NTtot * 64 * 4);
     {
         const int64_t total = (K / 16) * (int64_t)NTtot * 64;
@@ -2520,9 +2867,13 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     int64_t nsplit = std::max<int64_t>(1, waves_target / mslices);
     nsplit = std::min<int64_t>(nsplit, 256);  // bounds the partial-slab traffic of narrow (Gram) products
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 64));
-    const int64_t chunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
-    nsplit = (n + chunk - 1) / chunk;
-    float* part = (float*)dev_alloc(d, sizeof(float) * nsplit * M * N);
+    const bool split3_mode = gemm_split_product(d) && !muB && n >= 32 * nsplit;
+    const int64_t cq = split3_mode ? 32 : 16;  // rows per pipeline stage
+    const int64_t n_main = split3_mode ? n / 32 * 32 : n, n_tail = n - n_main;  // split-product kernel: whole 32-row stages
+    const int64_t chunk = ((n_main + nsplit - 1) / nsplit + cq - 1) / cq * cq;
+    nsplit = (n_main + chunk - 1) / chunk;
+    const int64_t nslab = nsplit + (n_tail ? 1 : 0);
+    float* part = (float*)dev_alloc(d, sizeof(float) * nslab * M * N);
     const int NTtot = int(N / 16);
     TagScope ts(d);
     for (int nt0 = 0; nt0 < NTtot;) {
@@ -2530,6 +2881,36 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         const int w = rem >= 5 ? 5 : rem;
         const float* Af = (const float*)A; const float* Bf = (const float*)B;
         const float* ma = (const float*)muA; const float* mb = (const float*)muB;
+        if (split3_mode) {
+            const dim3 grid(cdiv(M, 256), (unsigned)nsplit), block(256);
+#define ATB3_LAUNCH(NTv)                                                                                                              \
+            do {                                                                                                                      \
+                if (ma) hipLaunchKernelGGL((k_atb3<NTv, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+                else hipLaunchKernelGGL((k_atb3<NTv, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+            } while (0)
+            switch (w) {
+                case 5: ATB3_LAUNCH(5); break;
+                case 4: ATB3_LAUNCH(4); break;
+                case 3: ATB3_LAUNCH(3); break;
+                case 2: ATB3_LAUNCH(2); break;
+                default: ATB3_LAUNCH(1); break;
+            }
+#undef ATB3_LAUNCH
+            launch_check();
+            if (n_tail) {  // the < 32 ragged rows: one more slab from the fp32 kernel
+                const float* At = Af + n_main * lda; const float* Bt = Bf + n_main * ldb;
+                float* pt = part + nsplit * M * N;
+                switch (w) {
+                    case 5: launch_atb<5>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 32, pt, 1); break;
+                    case 4: launch_atb<4>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 32, pt, 1); break;
+                    case 3: launch_atb<3>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 32, pt, 1); break;
+                    case 2: launch_atb<2>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 32, pt, 1); break;
+                    default: launch_atb<1>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 32, pt, 1); break;
+                }
+            }
+            nt0 += w;
+            continue;
+        }
         switch (w) {
             case 5: launch_atb<5>(d, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, mb, n, chunk, part, (int)nsplit); break;
             case 4: launch_atb<4>(d, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, mb, n, chunk, part, (int)nsplit); break;
@@ -2540,7 +2921,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         nt0 += w;
     }
     ts.stop();
-    hipLaunchKernelGGL(k_sum_parts2<float>, dim3(cdiv(M * N, 32)), dim3(256), 0, d->stream, part, nsplit, M * N, C, N, ldc, false);
+    hipLaunchKernelGGL(k_sum_parts2<float>, dim3(cdiv(M * N, 32)), dim3(256), 0, d->stream, part, nslab, M * N, C, N, ldc, false);
     launch_check();
     dev_free(d, part);
 }

@@ -39,6 +39,8 @@ void  dev_d2d(Dev*, void* dst, const void* src, size_t bytes);
 void  dev_copy2d(Dev*, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int kind);
 void  dev_sync(Dev*);
 void  dev_set_profiling(Dev*, int level);   // 0 off, 1 one sampled launch per tag and fit, 2 every tagged launch
+void  dev_set_gemm_mode(Dev*, int mode);    // 0 = split-product (bf16x3) GEMM kernels for fp32 data, 1 = fp32-MFMA kernels
+int   dev_gemm_mode(const Dev*);
 void  dev_make_current(Dev*);               // hipSetDevice(the ctx's device) on the calling thread
 void  dev_abort(Dev*);                     // error path: wait for the stream, drop queued device-to-host hand-overs
 void  dev_reset_timing(Dev*);

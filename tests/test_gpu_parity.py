@@ -8,10 +8,13 @@ import parity_cases as pc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+# every parity test runs in both GEMM modes of the fp32 path: the default split-product (bf16x3) kernels and the
+# fp32-MFMA kernels (petal_ctx_set_gemm_mode)
+@pytest.fixture(scope="module", params=["bf16x3", "fp32"])
+def ctx(request):
     import petal_decomposition_amd as petal
     c = petal.Context(0)          # raises (no CPU fallback) when the HIP library or the GPU is missing
+    c.set_gemm_mode(request.param)
     yield c
     c.close()
 
@@ -150,3 +153,26 @@ def test_builtin_rccl_collective_single_rank(ctx):
             c2.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_split_product_gemm_matches_fp32_mfma():
+    """The two GEMM modes against each other and against float64 on data with a large mean (|mu| >> sigma stresses the
+    centring + split): the split-product kernels must be at least as close to float64 as the fp32-MFMA kernels."""
+    import petal_decomposition_amd as petal
+    rng = np.random.default_rng(3)
+    n, d, l = 3000, 160, 74
+    x = (rng.standard_normal((n, d)) * 0.5 + 40.0 * rng.standard_normal(d)).astype(np.float32)
+    p = rng.standard_normal((d, l)).astype(np.float32)
+    mu = x.mean(0).astype(np.float32)
+    zref = (x.astype(np.float64) - mu.astype(np.float64)) @ p.astype(np.float64)
+    out = {}
+    for mode in ("bf16x3", "fp32"):
+        c = petal.Context(0)
+        c.set_gemm_mode(mode)
+        z = np.asarray(petal.gemm_xp(x, p, mu, ctx=c))
+        y = np.asarray(petal.gemm_atb(x, z, mu, ctx=c))
+        yref = (x.astype(np.float64) - mu.astype(np.float64)).T @ z.astype(np.float64)
+        out[mode] = (np.abs(z - zref).max() / np.abs(zref).mean(), np.abs(y - yref).max() / np.abs(yref).mean())
+        c.close()
+    assert out["bf16x3"][0] <= 2.0 * out["fp32"][0] + 1e-7 and out["bf16x3"][0] < 2e-5, out
+    assert out["bf16x3"][1] <= 2.0 * out["fp32"][1] + 1e-7 and out["bf16x3"][1] < 2e-5, out
