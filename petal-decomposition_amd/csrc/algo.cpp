@@ -185,7 +185,7 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
         if (it == 0) op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, Y.f64(), p, 0.0, R.f64(), p), std::swap(Y, R);
         orth(Y, Q);
         op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, Q.f64(), p, 0.0, Y.f64(), p);  // Y = C Q
-        if (it % 2 == 1 || it == 0) {
+        if (it % 2 == 1) {  // Rayleigh-Ritz + residual check every second product (never converged after the first)
             op_dgemm(dv, true, false, p, p, dp, 1.0, Q.f64(), p, Y.f64(), p, 0.0, H.f64(), p);  // Rayleigh quotient
             op_eigh(dv, H.f64(), p, p, S.f64(), p, th.f64());
             op_dgemm(dv, false, false, dp, p, p, 1.0, Q.f64(), p, S.f64(), p, 0.0, QS.f64(), p);  // Ritz vectors

@@ -1213,11 +1213,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool CA, bool CB>
 __global__ __launch_bounds__(256) void k_atb_f64(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
                                                  const float* __restrict__ B, int64_t ldb, int N, const float* __restrict__ muB,
-                                                 int64_t n, int64_t chunk, double* __restrict__ part) {
+                                                 int64_t n, int64_t chunk, double* __restrict__ part, int sym) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int m0 = (blockIdx.x * 4 + wave) * 32, n0 = blockIdx.y * 64;
     if (m0 >= M) return;
+    if (sym && n0 + 64 <= (int)blockIdx.x * 128) return;  // Gram matrix: tiles strictly below the diagonal are mirrored
     const int64_t rbeg = (int64_t)blockIdx.z * chunk, rend = min(n, rbeg + chunk);
     const int mc = min(m0 + 2 * i, M - 2), nc4 = min(n0 + 4 * i, N - 4);  // clamped: out-of-range outputs are never stored
     const float* ap = A + mc;
@@ -1267,6 +1268,14 @@ __global__ __launch_bounds__(256) void k_atb_f64(const float* __restrict__ A, in
                 if (col < N) out[(int64_t)m * N + col] = acc[t][e][r];
             }
         }
+}
+
+// C[m][j] (m > j) <- C[j][m]: completes a symmetric product whose strictly-lower tiles were skipped
+__global__ __launch_bounds__(256) void k_mirror_upper(double* __restrict__ C, int64_t M, int64_t ldc) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * M) return;
+    const int64_t m = e / M, j = e - m * M;
+    if (m > j) C[m * ldc + j] = C[j * ldc + m];
 }
 
 // ================================================================================================
@@ -1393,25 +1402,25 @@ __global__ __launch_bounds__(256) void k_ica_mfma(const float* __restrict__ X1T,
     for (int e = threadIdx.x; e < NCP * NCP + NCP; e += 256) out[e] = s_slab[e];
 }
 // combine the per-workgroup slabs in fp64 (fixed order) and drop the padding: GX_gp = [nc*nc | nc].
-// block = 32 outputs x 8 part-lanes.
-__global__ __launch_bounds__(256) void k_ica_reduce(const float* __restrict__ part, int64_t nparts, int NCP, int nc,
-                                                    double* __restrict__ out, const int* __restrict__ state) {
+// block = 32 outputs x 32 part-lanes (the reduction is latency-bound: many short independent load chains).
+__global__ __launch_bounds__(1024) void k_ica_reduce(const float* __restrict__ part, int64_t nparts, int NCP, int nc,
+                                                     double* __restrict__ out, const int* __restrict__ state) {
     if (state && state[0]) return;
-    __shared__ double red[8][33];
+    __shared__ double red[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + tx;
     const int64_t slab = (int64_t)NCP * NCP + NCP;
     double sacc = 0;
     if (e < nc * nc + nc) {
         const int src = e < nc * nc ? (e / nc) * NCP + (e % nc) : NCP * NCP + (e - nc * nc);
-        for (int64_t p = ty; p < nparts; p += 8) sacc += (double)part[p * slab + src];
+        for (int64_t p = ty; p < nparts; p += 32) sacc += (double)part[p * slab + src];
     }
     red[ty][tx] = sacc;
     __syncthreads();
     if (ty == 0 && e < nc * nc + nc) {
         double t = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][tx];
+        for (int k = 0; k < 32; ++k) t += red[k][tx];  // fixed order: deterministic
         out[e] = t;
     }
 }
@@ -2515,11 +2524,25 @@ __device__ bool wg_polar_ns(const double* D, double* Wout, int nc, double* X, do
         const double terr = block_sum(err);  // (its barriers also publish T)
         if (!(terr == terr)) return false;
         if (terr <= 1e-26) { ok = true; break; }
+        // Scaled step: g = max_i sum_j |T_ij| >= lambda_max(T) = sigma_max(X)^2 (Gershgorin), so X / sqrt(g) still has all
+        // singular values <= 1 (the iteration stays monotone) but the largest one is pushed towards 1.  For a nearly
+        // orthogonal D -- the FastICA case: D ~ beta W -- T is nearly diagonal, the bound is tight, and the iteration
+        // turns quadratic after one step instead of crawling up from sigma = 1 / sqrt(nc) by factors of 1.5.
+        if (tid < nc) {
+            double rs = 0;
+            for (int j = 0; j < nc; ++j) rs += fabs(T[tid * ld + j]);
+            s_red[64 + tid] = rs;
+        }
+        __syncthreads();
+        double g = 0;
+        for (int i = 0; i < nc; ++i) g = fmax(g, s_red[64 + i]);
+        double ca = 1.5, cb = 0.5;
+        if (g > 0.0 && g < 1.0) { const double rg = 1.0 / sqrt(g); ca = 1.5 * rg; cb = 0.5 * rg / g; }
         for (int e = tid; e < nc * nc; e += nt) {
             const int i = e / nc, j = e - i * nc;
             double acc = 0;
             for (int k = 0; k < nc; ++k) acc += T[i * ld + k] * X[k * ld + j];
-            Y[i * ld + j] = 1.5 * X[i * ld + j] - 0.5 * acc;
+            Y[i * ld + j] = ca * X[i * ld + j] - cb * acc;
         }
         __syncthreads();
         double* sw = X; X = Y; Y = sw;
@@ -2538,6 +2561,12 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_symdecorr(const double* Wi
     JacWs ws = jac_carve(sm_sd, nc, blockDim.x);
     double* S = scratch; double* Zt = S + nc * nc; double* Z = Zt + nc * nc; double* Mm = Z + nc * nc; double* w = Mm + nc * nc;
     if (use_lds) { S = sm_sd + jac_ws_doubles(nc, blockDim.x); Zt = S + nc * (nc | 1); }
+    // textbook (W W^T)^(-1/2) W is the orthogonal polar factor of W: scaled Newton-Schulz first, eigen-solver as fallback
+    if constexpr (MB > 0) {
+        if (mode == 0 || nc <= 2) {
+            if (wg_polar_ns(Win, Wout, nc, S, Zt, Zt + nc * (nc | 1), ws.red)) return;
+        }
+    }
     wg_symdecorr<MB>(Win, Wout, nc, mode, S, Zt, Z, Mm, w, ws);
 }
 template <int MB>
@@ -2837,14 +2866,19 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         const dim3 grid(cdiv(M, 128), npanels, (unsigned)nsplit), block(256);
         const float* Af = (const float*)A; const float* Bf = (const float*)B; const float* ma = (const float*)muA; const float* mb = (const float*)muB;
         TagScope ts(d);
-        if (ma && mb) hipLaunchKernelGGL((k_atb_f64<true, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part);
-        else if (ma) hipLaunchKernelGGL((k_atb_f64<true, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part);
-        else if (mb) hipLaunchKernelGGL((k_atb_f64<false, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part);
-        else hipLaunchKernelGGL((k_atb_f64<false, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part);
+        const int sym = (A == B && muA == muB && lda == ldb && M == N) ? 1 : 0;  // Gram matrix: upper tiles only, then mirror
+        if (ma && mb) hipLaunchKernelGGL((k_atb_f64<true, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym);
+        else if (ma) hipLaunchKernelGGL((k_atb_f64<true, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym);
+        else if (mb) hipLaunchKernelGGL((k_atb_f64<false, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym);
+        else hipLaunchKernelGGL((k_atb_f64<false, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym);
         launch_check();
         ts.stop();
         hipLaunchKernelGGL(k_sum_parts2<double>, dim3(cdiv(M * N, 32)), dim3(256), 0, d->stream, part, nsplit, M * N, C, N, ldc, false);
         launch_check();
+        if (sym) {
+            hipLaunchKernelGGL(k_mirror_upper, dim3(cdiv(M * M, 256)), dim3(256), 0, d->stream, C, M, ldc);
+            launch_check();
+        }
         dev_free(d, part);
         return;
     }
@@ -3016,7 +3050,7 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
     }
     launch_check();
     ts.stop();
-    hipLaunchKernelGGL(k_ica_reduce, dim3(cdiv(cnt, 32)), dim3(256), 0, d->stream, part, nparts, NCP, (int)nc, GX_gp, state);
+    hipLaunchKernelGGL(k_ica_reduce, dim3(cdiv(cnt, 32)), dim3(1024), 0, d->stream, part, nparts, NCP, (int)nc, GX_gp, state);
     launch_check();
     dev_free(d, part);
     dev_free(d, Wpk);
@@ -3051,7 +3085,7 @@ void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX
 void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode) {
     double* scratch = (double*)dev_alloc(d, sizeof(double) * (4 * nc * nc + nc));
     const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
-    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 2 * nc * (nc | 1) : 0));
+    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 3 * nc * (nc | 1) : 0));
     MB_DISPATCH(mb, {
         static bool once = false;
         if (!once) { set_max_lds(reinterpret_cast<const void*>(k_symdecorr<MBv>)); once = true; }
