@@ -176,3 +176,24 @@ def test_split_product_gemm_matches_fp32_mfma():
         c.close()
     assert out["bf16x3"][0] <= 2.0 * out["fp32"][0] + 1e-7 and out["bf16x3"][0] < 2e-5, out
     assert out["bf16x3"][1] <= 2.0 * out["fp32"][1] + 1e-7 and out["bf16x3"][1] < 2e-5, out
+
+
+def test_rank_deficient_fp32_on_the_mfma_path(ctx):
+    """Rank 10 data in 128 dims with l = k + 10 = 26 > rank, at a size that runs the MFMA kernels: the optimistic
+    single-Cholesky re-basing must report pivot breakdowns and the fit must redo itself on the robust path
+    (dependent columns dropped) -- finite results, the leading part matching the oracle, nothing beyond the rank."""
+    import petal_decomposition_amd as petal
+    from oracle import petal_oracle as po
+    rng = np.random.default_rng(77)
+    n, d, r, k = 4096, 128, 10, 16
+    x = ((rng.standard_normal((n, r)) * np.logspace(0, -1.5, r)) @ rng.standard_normal((r, d)) + rng.standard_normal(d)).astype(np.float32)
+    om = rng.standard_normal((d, k + 10)).astype(np.float32)
+    o = po.RandomizedPcaOracle(k, n_iter=5).fit(x.astype(np.float64), omega=om.astype(np.float64))
+    m = petal.RandomizedPca(k, ctx=ctx, n_iter=5)
+    y = np.asarray(m.fit_transform(x, omega=om))
+    assert np.all(np.isfinite(m.components())) and np.all(np.isfinite(y)) and np.all(np.isfinite(m.singular_values()))
+    assert np.allclose(m.singular_values()[:r], o.singular[:r], rtol=2e-4)
+    assert np.all(m.singular_values()[r:] < 2e-3 * m.singular_values()[0])
+    assert pc.rowwise_rel(m.components()[:r].astype(np.float64), o.components[:r]).max() < 2e-3
+    back = np.asarray(m.inverse_transform(m.transform(x)))
+    assert np.abs(back - x).max() < 1e-3 * np.abs(x).max()
