@@ -2895,9 +2895,13 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         dev_free(d, part);
         return;
     }
-    // split the rows so that about 1024 waves (one per SIMD) exist; chunk a multiple of 16 rows
+    // split the rows so that every SIMD gets one wave (fp32-MFMA kernel: MFMA-bound, 256 workgroups) or two (split-product
+    // kernel: paced by loads in flight -- 512 workgroups = two per CU measured 67 vs 75 us at 100000 x 512)
     const int mslices = cdiv(M, 64);
-    static const int waves_target = [] { const char* e = getenv("PETAL_K2_WAVES"); return e ? atoi(e) : 1024; }();
+    static const int waves_env = [] { const char* e = getenv("PETAL_K2_WAVES"); return e ? atoi(e) : 0; }();
+    static int num_cu2 = 0;
+    if (!num_cu2) { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, d->device)); num_cu2 = prop.multiProcessorCount; }
+    const int waves_target = waves_env > 0 ? waves_env : num_cu2 * ((gemm_split_product(d) && !muB) ? 8 : 4);
     int64_t nsplit = std::max<int64_t>(1, waves_target / mslices);
     nsplit = std::min<int64_t>(nsplit, 256);  // bounds the partial-slab traffic of narrow (Gram) products
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 64));
