@@ -102,3 +102,30 @@ def test_numpy_generator_has_no_serde_form():
         assert "Pcg" in str(e)
     else:
         raise AssertionError("expected InvalidInput")
+
+
+def test_fitted_models_survive_a_json_round_trip_like_the_reference_tests():
+    """pca_serialize / randomized_pca_serialize / fast_ica_serialize (src/pca.rs:935-946, 1029-1040; src/ica.rs:422-431):
+    fit, serde_json::to_string, from_str, same components and mean -- on the host simulation of the device ops."""
+    import hostsim
+    ctx = hostsim.context()
+    x = np.array([[1.0, 1.0]], dtype=np.float32)
+    pca = petal.Pca.new(1, ctx)
+    pca.fit(x)
+    back = petal.Pca.from_json(pca.to_json(), dtype=np.float32)
+    assert np.allclose(back.components(), pca.components(), atol=1e-12) and np.allclose(back.mean(), pca.mean(), atol=1e-12)
+
+    rp = petal.RandomizedPca.with_seed(1, 1, ctx=ctx)
+    rp.fit(x)
+    back = petal.RandomizedPca.from_json(rp.to_json(), dtype=np.float32)
+    assert np.allclose(back.components(), rp.components(), atol=1e-12) and np.allclose(back.mean(), rp.mean(), atol=1e-12)
+    assert back.rng.state == rp.rng.state  # the generator advanced by exactly one Omega draw and travelled with the model
+
+    xi = np.array([[0.0, 0.0], [1.0, 1.0], [1.0, -1.0]])
+    ica = petal.FastIca.with_seed(0, ctx)
+    ica.fit(xi)
+    back = petal.FastIca.from_json(ica.to_json(), dtype=np.float64)
+    assert np.allclose(back.components, ica.components, atol=1e-12) and np.allclose(back.means, ica.means, atol=1e-12)
+    assert back.n_iter == ica.n_iter
+    y0, y1 = np.asarray(ica.transform(xi)), np.asarray(petal.FastIca.from_json(ica.to_json(), ctx=ctx).transform(xi))
+    assert np.allclose(y0, y1, atol=1e-12)
