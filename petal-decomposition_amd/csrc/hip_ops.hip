@@ -2198,6 +2198,9 @@ __host__ __device__ inline size_t jaca_lds_bytes(int L) {
     const int half = ((L + 1) & ~1) / 2;
     return sizeof(double) * ((size_t)L * (L | 1) + 2 * (size_t)half + 64);
 }
+// workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt) but leaves its global
+// stores in flight, unlike __syncthreads(), whose fence also drains vmcnt
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // round-robin tournament: pair k of round rd (Le players, Le - 1 rounds); p < q, or p == q for a bye (odd L)
 __device__ __forceinline__ void pair_pq(int k, int rd, int Le, int L, int& p, int& q) {
     if (k == 0) { p = Le - 1; q = rd; }
@@ -2255,7 +2258,7 @@ __device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq,
 //   block threads (tid >= PW): 16-lane group g owns the row pairs k = g and k = half-1-g, which together have exactly
 //     half-1 partners k' > k.  Their operands do not depend on this round's angles, so addresses and the 2 x 2 blocks are
 //     fetched BEFORE the barrier, under the angle threads' latency chain; after it only (c, s) are read and applied.
-template <int MB2>  // 16-wide batches of partner pairs per lane: half - 1 <= 16 MB2
+template <int MB2, int GW>  // GW-wide batches of partner pairs per lane: half - 1 <= GW MB2
 __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ain, int L, int64_t lda, jf64x2* __restrict__ log_cs,
                                                    int* __restrict__ nrounds_out, double* __restrict__ w,
                                                    int* __restrict__ rank_out, int PW) {
@@ -2277,7 +2280,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
     }
     __syncthreads();
     // this block thread's slots j = k0 + 16 m: slot j < n1 -> (k = g, k' = g + 1 + j), else (k = gb, k' = gb + 1 + j - n1)
-    const int bt = tid - PW, g = bt >> 4, k0 = bt & 15;
+    const int bt = tid - PW, g = bt / GW, k0 = bt - g * GW;  // GW lanes per group of two row pairs
     const int gb = half - 1 - g, n1 = half - 1 - g;
     const int nslots = (bt < 0) ? 0 : ((g < gb) ? half - 1 : (g == gb ? n1 : 0));
     int R = 0;  // rounds logged so far
@@ -2312,7 +2315,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
         ita.init(max(g, 0), 0, Le); itb.init(max(gb, 0) % half, 0, Le); itme.init(min(tid, half - 1), 0, Le);
 #pragma unroll
         for (int m = 0; m < MB2; ++m) {
-            const int j = k0 + 16 * m;
+            const int j = k0 + GW * m;
             itk[m].init(min(max(j < n1 ? g + 1 + j : gb + 1 + (j - n1), 0), half - 1), 0, Le);
         }
         for (int rd = 0; rd < rounds; ++rd, ++R) {
@@ -2341,7 +2344,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
                 itb.get(gb, Le, L, pb, qb);
 #pragma unroll
                 for (int m = 0; m < MB2; ++m) {
-                    const int j = k0 + 16 * m;
+                    const int j = k0 + GW * m;
                     const bool first = j < n1;
                     const int kp = min(first ? g + 1 + j : gb + 1 + (j - n1), half - 1);
                     kpv[m] = kp;
@@ -2356,7 +2359,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
                 }
             }
             DBG_T(0);
-            __syncthreads();
+            lds_barrier();  // NOT __syncthreads(): that also waits for the global log stores (vmcnt), ~1 us per round
             DBG_T(1);
             if (nslots > 0) {
                 const jf64x2 csa = s_cs[g], csb = s_cs[gb];
@@ -2365,7 +2368,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
                 for (int m = 0; m < MB2; ++m) cs2[m] = s_cs[kpv[m]];
 #pragma unroll
                 for (int m = 0; m < MB2; ++m) {
-                    const int j = k0 + 16 * m;
+                    const int j = k0 + GW * m;
                     if (j >= nslots) continue;
                     const jf64x2 cs = (j < n1) ? csa : csb;
                     // right rotation (columns p', q') with the partner's angle, then left rotation (rows p, q) with ours
@@ -2378,7 +2381,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
                 }
             }
             DBG_T(2);
-            __syncthreads();
+            lds_barrier();
             DBG_T(3);
             ita.next(Le); itb.next(Le); itme.next(Le);
 #pragma unroll
@@ -3155,18 +3158,25 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         jf64x2* log_cs = reinterpret_cast<jf64x2*>(buf);
         int* nrounds = reinterpret_cast<int*>(buf + nlog * 16);
         int* rank = nrounds + 4;
-        const int mb2 = std::max(1, (half - 1 + 15) / 16);               // partner pairs per lane
-        const int groups = (half + 1) / 2;                                // 16-lane groups, two row pairs each
+        // block threads: groups of GW lanes own two row pairs each; 32-lane groups (fewer blocks per thread: the rounds are
+        // paced by the per-thread work on both sides of the barrier) while the workgroup still fits 1024 threads
+        const int groups = (half + 1) / 2;                                // two row pairs each
         const int pw = (half + 63) / 64 * 64;                             // angle threads (whole waves)
-        const int threads = std::min(1024, (pw + 16 * groups + 63) / 64 * 64);
+        const int gw = (pw + 32 * groups <= 1024) ? 32 : 16;
+        const int mb2 = std::max(1, (half - 1 + gw - 1) / gw);            // partner pairs per lane
+        const int threads = std::min(1024, (pw + gw * groups + 63) / 64 * 64);
         const size_t lds = jaca_lds_bytes((int)L);
-#define JACA_CASE(M)                                                                                                     \
-    case M: {                                                                                                            \
+#define JACA_CASE(M, G)                                                                                                  \
+    case 10 * M + (G == 32 ? 1 : 0): {                                                                                   \
         static bool once = false;                                                                                        \
-        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_jacobi_a<M>)); once = true; }                           \
-        hipLaunchKernelGGL(k_jacobi_a<M>, dim3(1), dim3(threads), lds, d->stream, A, (int)L, lda, log_cs, nrounds, w, rank, pw); \
+        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_jacobi_a<M, G>)); once = true; }                        \
+        hipLaunchKernelGGL((k_jacobi_a<M, G>), dim3(1), dim3(threads), lds, d->stream, A, (int)L, lda, log_cs, nrounds, w, rank, pw); \
     } break;
-        switch (mb2) { JACA_CASE(1) JACA_CASE(2) JACA_CASE(3) JACA_CASE(4) default: JACA_CASE(5) }
+        switch (10 * std::min(mb2, 5) + (gw == 32 ? 1 : 0)) {
+            JACA_CASE(1, 16) JACA_CASE(2, 16) JACA_CASE(3, 16) JACA_CASE(4, 16) JACA_CASE(5, 16)
+            JACA_CASE(1, 32) JACA_CASE(2, 32) JACA_CASE(3, 32)
+            default: throw std::runtime_error("eigh: unsupported size for the split Jacobi solver");
+        }
 #undef JACA_CASE
         launch_check();
         const int hp = (half + 63) / 64;
