@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=100000, help="rows per GPU")
     ap.add_argument("--d", type=int, default=512)
     ap.add_argument("--k", type=int, default=64)
