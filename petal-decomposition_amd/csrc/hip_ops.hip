@@ -2904,7 +2904,8 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     static const int waves_env = [] { const char* e = getenv("PETAL_K2_WAVES"); return e ? atoi(e) : 0; }();
     static int num_cu2 = 0;
     if (!num_cu2) { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, d->device)); num_cu2 = prop.multiProcessorCount; }
-    const int waves_target = waves_env > 0 ? waves_env : num_cu2 * ((gemm_split_product(d) && !muB) ? 8 : 4);
+    // (at 100000 rows the extra 128 slabs cost k_sum_parts2 what the kernel gains: two per CU only for long row ranges)
+    const int waves_target = waves_env > 0 ? waves_env : num_cu2 * ((gemm_split_product(d) && !muB && n >= 400000) ? 8 : 4);
     int64_t nsplit = std::max<int64_t>(1, waves_target / mslices);
     nsplit = std::min<int64_t>(nsplit, 256);  // bounds the partial-slab traffic of narrow (Gram) products
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 64));
