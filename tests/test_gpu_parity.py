@@ -197,3 +197,49 @@ def test_rank_deficient_fp32_on_the_mfma_path(ctx):
     assert pc.rowwise_rel(m.components()[:r].astype(np.float64), o.components[:r]).max() < 2e-3
     back = np.asarray(m.inverse_transform(m.transform(x)))
     assert np.abs(back - x).max() < 1e-3 * np.abs(x).max()
+
+
+def test_cfg4_shard_shape_properties():
+    """One rank's share of BASELINE configs[3] (250000 x 1024 fp32, k = 128, n_iter = 7: l = 138, two column panels, the
+    largest LDS-resident Cholesky / Jacobi sizes), too big for the oracle in seconds: size-independent properties instead --
+    orthonormal components, the planted spectrum and subspace recovered, transform / inverse_transform a projection,
+    both GEMM modes agreeing."""
+    import torch
+    import petal_decomposition_amd as petal
+    from synth_data import synth_pca
+    n, d, k = 250000, 1024, 128
+    rng = np.random.default_rng(4)
+    r = 2 * k
+    rho = 10.0 ** (-3.0 / k)
+    v, _ = np.linalg.qr(rng.standard_normal((d, r)))
+    s = 100.0 * np.sqrt(n) * rho ** np.arange(r)
+    x = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    step = 50000
+    for i in range(0, n, step):  # the planted model of synth_data.synth_pca, generated block-wise straight into HBM
+        g = rng.standard_normal((step, r)) / np.sqrt(n)
+        x[i:i + step] = torch.from_numpy(((g * s) @ v.T + 0.01 * rng.standard_normal((step, d)) + 0.5).astype(np.float32)).cuda()
+    omega = rng.standard_normal((d, k + 10)).astype(np.float32)
+    comps = {}
+    for mode in ("bf16x3", "fp32"):
+        c = petal.Context(0)
+        c.set_gemm_mode(mode)
+        m = petal.RandomizedPca(k, ctx=c, n_iter=7)
+        m.fit(x, omega=omega)
+        cm = m.components().astype(np.float64)
+        assert np.abs(cm @ cm.T - np.eye(k)).max() < 2e-5                      # orthonormal rows
+        sig = m.singular_values().astype(np.float64)
+        assert np.all(np.diff(sig) <= 1e-6 * sig[0])                            # descending
+        assert np.allclose(sig[:k // 2], s[:k // 2], rtol=0.05)                 # the planted spectrum (G is only ~orthonormal)
+        cosines = np.linalg.svd(v[:, :k // 2].T @ cm.T, compute_uv=False)       # planted leading subspace inside the fitted one
+        assert cosines.min() > 1 - 1e-3
+        evr = m.explained_variance_ratio()
+        assert 0.99 < evr.sum() <= 1.0 + 1e-5
+        xs = x[:2000]
+        y = m.transform(xs)
+        back = m.inverse_transform(y)
+        y2 = m.transform(back)
+        assert float((y2 - y).abs().max()) < 1e-3 * float(y.abs().max())       # projection: idempotent
+        comps[mode] = (cm, sig)
+        c.close()
+    assert np.allclose(comps["bf16x3"][1], comps["fp32"][1], rtol=1e-5)
+    assert pc.rowwise_rel(comps["bf16x3"][0][:k // 2], comps["fp32"][0][:k // 2]).max() < 1e-4
