@@ -71,7 +71,9 @@ typedef struct petal_stats {
 
 /* ---- context ------------------------------------------------------------------------------- */
 /* `stream`: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let
- * the ctx create its own. */
+ * the ctx create its own.  Device-resident inputs (space = 1) are read on that stream: the caller makes sure whatever
+ * produces them has finished or is ordered before the call (the Python mirror synchronises torch's stream itself);
+ * every entry point returns after its own work is complete. */
 int         petal_ctx_create(int device, void* stream, petal_ctx** out);
 void        petal_ctx_destroy(petal_ctx* ctx);
 const char* petal_last_error(const petal_ctx* ctx);

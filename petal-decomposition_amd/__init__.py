@@ -165,6 +165,10 @@ def describe(x, keep: list) -> petal_matrix:
             raise InvalidInput(f"unsupported dtype {x.dtype}")
         keep.append(x)
         space = PETAL_DEVICE if x.is_cuda else PETAL_HOST
+        if x.is_cuda:
+            # the ctx launches on its own stream: whatever torch still has queued for this tensor on ITS current stream
+            # must be finished first (the calls are synchronous anyway; a no-op when the ctx shares torch's stream)
+            torch.cuda.current_stream(x.device).synchronize()
         return petal_matrix(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), x.stride(1), dt, space)
     if hasattr(x, "__cuda_array_interface__") and not isinstance(x, np.ndarray):
         cai = x.__cuda_array_interface__

@@ -136,6 +136,10 @@ void* dev_alloc(Dev* d, size_t bytes) {
         }
     }
     d->live[p] = sz;
+    // PETAL_POISON=1 (test aid): every block handed out is filled with 0xFF bytes (NaN as fp32 / fp64), so a kernel that
+    // reads memory it never wrote produces a visible NaN instead of depending on what the block held before
+    static const bool poison = getenv("PETAL_POISON") != nullptr;
+    if (poison) HIP_CHECK(hipMemsetAsync(p, 0xFF, sz, d->stream));
     return p;
 }
 
