@@ -2501,6 +2501,10 @@ __device__ void wg_symdecorr(const double* Win, double* Wout, int nc, int mode, 
 __device__ bool wg_polar_ns(const double* D, double* Wout, int nc, double* X, double* T, double* Y, double* s_red) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
     const int ld = nc | 1;
+    // nc a multiple of 16: the two nc^3 products of a step run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, operands
+    // straight from LDS); the scalar loops below are LDS-bound -- two reads per FMA -- and cost 20 us per product at nc = 64
+    const bool use_mfma = (nc & 15) == 0;
+    const int ntile = nc >> 4;
     auto block_sum = [&](double v) {
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         __syncthreads();
@@ -2520,13 +2524,32 @@ __device__ bool wg_polar_ns(const double* D, double* Wout, int nc, double* X, do
     bool ok = false;
     for (int it = 0; it < 60; ++it) {
         double err = 0;
-        for (int e = tid; e < nc * nc; e += nt) {
-            const int i = e / nc, j = e - i * nc;
-            double acc = 0;
-            for (int k = 0; k < nc; ++k) acc += X[i * ld + k] * X[j * ld + k];
-            T[i * ld + j] = acc;
-            const double dlt = acc - (i == j ? 1.0 : 0.0);
-            err += dlt * dlt;
+        if (use_mfma) {
+            // T = X X^T: tile (ti, tj) per wave pass; A[i][k] = X[16 ti + i][k], B[k][j] = X[16 tj + j][k];
+            // C/D: reg r of lane l is row (l >> 4) + 4 r, column l & 15
+            for (int tile = wv; tile < ntile * ntile; tile += nw) {
+                const int ti = tile / ntile, tj = tile - ti * ntile;
+                const double* pa = X + (16 * ti + (lane & 15)) * ld + (lane >> 4);
+                const double* pb = X + (16 * tj + (lane & 15)) * ld + (lane >> 4);
+                f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+                for (int k0 = 0; k0 < nc; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ti + (lane >> 4) + 4 * r, j = 16 * tj + (lane & 15);
+                    T[i * ld + j] = acc[r];
+                    const double dlt = acc[r] - (i == j ? 1.0 : 0.0);
+                    err += dlt * dlt;
+                }
+            }
+        } else {
+            for (int e = tid; e < nc * nc; e += nt) {
+                const int i = e / nc, j = e - i * nc;
+                double acc = 0;
+                for (int k = 0; k < nc; ++k) acc += X[i * ld + k] * X[j * ld + k];
+                T[i * ld + j] = acc;
+                const double dlt = acc - (i == j ? 1.0 : 0.0);
+                err += dlt * dlt;
+            }
         }
         const double terr = block_sum(err);  // (its barriers also publish T)
         if (!(terr == terr)) return false;
@@ -2545,11 +2568,27 @@ __device__ bool wg_polar_ns(const double* D, double* Wout, int nc, double* X, do
         for (int i = 0; i < nc; ++i) g = fmax(g, s_red[64 + i]);
         double ca = 1.5, cb = 0.5;
         if (g > 0.0 && g < 1.0) { const double rg = 1.0 / sqrt(g); ca = 1.5 * rg; cb = 0.5 * rg / g; }
-        for (int e = tid; e < nc * nc; e += nt) {
-            const int i = e / nc, j = e - i * nc;
-            double acc = 0;
-            for (int k = 0; k < nc; ++k) acc += T[i * ld + k] * X[k * ld + j];
-            Y[i * ld + j] = ca * X[i * ld + j] - cb * acc;
+        if (use_mfma) {
+            // Y = ca X - cb T X: A[i][k] = T[16 ti + i][k], B[k][j] = X[k][16 tj + j]
+            for (int tile = wv; tile < ntile * ntile; tile += nw) {
+                const int ti = tile / ntile, tj = tile - ti * ntile;
+                const double* pa = T + (16 * ti + (lane & 15)) * ld + (lane >> 4);
+                const double* pb = X + (lane >> 4) * ld + 16 * tj + (lane & 15);
+                f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+                for (int k0 = 0; k0 < nc; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0 * ld], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ti + (lane >> 4) + 4 * r, j = 16 * tj + (lane & 15);
+                    Y[i * ld + j] = ca * X[i * ld + j] - cb * acc[r];
+                }
+            }
+        } else {
+            for (int e = tid; e < nc * nc; e += nt) {
+                const int i = e / nc, j = e - i * nc;
+                double acc = 0;
+                for (int k = 0; k < nc; ++k) acc += T[i * ld + k] * X[k * ld + j];
+                Y[i * ld + j] = ca * X[i * ld + j] - cb * acc;
+            }
         }
         __syncthreads();
         double* sw = X; X = Y; Y = sw;
