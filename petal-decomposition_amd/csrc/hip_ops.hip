@@ -1723,6 +1723,9 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int cp(int k, int c) { return (c * (c + 1)) / 2 + k; }
+typedef double cf64x4 __attribute__((ext_vector_type(4)));
+// element (r, c) of an upper-triangular matrix kept column-packed; zero below the diagonal and outside the L x L matrix
+__device__ __forceinline__ double ld_up(const double* P, int r, int c, int L) { return (r <= c && c < L) ? P[cp(r, c)] : 0.0; }
 constexpr int CHOL2_MAXL = 140;
 __host__ __device__ inline size_t chol2_lds_bytes(int L) {
     return sizeof(double) * ((size_t)L * (L + 1) + 2 * (size_t)L) + sizeof(int) * (size_t)L;
@@ -1757,20 +1760,19 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
     const int nb = (L + 15) / 16;
     for (int J = 0; J < nb; ++J) {
         const int jb = 16 * J;
-        // (1) block row J -= (finished rows above)^T (finished rows above): 16 rows x 4 columns per wave
+        // (1) block row J -= (finished rows above)^T (finished rows above), one 16 x 16 tile per wave pass on the fp64 matrix
+        //     cores: C(J, Ct) -= sum_K R_KJ^T R_K,Ct.  MFMA 16x16x4 f64: lane l feeds A[l & 15][l >> 4], B[l >> 4][l & 15];
+        //     register r of lane l is C[(l >> 4) + 4 r][l & 15].
         if (jb > 0) {
-            const int ncol = L - jb;
-            for (int e = tid; e < 16 * ncol; e += nt) {
-                const int r = jb + (e & 15), c = jb + (e >> 4);
-                if (r < L && c >= r) {
-                    const double* pr = Rc + (r * (r + 1)) / 2;
-                    const double* pc = Rc + (c * (c + 1)) / 2;
-                    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-                    for (int k = 0; k < jb; k += 4) {  // jb is a multiple of 16
-                        a0 += pr[k] * pc[k]; a1 += pr[k + 1] * pc[k + 1];
-                        a2 += pr[k + 2] * pc[k + 2]; a3 += pr[k + 3] * pc[k + 3];
-                    }
-                    Rc[cp(r, c)] -= (a0 + a1) + (a2 + a3);
+            const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+            for (int Ct = J + (tid >> 6); Ct < nb; Ct += nt >> 6) {
+                cf64x4 acc = cf64x4{0.0, 0.0, 0.0, 0.0};
+                for (int k0 = 0; k0 < jb; k0 += 4)  // rows k0 + lk of R: (R_KJ^T)[i][k] = R[k][jb + i]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ld_up(Rc, k0 + lk, jb + li, L), ld_up(Rc, k0 + lk, 16 * Ct + li, L), acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = jb + lk + 4 * r, cc = 16 * Ct + li;
+                    if (rr <= cc && cc < L) Rc[cp(rr, cc)] -= acc[r];
                 }
             }
             __syncthreads();
@@ -1854,65 +1856,45 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
     __syncthreads();
     DBG_T(11);
     if (tid == 0 && ndead_out) { int cdead = 0; for (int j = 0; j < L; ++j) cdead += dead[j]; if (cdead > *ndead_out) *ndead_out = cdead; }
-    // ---- off-diagonal blocks of T = R^-1: T_IJ = -T_II sum_{K = I+1 .. J} R_IK T_KJ.  The left factor is applied once to
-    //      every off-diagonal block of R (R~_IK = T_II R_IK, in place, through registers); after that each block
-    //      super-diagonal dl is ONE phase: T_IJ = -sum_K R~_IK T_KJ with all T_KJ (K > I) already final.
+    // ---- off-diagonal blocks of T = R^-1: T_IJ = -T_II sum_{K = I+1 .. J} R_IK T_KJ, as 16 x 16 block products on the fp64
+    //      matrix cores.  First R~_IK = T_II R_IK for every off-diagonal block (in place: a block is read and written by
+    //      one wave only), then block super-diagonal by block super-diagonal T_IJ = -sum_K R~_IK T_KJ.
     {
-        constexpr int ITMAX = 18;  // 36 off-diagonal blocks (nb <= 9) x 256 elements / 512 threads
-        const int nel = (nb * (nb - 1) / 2) * 256;
-        double res[ITMAX];
+        const int lane = tid & 63, li = lane & 15, lk = lane >> 4, wv = tid >> 6, nw = nt >> 6;
+        for (int blk = wv; blk < nb * (nb - 1) / 2; blk += nw) {
+            int bI = blk, dl = 1;
+            while (bI >= nb - dl) { bI -= nb - dl; ++dl; }
+            const int bK = bI + dl;
+            cf64x4 acc = cf64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int it = 0; it < ITMAX; ++it) {
-            const int e = tid + it * nt;
-            res[it] = 0;
-            if (e < nel) {
-                int bI = e >> 8, dl = 1;
-                while (bI >= nb - dl) { bI -= nb - dl; ++dl; }
-                const int r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
-                if (c < L) {
-                    const double* pr = Rc + (c * (c + 1)) / 2;  // R[m][c], contiguous in m
-                    const int m1 = 16 * (bI + 1);
-                    int to = (r * (r + 1)) / 2 + r;             // T[r][m] = Tc[m (m + 1) / 2 + r]
-                    double t2 = 0;
-                    for (int m = r; m < m1; ++m) { t2 += Tc[to] * pr[m]; to += m + 1; }
-                    res[it] = t2;
+            for (int k0 = 0; k0 < 16; k0 += 4)  // A = T_II (upper triangular), B = R_IK
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ld_up(Tc, 16 * bI + li, 16 * bI + k0 + lk, L),
+                                                           ld_up(Rc, 16 * bI + k0 + lk, 16 * bK + li, L), acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * bI + lk + 4 * r, cc = 16 * bK + li;
+                if (cc < L) Rc[cp(rr, cc)] = acc[r];
+            }
+        }
+        __syncthreads();
+        DBG_T(12);
+        for (int dl = 1; dl < nb; ++dl) {
+            for (int bI = wv; bI < nb - dl; bI += nw) {
+                const int bJ = bI + dl;
+                cf64x4 acc = cf64x4{0.0, 0.0, 0.0, 0.0};
+                for (int bK = bI + 1; bK <= bJ; ++bK)
+#pragma unroll
+                    for (int k0 = 0; k0 < 16; k0 += 4)  // A = R~_IK, B = T_KJ (upper triangular when K == J)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ld_up(Rc, 16 * bI + li, 16 * bK + k0 + lk, L),
+                                                                   ld_up(Tc, 16 * bK + k0 + lk, 16 * bJ + li, L), acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * bI + lk + 4 * r, cc = 16 * bJ + li;
+                    if (cc < L) Tc[cp(rr, cc)] = -acc[r];
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < ITMAX; ++it) {
-            const int e = tid + it * nt;
-            if (e < nel) {
-                int bI = e >> 8, dl = 1;
-                while (bI >= nb - dl) { bI -= nb - dl; ++dl; }
-                const int r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
-                if (c < L) Rc[cp(r, c)] = res[it];
-            }
-        }
-        __syncthreads();
-    }
-    DBG_T(12);
-    for (int dl = 1; dl < nb; ++dl) {
-        const int nel = (nb - dl) * 256;
-        for (int e = tid; e < nel; e += nt) {
-            const int bI = e >> 8, r = 16 * bI + ((e >> 4) & 15), c = 16 * (bI + dl) + (e & 15);
-            if (c < L) {  // r < c < L
-                const int k0 = 16 * (bI + 1);
-                const double* pt = Tc + (c * (c + 1)) / 2;  // T[k][c], contiguous in k
-                int ro = (k0 * (k0 + 1)) / 2 + r;           // R~[r][k] = Rc[k (k + 1) / 2 + r]
-                double w0 = 0, w1 = 0;
-                int k = k0;
-                for (; k + 1 <= c; k += 2) {
-                    w0 += Rc[ro] * pt[k];
-                    w1 += Rc[ro + k + 1] * pt[k + 1];
-                    ro += 2 * k + 3;
-                }
-                if (k <= c) w0 += Rc[ro] * pt[k];
-                Tc[cp(r, c)] = -(w0 + w1);
-            }
-        }
-        __syncthreads();
     }
     DBG_T(13);
     for (int e = tid; e < L * L; e += nt) {
