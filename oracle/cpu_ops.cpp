@@ -31,6 +31,7 @@ void* dev_alloc(Dev*, size_t bytes) {
 void dev_free(Dev*, void* p) { std::free(p); }
 void dev_memset(Dev*, void* p, int v, size_t bytes) { std::memset(p, v, bytes); }
 void dev_h2d(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
+void dev_h2d_async(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
 void dev_d2h(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
 void dev_d2d(Dev*, void* dst, const void* src, size_t bytes) { std::memmove(dst, src, bytes); }
 void dev_copy2d(Dev*, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int) {
@@ -258,6 +259,10 @@ void op_dscale_cols(Dev*, double* A, int64_t M, int64_t N, int64_t lda, const do
 }
 void op_cvt_from_f64(Dev*, int dt, void* dst, const double* src, int64_t count) {
     for (int64_t i = 0; i < count; ++i) st(dst, dt, i, src[i]);
+}
+void op_pad_to_f64(Dev*, int dt, double* dst, int64_t rows_p, int64_t cols_p, const void* src, int64_t rows, int64_t cols, int64_t lds) {
+    for (int64_t r = 0; r < rows_p; ++r)
+        for (int64_t c = 0; c < cols_p; ++c) dst[r * cols_p + c] = (r < rows && c < cols) ? ld(src, dt, r * lds + c) : 0.0;
 }
 void op_cvt_to_f64(Dev*, int dt, double* dst, const void* src, int64_t count) {
     for (int64_t i = 0; i < count; ++i) dst[i] = ld(src, dt, i);

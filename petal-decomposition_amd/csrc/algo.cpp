@@ -341,13 +341,13 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     const bool tv_from_sq = centering && dt == F32;
     column_means(c, X, ri.n_total, centering, mu64, muT, tv_from_sq);
 
-    // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64
+    // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64.  The raw draw goes
+    // up through the pinned ring without a host wait (it overlaps the column-means pass) and is widened on the device.
     DBuf P(c.dev, sizeof(double) * dp * LP);
     {
-        std::vector<double> h(size_t(dp) * LP, 0.0);
-        for (int64_t i = 0; i < d; ++i)
-            for (int64_t j = 0; j < L; ++j) h[size_t(i) * LP + j] = get_elem(omega, dt, i * l_req + j);
-        dev_h2d(c.dev, P.p, h.data(), P.bytes);
+        DBuf raw(c.dev, esz * size_t(d) * l_req);
+        dev_h2d_async(c.dev, raw.p, omega, raw.bytes);
+        op_pad_to_f64(c.dev, dt, P.f64(), dp, LP, raw.p, d, L, l_req);
     }
     DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
     DBuf ndead(c.dev, sizeof(int));

@@ -183,6 +183,24 @@ void dev_d2h(Dev* d, void* dst, const void* src, size_t bytes) {
     d->pend.push_back({dst, d->pin_used, bytes});
     d->pin_used += need;
 }
+// Host-to-device without blocking the host: the bytes are copied into the pinned ring now (so the caller's buffer may be
+// a short-lived pageable one) and the transfer is queued on the stream; the slot is recycled at the next dev_sync.
+void dev_h2d_async(Dev* d, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    if (bytes > PIN_MAX_COPY) { dev_h2d(d, dst, src, bytes); return; }
+    if (!d->pin) {
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->pin), PIN_RING, hipHostMallocDefault));
+        d->pin_cap = PIN_RING;
+    }
+    const size_t need = (bytes + 63) / 64 * 64;
+    if (d->pin_used + need > d->pin_cap) {
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        drain_pending(d);
+    }
+    std::memcpy(d->pin + d->pin_used, src, bytes);
+    HIP_CHECK(hipMemcpyAsync(dst, d->pin + d->pin_used, bytes, hipMemcpyHostToDevice, d->stream));
+    d->pin_used += need;
+}
 void dev_abort(Dev* d) {  // error path: the destinations of queued copies may be gone
     (void)hipStreamSynchronize(d->stream);
     d->pend.clear();
@@ -2658,6 +2676,15 @@ __global__ void k_cvt_from_f64(T* dst, const double* src, int64_t count) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e < count) dst[e] = (T)src[e];
 }
+// dst (rows_p x cols_p fp64, zero padded) <- the leading rows x cols block of src (row-major, leading dimension lds)
+template <class T>
+__global__ void k_pad_to_f64(double* __restrict__ dst, int64_t rows_p, int64_t cols_p, const T* __restrict__ src, int64_t rows,
+                             int64_t cols, int64_t lds) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= rows_p * cols_p) return;
+    const int64_t r = e / cols_p, c = e - r * cols_p;
+    dst[e] = (r < rows && c < cols) ? (double)src[r * lds + c] : 0.0;
+}
 template <class T>
 __global__ void k_cvt_to_f64(double* dst, const T* src, int64_t count) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -3247,6 +3274,12 @@ void op_dscale_cols(Dev* d, double* A, int64_t M, int64_t N, int64_t lda, const 
 void op_cvt_from_f64(Dev* d, int dt, void* dst, const double* src, int64_t count) {
     if (!count) return;
     DISPATCH_T(dt, hipLaunchKernelGGL(k_cvt_from_f64<T>, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, (T*)dst, src, count));
+    launch_check();
+}
+void op_pad_to_f64(Dev* d, int dt, double* dst, int64_t rows_p, int64_t cols_p, const void* src, int64_t rows, int64_t cols, int64_t lds) {
+    if (rows_p * cols_p == 0) return;
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_pad_to_f64<T>, dim3(cdiv(rows_p * cols_p, 256)), dim3(256), 0, d->stream, dst, rows_p, cols_p,
+                                      (const T*)src, rows, cols, lds));
     launch_check();
 }
 void op_cvt_to_f64(Dev* d, int dt, double* dst, const void* src, int64_t count) {

@@ -33,6 +33,7 @@ void* dev_alloc(Dev*, size_t bytes);      // cached; never returns nullptr (thro
 void  dev_free(Dev*, void*);
 void  dev_memset(Dev*, void* p, int v, size_t bytes);
 void  dev_h2d(Dev*, void* dst, const void* src, size_t bytes);
+void  dev_h2d_async(Dev*, void* dst, const void* src, size_t bytes);  // src is consumed before the call returns; no host wait
 void  dev_d2h(Dev*, void* dst, const void* src, size_t bytes);  // dst is valid after the next dev_sync
 void  dev_d2d(Dev*, void* dst, const void* src, size_t bytes);
 // pitched copies (bytes); kind: 0 h2d, 1 d2h, 2 d2d
@@ -118,5 +119,7 @@ void op_dvec(Dev*, int mode, const double* x, double* y, int64_t count, double t
 void op_dscale_cols(Dev*, double* A, int64_t M, int64_t N, int64_t lda, const double* s);
 void op_cvt_from_f64(Dev*, int dtype, void* dst, const double* src, int64_t count);
 void op_cvt_to_f64(Dev*, int dtype, double* dst, const void* src, int64_t count);
+// dst (rows_p x cols_p fp64, zero padded) <- the leading rows x cols block of the row-major device matrix src (ld lds)
+void op_pad_to_f64(Dev*, int dtype, double* dst, int64_t rows_p, int64_t cols_p, const void* src, int64_t rows, int64_t cols, int64_t lds);
 
 }  // namespace petal
