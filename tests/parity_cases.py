@@ -189,6 +189,9 @@ def gemm_exact(ctx, n, K, N, seed=0, device=False):
     c = petal.gemm_atb(xin, bin_, mu, mub, ctx=ctx)
     ref = (x.astype(np.float64) - mu).T @ (bm.astype(np.float64) - mub)
     assert np.array_equal(c, ref), f"gemm_atb mismatch n={n} M={K} N={N}: max|d|={np.abs(c - ref).max()}"
+    c = petal.gemm_atb(xin, bin_, mu, ctx=ctx)   # the power-iteration form: only the tall side is centred
+    ref = (x.astype(np.float64) - mu).T @ bm.astype(np.float64)
+    assert np.array_equal(c, ref), f"gemm_atb (A centred only) mismatch n={n} M={K} N={N}: max|d|={np.abs(c - ref).max()}"
     c = petal.gemm_atb(xin, ctx=ctx)
     assert np.array_equal(c, x.astype(np.float64).T @ x.astype(np.float64))
 

@@ -31,6 +31,17 @@ def test_gemm_kernels_exact(ctx, n, K, N):
     pc.gemm_exact(ctx, n, K, N, seed=n + K + N)
 
 
+def test_gemm_kernels_exact_random_shapes(ctx):
+    """Seeded random shapes through both X-streaming kernels (ragged row counts, K % 32 == 16, several column panels,
+    shapes that fall back to the generic kernels): exact-integer data, so any indexing slip is an exact mismatch."""
+    rng = np.random.default_rng(2024)
+    for _ in range(24):
+        n = int(rng.integers(33, 9000))
+        K = int(rng.choice([16, 32, 48, 80, 96, 112, 160, 24, 40, 200]))
+        N = int(rng.choice([1, 7, 16, 30, 64, 74, 80, 96, 138, 170]))
+        pc.gemm_exact(ctx, n, K, N, seed=n * 7 + K + N, device=bool(rng.integers(0, 2)))
+
+
 def test_gemm_kernels_exact_device_resident(ctx):
     pc.gemm_exact(ctx, 4096, 512, 80, seed=5, device=True)      # zero-copy ingest path
     pc.gemm_exact(ctx, 1001, 100, 30, seed=6, device=True)      # device-side pad/pack path
