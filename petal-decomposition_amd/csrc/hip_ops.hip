@@ -1232,10 +1232,13 @@ __global__ __launch_bounds__(256, 2) void k_atb3(const float* __restrict__ A, in
 // f64 C/D map: reg r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <bool CA, bool CB>
-__global__ __launch_bounds__(256) void k_atb_f64(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
-                                                 const float* __restrict__ B, int64_t ldb, int N, const float* __restrict__ muB,
+// T = float: the precise Gram of fp32 data; T = double: K2 for fp64 inputs (same kernel, 16-B / 32-B loads).
+template <class T, bool CA, bool CB>
+__global__ __launch_bounds__(256) void k_atb_f64(const T* __restrict__ A, int64_t lda, int M, const T* __restrict__ muA,
+                                                 const T* __restrict__ B, int64_t ldb, int N, const T* __restrict__ muB,
                                                  int64_t n, int64_t chunk, double* __restrict__ part, int sym) {
+    typedef T tx2 __attribute__((ext_vector_type(2)));
+    typedef T tx4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int m0 = (blockIdx.x * 4 + wave) * 32, n0 = blockIdx.y * 64;
@@ -1243,33 +1246,33 @@ __global__ __launch_bounds__(256) void k_atb_f64(const float* __restrict__ A, in
     if (sym && n0 + 64 <= (int)blockIdx.x * 128) return;  // Gram matrix: tiles strictly below the diagonal are mirrored
     const int64_t rbeg = (int64_t)blockIdx.z * chunk, rend = min(n, rbeg + chunk);
     const int mc = min(m0 + 2 * i, M - 2), nc4 = min(n0 + 4 * i, N - 4);  // clamped: out-of-range outputs are never stored
-    const float* ap = A + mc;
-    const float* bp = B + nc4;
-    f32x2 ma = f32x2{0.f, 0.f};
-    f32x4 mb = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (CA) ma = *reinterpret_cast<const f32x2*>(muA + mc);
-    if (CB) mb = *reinterpret_cast<const f32x4*>(muB + nc4);
+    const T* ap = A + mc;
+    const T* bp = B + nc4;
+    tx2 ma = tx2{T(0), T(0)};
+    tx4 mb = tx4{T(0), T(0), T(0), T(0)};
+    if (CA) ma = *reinterpret_cast<const tx2*>(muA + mc);
+    if (CB) mb = *reinterpret_cast<const tx4*>(muB + nc4);
     f64x4 acc[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t][e] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int64_t r0 = rbeg; r0 < rend; r0 += 16) {
-        f32x2 av[4];
-        f32x4 bv[4];
+        tx2 av[4];
+        tx4 bv[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t r = r0 + 4 * s + q;
             const int64_t rc = r < rend ? r : rend - 1;
-            av[s] = *reinterpret_cast<const f32x2*>(ap + rc * lda);
-            bv[s] = *reinterpret_cast<const f32x4*>(bp + rc * ldb);
+            av[s] = *reinterpret_cast<const tx2*>(ap + rc * lda);
+            bv[s] = *reinterpret_cast<const tx4*>(bp + rc * ldb);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bool rv = (r0 + 4 * s + q) < rend;
             if (CA) av[s] -= ma;            // centred in the storage type, exactly like the crate's `input - &means`
             if (CB) bv[s] -= mb;
-            if (!rv) bv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!rv) bv[s] = tx4{T(0), T(0), T(0), T(0)};
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1290,6 +1293,108 @@ __global__ __launch_bounds__(256) void k_atb_f64(const float* __restrict__ A, in
                 if (col < N) out[(int64_t)m * N + col] = acc[t][e][r];
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 for fp64 inputs on the fp64 matrix cores: Z = (X - mu) P (+ bias, + sum (X - mu)^2).  One wave = 32 rows x NT column
+// tiles, K in 8-deep chunks: lane (i, q) loads X[row][8 c + 2 q, + 1] (16 B) -- the operands of two MFMA k-steps -- and
+// the matching pair of the packed P (k order inside a chunk permuted identically); two register stages.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+// Ppk64[((c NTtot + nt) 64 + lane) 2 + s] = P[8 c + 2 (lane >> 4) + s][16 nt + (lane & 15)]
+__global__ __launch_bounds__(256) void k_pack_p64(const double* __restrict__ P, int64_t K, int64_t N, int64_t ldp,
+                                                  f64x2* __restrict__ out, int NTtot, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int64_t tile = idx >> 6;
+    const int nt = (int)(tile % NTtot);
+    const int64_t c = tile / NTtot, col = 16 * nt + (lane & 15), k0 = 8 * c + 2 * (lane >> 4);
+    f64x2 v;
+    v[0] = (k0 < K && col < N) ? P[k0 * ldp + col] : 0.0;
+    v[1] = (k0 + 1 < K && col < N) ? P[(k0 + 1) * ldp + col] : 0.0;
+    out[idx] = v;
+}
+template <int NT, bool CENTER, bool SUMSQ>
+__global__ __launch_bounds__(256) void k_xp_f64(const double* __restrict__ X, int64_t n, int K, int64_t ldx,
+                                                const double* __restrict__ mu, const f64x2* __restrict__ Ppk, int NTtot, int nt0,
+                                                int N, const double* __restrict__ bias, double* __restrict__ Z, int64_t ldz,
+                                                double* __restrict__ ss_part) {
+    constexpr int RT = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+    double ssq = 0.0;
+    if (row0 < n) {
+        f64x4 acc[RT][NT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[t][u] = f64x4{0.0, 0.0, 0.0, 0.0};
+        const double* xrow[RT];
+        bool rvalid[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int64_t r = row0 + 16 * t + i;
+            rvalid[t] = r < n;
+            xrow[t] = X + (rvalid[t] ? r : (n - 1)) * ldx + 2 * q;
+        }
+        const f64x2* pb = Ppk + (int64_t)nt0 * 64 + lane;
+        const double* mup = mu + 2 * q;
+        const int nchunk = K >> 3;
+        auto load_chunk = [&](int c, f64x2(&a)[RT], f64x2(&b)[NT], f64x2& m) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const f64x2*>(xrow[t] + 8 * c);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) b[u] = pb[((int64_t)c * NTtot + u) * 64];
+            if (CENTER) m = *reinterpret_cast<const f64x2*>(mup + 8 * c);
+        };
+        auto compute = [&](f64x2(&a)[RT], f64x2(&b)[NT], const f64x2& m) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                if (CENTER) a[t] -= m;
+                if (SUMSQ && rvalid[t]) ssq += a[t][0] * a[t][0] + a[t][1] * a[t][1];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][s2], b[u][s2], acc[t][u], 0, 0, 0);
+        };
+        f64x2 a0[RT], b0[NT], a1[RT], b1[NT], m0 = f64x2{0.0, 0.0}, m1 = m0;
+        const int last = nchunk - 1;
+        load_chunk(0, a0, b0, m0);
+        int c = 0;
+        for (; c + 2 <= nchunk; c += 2) {
+            load_chunk(c + 1, a1, b1, m1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a0, b0, m0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(c + 2 < last ? c + 2 : last, a0, b0, m0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a1, b1, m1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c < nchunk) compute(a0, b0, m0);
+        // C/D of the f64 MFMA: register r of lane (i, q) is row q + 4 r of the A side (the X row), column i of the B side
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int col = 16 * (nt0 + u) + i;
+            if (col >= N) continue;
+            const double bv = bias ? bias[col] : 0.0;
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + 16 * t + q + 4 * r;
+                    if (row < n) Z[row * ldz + col] = acc[t][u][r] + bv;
+                }
+        }
+    }
+    if (SUMSQ) {
+        for (int off = 32; off > 0; off >>= 1) ssq += __shfl_down(ssq, off, 64);
+        if (lane == 0) ss_part[(int64_t)blockIdx.x * 4 + wave] = ssq;
+    }
 }
 
 // C[m][j] (m > j) <- C[j][m]: completes a symmetric product whose strictly-lower tiles were skipped
@@ -2755,6 +2860,51 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
     if (n == 0 || N == 0) return;
     const bool mfma = dt == F32 && K % 16 == 0 && K > 0 && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
                       K < (1 << 24) && N < (1 << 24) && N % 16 == 0 && ldz % 4 == 0 && aligned16(Z) && (!bias || aligned16(bias));
+    const bool mfma64 = dt == F64 && K % 8 == 0 && K > 0 && ldx % 2 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
+                        K < (1 << 24) && N < (1 << 24) && N % 16 == 0;
+    if (mfma64) {  // fp64 inputs: the fp64 matrix cores, 32-row wave tiles, column panels of <= 5 tiles
+        const int NTtot = cdiv(N, 16);
+        const int64_t total = (K / 8) * (int64_t)NTtot * 64;
+        f64x2* Ppk = (f64x2*)dev_alloc(d, sizeof(f64x2) * total);
+        hipLaunchKernelGGL(k_pack_p64, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk, NTtot, total);
+        launch_check();
+        const int blocks = cdiv(n, 128);
+        double* ssp = sumsq ? (double*)dev_alloc(d, sizeof(double) * blocks * 4) : nullptr;
+        const double* Xd = (const double*)X; const double* mud = (const double*)mu; const double* bd = (const double*)bias; double* Zd = (double*)Z;
+        TagScope ts(d);
+        for (int nt0 = 0; nt0 < NTtot;) {
+            const int rem = NTtot - nt0;
+            const int w = rem >= 5 ? 5 : rem;
+            double* sp = nt0 == 0 ? ssp : nullptr;
+#define XP64_ARGS Xd, n, (int)K, ldx, mud, Ppk, NTtot, nt0, (int)N, bd, Zd, ldz, sp
+#define XP64_LAUNCH(NTv)                                                                                                            \
+            do {                                                                                                                    \
+                if (mud && sp) hipLaunchKernelGGL((k_xp_f64<NTv, true, true>), dim3(blocks), dim3(256), 0, d->stream, XP64_ARGS);    \
+                else if (mud) hipLaunchKernelGGL((k_xp_f64<NTv, true, false>), dim3(blocks), dim3(256), 0, d->stream, XP64_ARGS);    \
+                else if (sp) hipLaunchKernelGGL((k_xp_f64<NTv, false, true>), dim3(blocks), dim3(256), 0, d->stream, XP64_ARGS);     \
+                else hipLaunchKernelGGL((k_xp_f64<NTv, false, false>), dim3(blocks), dim3(256), 0, d->stream, XP64_ARGS);            \
+            } while (0)
+            switch (w) {
+                case 5: XP64_LAUNCH(5); break;
+                case 4: XP64_LAUNCH(4); break;
+                case 3: XP64_LAUNCH(3); break;
+                case 2: XP64_LAUNCH(2); break;
+                default: XP64_LAUNCH(1); break;
+            }
+#undef XP64_LAUNCH
+#undef XP64_ARGS
+            launch_check();
+            nt0 += w;
+        }
+        ts.stop();
+        if (sumsq) {
+            hipLaunchKernelGGL(k_add_scalar_parts, dim3(1), dim3(256), 0, d->stream, ssp, (int64_t)blocks * 4, sumsq);
+            launch_check();
+            dev_free(d, ssp);
+        }
+        dev_free(d, Ppk);
+        return;
+    }
     if (!mfma) {
         double* ssp = sumsq ? (double*)dev_alloc(d, sizeof(double) * n) : nullptr;
         TagScope ts(d);
@@ -2908,8 +3058,11 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     if (n == 0) { HIP_CHECK(hipMemset2DAsync(C, ldc * sizeof(double), 0, N * sizeof(double), M, d->stream)); return; }
     const bool mfma = !precise && dt == F32 && M % 16 == 0 && N % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B) &&
                       (!muA || aligned16(muA)) && (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
-    const bool mfma64 = precise && dt == F32 && M % 16 == 0 && N % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) &&
-                        aligned16(B) && (!muA || aligned16(muA)) && (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
+    // fp64 matrix cores: the precise Gram of fp32 data, and every product of fp64 data (8-byte elements: rows 16-B aligned
+    // with an even leading dimension)
+    const bool mfma64 = ((precise && dt == F32 && lda % 4 == 0 && ldb % 4 == 0) || (dt == F64 && lda % 2 == 0 && ldb % 2 == 0)) &&
+                        M % 16 == 0 && N % 16 == 0 && aligned16(A) && aligned16(B) && (!muA || aligned16(muA)) &&
+                        (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
     if (mfma64) {
         const int mslices = cdiv(M, 32), npanels = cdiv(N, 64);
         int64_t nsplit = std::max<int64_t>(1, 2048 / ((int64_t)mslices * npanels));
@@ -2919,13 +3072,18 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         nsplit = (n + chunk - 1) / chunk;
         double* part = (double*)dev_alloc(d, sizeof(double) * nsplit * M * N);
         const dim3 grid(cdiv(M, 128), npanels, (unsigned)nsplit), block(256);
-        const float* Af = (const float*)A; const float* Bf = (const float*)B; const float* ma = (const float*)muA; const float* mb = (const float*)muB;
         TagScope ts(d);
         const int sym = (A == B && muA == muB && lda == ldb && M == N) ? 1 : 0;  // Gram matrix: upper tiles only, then mirror
-        if (ma && mb) hipLaunchKernelGGL((k_atb_f64<true, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym);
-        else if (ma) hipLaunchKernelGGL((k_atb_f64<true, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym);
-        else if (mb) hipLaunchKernelGGL((k_atb_f64<false, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym);
-        else hipLaunchKernelGGL((k_atb_f64<false, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym);
+#define ATB64_LAUNCH(TT)                                                                                                          \
+        do {                                                                                                                      \
+            const TT* Af = (const TT*)A; const TT* Bf = (const TT*)B; const TT* ma = (const TT*)muA; const TT* mb = (const TT*)muB; \
+            if (ma && mb) hipLaunchKernelGGL((k_atb_f64<TT, true, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
+            else if (ma) hipLaunchKernelGGL((k_atb_f64<TT, true, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
+            else if (mb) hipLaunchKernelGGL((k_atb_f64<TT, false, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
+            else hipLaunchKernelGGL((k_atb_f64<TT, false, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
+        } while (0)
+        if (dt == F64) ATB64_LAUNCH(double); else ATB64_LAUNCH(float);
+#undef ATB64_LAUNCH
         launch_check();
         ts.stop();
         hipLaunchKernelGGL(k_sum_parts2<double>, dim3(cdiv(M * N, 32)), dim3(256), 0, d->stream, part, nsplit, M * N, C, N, ldc, false);

@@ -162,12 +162,12 @@ ALL_KATS = [kat_pca_zero_component, kat_pca_single_sample, kat_pca, kat_pca_with
 
 
 # ---- kernels against exact integer data (fragment-layout bugs show up as exact mismatches) ----------
-def gemm_exact(ctx, n, K, N, seed=0, device=False):
+def gemm_exact(ctx, n, K, N, seed=0, device=False, dtype=np.float32):
     rng = np.random.default_rng(seed)
-    x = rng.integers(-4, 5, (n, K)).astype(np.float32)
-    p = rng.integers(-3, 4, (K, N)).astype(np.float32)   # asymmetric on purpose
-    mu = rng.integers(-2, 3, K).astype(np.float32)
-    b = rng.integers(-5, 6, N).astype(np.float32)
+    x = rng.integers(-4, 5, (n, K)).astype(dtype)
+    p = rng.integers(-3, 4, (K, N)).astype(dtype)   # asymmetric on purpose
+    mu = rng.integers(-2, 3, K).astype(dtype)
+    b = rng.integers(-5, 6, N).astype(dtype)
     xin = x
     if device:
         import torch
@@ -181,8 +181,8 @@ def gemm_exact(ctx, n, K, N, seed=0, device=False):
     if device:
         z = z.cpu().numpy()
     assert np.array_equal(z.astype(np.float64), x.astype(np.float64) @ p)
-    bm = rng.integers(-3, 4, (n, N)).astype(np.float32)
-    mub = rng.integers(-2, 3, N).astype(np.float32)
+    bm = rng.integers(-3, 4, (n, N)).astype(dtype)
+    mub = rng.integers(-2, 3, N).astype(dtype)
     bin_ = bm
     if device:
         bin_ = torch.from_numpy(bm).cuda()

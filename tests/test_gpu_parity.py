@@ -42,6 +42,13 @@ def test_gemm_kernels_exact_random_shapes(ctx):
         pc.gemm_exact(ctx, n, K, N, seed=n * 7 + K + N, device=bool(rng.integers(0, 2)))
 
 
+@pytest.mark.parametrize("n,K,N", [(64, 16, 16), (1000, 48, 80), (4099, 512, 74), (777, 32, 138), (5000, 208, 200), (300, 24, 7)])
+def test_gemm_kernels_exact_f64(ctx, n, K, N):
+    """fp64 inputs: the fp64-matrix-core forms of both GEMMs (k_xp_f64, k_atb_f64<double>) and their generic fall-backs."""
+    pc.gemm_exact(ctx, n, K, N, seed=n + K + N + 1, dtype=np.float64)
+    pc.gemm_exact(ctx, n, K, N, seed=n + K + N + 2, dtype=np.float64, device=True)
+
+
 def test_gemm_kernels_exact_device_resident(ctx):
     pc.gemm_exact(ctx, 4096, 512, 80, seed=5, device=True)      # zero-copy ingest path
     pc.gemm_exact(ctx, 1001, 100, 30, seed=6, device=True)      # device-side pad/pack path
@@ -57,6 +64,7 @@ def test_rpca_parity_variants(ctx):
     pc.rpca_parity(ctx, 6000, 96, 8, 7, seed=21, device=True)
     pc.rpca_parity(ctx, 3000, 64, 6, 7, seed=22, centering=False)
     pc.rpca_parity(ctx, 2000, 48, 6, 7, seed=23, dtype=np.float64, tol=1e-9)
+    pc.rpca_parity(ctx, 20000, 256, 32, 5, seed=24, dtype=np.float64, tol=1e-9, device=True)   # fp64 MFMA kernels
 
 
 def test_pca_parity(ctx):
