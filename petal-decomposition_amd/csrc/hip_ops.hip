@@ -2603,7 +2603,8 @@ __device__ void wg_symdecorr(const double* Win, double* Wout, int nc, int mode, 
 // three barriers per step instead of a full Jacobi eigen-solve (305 us -> tens of us at nc = 32).  Converges
 // quadratically once the singular values are O(1); returns false (caller falls back to the eigen-solver) if D is
 // singular / non-finite or 60 steps do not reach ||X X^T - I||_F <= 1e-13.
-__device__ bool wg_polar_ns(const double* D, double* Wout, int nc, double* X, double* T, double* Y, double* s_red) {
+// On entry X (LDS, leading dimension nc | 1) holds D; returns the LDS buffer holding the polar factor, or nullptr.
+__device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* s_red) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
     const int ld = nc | 1;
     // nc a multiple of 16: the two nc^3 products of a step run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, operands
@@ -2620,11 +2621,11 @@ __device__ bool wg_polar_ns(const double* D, double* Wout, int nc, double* X, do
         return t;
     };
     double ss = 0;
-    for (int e = tid; e < nc * nc; e += nt) ss += D[e] * D[e];
+    for (int e = tid; e < nc * nc; e += nt) { const double v = X[(e / nc) * ld + (e % nc)]; ss += v * v; }
     const double fro2 = block_sum(ss);
-    if (!(fro2 > 0.0) || !(fro2 < 1e300)) return false;
+    if (!(fro2 > 0.0) || !(fro2 < 1e300)) return nullptr;
     const double inv = 1.0 / sqrt(fro2);
-    for (int e = tid; e < nc * nc; e += nt) X[(e / nc) * ld + (e % nc)] = D[e] * inv;
+    for (int e = tid; e < nc * nc; e += nt) X[(e / nc) * ld + (e % nc)] *= inv;
     __syncthreads();
     bool ok = false;
     for (int it = 0; it < 60; ++it) {
@@ -2657,7 +2658,7 @@ __device__ bool wg_polar_ns(const double* D, double* Wout, int nc, double* X, do
             }
         }
         const double terr = block_sum(err);  // (its barriers also publish T)
-        if (!(terr == terr)) return false;
+        if (!(terr == terr)) return nullptr;
         if (terr <= 1e-26) { ok = true; break; }
         // Scaled step: g = max_i sum_j |T_ij| >= lambda_max(T) = sigma_max(X)^2 (Gershgorin), so X / sqrt(g) still has all
         // singular values <= 1 (the iteration stays monotone) but the largest one is pushed towards 1.  For a nearly
@@ -2698,10 +2699,7 @@ __device__ bool wg_polar_ns(const double* D, double* Wout, int nc, double* X, do
         __syncthreads();
         double* sw = X; X = Y; Y = sw;
     }
-    if (!ok) return false;
-    for (int e = tid; e < nc * nc; e += nt) Wout[e] = X[(e / nc) * ld + (e % nc)];
-    __syncthreads();
-    return true;
+    return ok ? X : nullptr;
 }
 
 constexpr int ICA_TAIL_THREADS = 512;
@@ -2715,7 +2713,15 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_symdecorr(const double* Wi
     // textbook (W W^T)^(-1/2) W is the orthogonal polar factor of W: scaled Newton-Schulz first, eigen-solver as fallback
     if constexpr (MB > 0) {
         if (mode == 0 || nc <= 2) {
-            if (wg_polar_ns(Win, Wout, nc, S, Zt, Zt + nc * (nc | 1), ws.red)) return;
+            const int ld = nc | 1;
+            for (int e = threadIdx.x; e < nc * nc; e += blockDim.x) S[(e / nc) * ld + (e % nc)] = Win[e];
+            __syncthreads();
+            const double* res = wg_polar_ns(nc, S, Zt, Zt + nc * ld, ws.red);
+            if (res) {
+                for (int e = threadIdx.x; e < nc * nc; e += blockDim.x) Wout[e] = res[(e / nc) * ld + (e % nc)];
+                return;
+            }
+            __syncthreads();
         }
     }
     wg_symdecorr<MB>(Win, Wout, nc, mode, S, Zt, Z, Mm, w, ws);
@@ -2733,18 +2739,39 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
     if (use_lds) { S = sm_tail + jac_ws_doubles(nc, nt); Zt = S + nc * (nc | 1); }
     const double* GX = GX_gp; const double* gp = GX_gp + nc * nc;
     const double pinv = 1.0 / n_total;
-    for (int e = tid; e < nc * nc; e += nt) D[e] = GX[e] * pinv - gp[e / nc] * pinv * W[e];  // ica.rs:334-342
-    __syncthreads();
-    bool done_ns = false;  // ica.rs:343
+    const int ldl = nc | 1;
+    double* Wl = nullptr;        // LDS copy of W (fast path): one global read of W, none of W1
+    const double* res = nullptr; // LDS result of the polar iteration
     if constexpr (MB > 0) {
-        if (mode == 0 || nc <= 2) done_ns = wg_polar_ns(D, W1, nc, S, Zt, Zt + nc * (nc | 1), ws.red);
+        if (mode == 0 || nc <= 2) {
+            Wl = Zt + 2 * nc * ldl;
+            for (int e = tid; e < nc * nc; e += nt) {  // D = GX / n - diag(g') W / n (ica.rs:334-342), straight into LDS
+                const int i = e / nc, j = e - i * nc;
+                const double wv_ = W[e];
+                Wl[i * ldl + j] = wv_;
+                S[i * ldl + j] = GX[e] * pinv - gp[i] * pinv * wv_;
+            }
+            __syncthreads();
+            res = wg_polar_ns(nc, S, Zt, Zt + nc * ldl, ws.red);  // ica.rs:343
+        }
     }
-    if (!done_ns) wg_symdecorr<MB>(D, W1, nc, mode, S, Zt, Z, Mm, w, ws);
     double lim = 0;  // ica.rs:344-354
-    for (int i = tid; i < nc; i += nt) {
-        double dot = 0;
-        for (int j = 0; j < nc; ++j) dot += W1[i * nc + j] * (mode == 1 ? W[j * nc + i] : W[i * nc + j]);
-        lim = fmax(lim, fabs(fabs(dot) - 1.0));
+    if (res) {
+        for (int i = tid; i < nc; i += nt) {
+            double dot = 0;
+            for (int j = 0; j < nc; ++j) dot += res[i * ldl + j] * Wl[i * ldl + j];
+            lim = fmax(lim, fabs(fabs(dot) - 1.0));
+        }
+    } else {
+        __syncthreads();
+        for (int e = tid; e < nc * nc; e += nt) D[e] = GX[e] * pinv - gp[e / nc] * pinv * W[e];
+        __syncthreads();
+        wg_symdecorr<MB>(D, W1, nc, mode, S, Zt, Z, Mm, w, ws);
+        for (int i = tid; i < nc; i += nt) {
+            double dot = 0;
+            for (int j = 0; j < nc; ++j) dot += W1[i * nc + j] * (mode == 1 ? W[j * nc + i] : W[i * nc + j]);
+            lim = fmax(lim, fabs(fabs(dot) - 1.0));
+        }
     }
     ws.red[tid] = lim;
     __syncthreads();
@@ -2754,7 +2781,8 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
     }
     const double tl = ws.red[0];
     __syncthreads();
-    for (int e = tid; e < nc * nc; e += nt) W[e] = W1[e];
+    if (res) { for (int e = tid; e < nc * nc; e += nt) W[e] = res[(e / nc) * ldl + (e % nc)]; }
+    else { for (int e = tid; e < nc * nc; e += nt) W[e] = W1[e]; }
     if (tid == 0 && (tl < tol)) { state[0] = 1; state[1] = iter + 1; }  // ica.rs:355-357
 }
 
@@ -3290,7 +3318,7 @@ static void set_max_lds(const void* fn) { HIP_CHECK(hipFuncSetAttribute(fn, hipF
 void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol, int* state, int iter) {
     double* scratch = (double*)dev_alloc(d, sizeof(double) * (6 * nc * nc + nc));
     const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
-    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 3 * nc * (nc | 1) : 0));
+    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 4 * nc * (nc | 1) : 0));
     MB_DISPATCH(mb, {
         static bool once = false;
         if (!once) { set_max_lds(reinterpret_cast<const void*>(k_ica_tail<MBv>)); once = true; }
