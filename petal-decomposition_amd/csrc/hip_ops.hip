@@ -1410,9 +1410,10 @@ __global__ __launch_bounds__(256) void k_mirror_upper(double* __restrict__ C, in
 // D += G^T . X1 (MFMA) and gp += sum(1 - g^2); partial D / gp per wave, combined in fp64.
 // ================================================================================================
 __device__ __forceinline__ float tanh_fast(float x) {
-    // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates correctly at +-inf; |abs err| ~ 1e-7
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
+    // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates correctly at +-inf; |abs err| ~ 1e-7; tanh(0) = 0 exactly.
+    // v_exp_f32 + v_rcp_f32 (1 ulp each): five VALU instructions instead of the ~14 of an IEEE division
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 // Wpk[((kc * NT + nt) * 64 + lane) * 4 + s] = W[16 nt + (lane&15)][16 kc + 4 (lane>>4) + s]   (B = W^T)
 __global__ void k_pack_w(const double* __restrict__ W, int nc, float* __restrict__ Wpk, int NT) {
@@ -1425,6 +1426,42 @@ __global__ void k_pack_w(const double* __restrict__ W, int nc, float* __restrict
         v[s] = (comp < nc && k < nc) ? (float)W[comp * nc + k] : 0.f;
     }
     reinterpret_cast<f32x4*>(Wpk)[e] = v;
+}
+
+// one partial slab per WORKGROUP: the four waves add their tiles into LDS in a fixed order (deterministic), then
+// the slab [NCP*NCP D | NCP gp] is written once, coalesced
+template <int NT>
+__device__ __forceinline__ void ica_write_slab(const f32x4 (&dacc)[NT][NT], const float (&gpa)[NT], float* s_slab,
+                                               float* __restrict__ part) {
+    constexpr int NCP = 16 * NT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* dst = &s_slab[(16 * a + 4 * q + r) * NCP + 16 * b + i];
+                        *dst = (w == 0 ? 0.f : *dst) + dacc[a][b][r];
+                    }
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                float gsum = gpa[a];
+                gsum += __shfl_xor(gsum, 16, 64);
+                gsum += __shfl_xor(gsum, 32, 64);
+                if (q == 0) {
+                    float* dst = &s_slab[NCP * NCP + 16 * a + i];
+                    *dst = (w == 0 ? 0.f : *dst) + gsum;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = part + (int64_t)blockIdx.x * (NCP * NCP + NCP);
+    for (int e = threadIdx.x; e < NCP * NCP + NCP; e += 256) out[e] = s_slab[e];
 }
 
 template <int NT>
@@ -1498,35 +1535,164 @@ __global__ __launch_bounds__(256) void k_ica_mfma(const float* __restrict__ X1T,
                 for (int b = 0; b < NT; ++b)
                     dacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[a][s], xb[s][b], dacc[a][b], 0, 0, 0);
     }
-    // one partial slab per WORKGROUP: the four waves add their tiles into LDS in a fixed order (deterministic), then
-    // the slab [NCP*NCP D | NCP gp] is written once, coalesced
     __shared__ float s_slab[NCP * NCP + NCP];
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
+    ica_write_slab<NT>(dacc, gpa, s_slab, part);
+}
+// K7, split-product form: both products of the step on the bf16 matrix cores (six piece products each, see K1).  One
+// wave handles 32 samples per pass.  The first product is laid out so that its OUTPUT is already the second product's
+// A operand: C[row = sample][col = component] puts S[samples 4q+r of either 16-sample tile][component i] in lane (i, q),
+// and since the k-slot <-> sample assignment of an MFMA is free as long as A and B agree, slot e of lane group q is
+// declared to be sample (e < 4 ? 4q+e : 16+4q+e-4); X1 is then loaded in exactly that order for the B operand.  No
+// cross-lane traffic between the two products.  W's three planes live in LDS (shared by the four waves).
+// Wpk3[((kc NT + u) 3 + plane) 64 + lane][e] = plane of (float)W[16 u + (lane & 15)][32 kc + 8 (lane >> 4) + e]
+__global__ __launch_bounds__(256) void k_pack_w3(const double* __restrict__ W, int nc, bf16x8* __restrict__ out, int NT,
+                                                 int KCH) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= KCH * NT * 64) return;
+    const int lane = idx & 63, tile = idx >> 6, u = tile % NT, kc = tile / NT;
+    const int comp = 16 * u + (lane & 15), k0 = 32 * kc + 8 * (lane >> 4);
+    f32x8 x;
 #pragma unroll
-            for (int a = 0; a < NT; ++a)
+    for (int e = 0; e < 8; ++e) x[e] = (comp < nc && k0 + e < nc) ? (float)W[comp * nc + k0 + e] : 0.f;
+    bf16x8 h, m, l;
+    split3(x, h, m, l);
+    out[(tile * 3 + 0) * 64 + lane] = h;
+    out[(tile * 3 + 1) * 64 + lane] = m;
+    out[(tile * 3 + 2) * 64 + lane] = l;
+}
+
+#ifndef PETAL_ICA3_PREFETCH
+#define PETAL_ICA3_PREFETCH 1
+#endif
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_ica3(const float* __restrict__ X1T, int64_t n, int64_t ld,
+                                                 const bf16x8* __restrict__ Wpk3, int64_t blocks_per_wave,
+                                                 float* __restrict__ part, const int* __restrict__ state) {
+    if (state && state[0]) return;
+    constexpr int NCP = 16 * NT, KCH = (NCP + 31) / 32, WITEMS = KCH * NT * 192;
+    constexpr int XP = NCP + 4;  // row pitch of the transposition buffer: 4 XP = 16 (mod 32) banks
+    constexpr int XT_FLOATS = 4 * 32 * XP, SLAB = NCP * NCP + NCP;
+    __shared__ bf16x8 sW[WITEMS];
+    __shared__ __attribute__((aligned(16))) float sX[XT_FLOATS > SLAB ? XT_FLOATS : SLAB];  // per wave [32 samples][XP]; the slab at the end
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    for (int e = threadIdx.x; e < WITEMS; e += 256) sW[e] = Wpk3[e];
+    __syncthreads();
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    float* xt = sX + wave * 32 * XP;
+    f32x4 dacc[NT][NT];  // [component tile][x tile]
+    float gpa[NT];
 #pragma unroll
-                for (int b = 0; b < NT; ++b)
+    for (int a = 0; a < NT; ++a) {
+        gpa[a] = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float* dst = &s_slab[(16 * a + 4 * q + r) * NCP + 16 * b + i];
-                        *dst = (w == 0 ? 0.f : *dst) + dacc[a][b][r];
-                    }
+        for (int b = 0; b < NT; ++b) dacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t b0 = wid * blocks_per_wave, b1 = min((n + 31) / 32, b0 + blocks_per_wave);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // A operand of the first product: lane (i, q) <- X1[r0 + 16 t + i][32 kc + 8 q .. + 7]
+    f32x4 xa[2][KCH][2];
+    auto load_a = [&](int64_t blk) {
 #pragma unroll
-            for (int a = 0; a < NT; ++a) {
-                float gsum = gpa[a];
-                gsum += __shfl_xor(gsum, 16, 64);
-                gsum += __shfl_xor(gsum, 32, 64);
-                if (q == 0) {
-                    float* dst = &s_slab[NCP * NCP + 16 * a + i];
-                    *dst = (w == 0 ? 0.f : *dst) + gsum;
+        for (int t = 0; t < 2; ++t) {
+            const int64_t ra = blk * 32 + 16 * t + i;
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+                const bool v = ra < n && (32 * kc + 8 * q) < NCP;
+                const float* src = X1T + ra * ld + 32 * kc + 8 * q;
+                xa[t][kc][0] = v ? *reinterpret_cast<const f32x4*>(src) : z4;
+                xa[t][kc][1] = v ? *reinterpret_cast<const f32x4*>(src + 4) : z4;
+            }
+        }
+    };
+    if (b0 < b1) load_a(b0);
+    for (int64_t blk = b0; blk < b1; ++blk) {
+        const int64_t r0 = blk * 32;
+        if (!PETAL_ICA3_PREFETCH && blk > b0) load_a(blk);
+        f32x4 sacc[2][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) sacc[t][u] = z4;
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x8 x = {xa[t][kc][0][0], xa[t][kc][0][1], xa[t][kc][0][2], xa[t][kc][0][3],
+                                 xa[t][kc][1][0], xa[t][kc][1][1], xa[t][kc][1][2], xa[t][kc][1][3]};
+                split3(x, ah[t], am[t], al[t]);
+                // the raw rows also go to the wave's LDS buffer, from which the second product reads them transposed
+                if ((32 * kc + 8 * q) < NCP) {
+                    float* dst = xt + (16 * t + i) * XP + 32 * kc + 8 * q;
+                    *reinterpret_cast<f32x4*>(dst) = xa[t][kc][0];
+                    *reinterpret_cast<f32x4*>(dst + 4) = xa[t][kc][1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const bf16x8* sw = sW + (kc * NT + u) * 192 + lane;
+                const bf16x8 wh = sw[0], wm = sw[64], wl = sw[128];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 c4 = sacc[t][u];
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], wh, c4, 0, 0, 0);  // smallest terms first
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], wm, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], wl, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], wh, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], wm, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], wh, c4, 0, 0, 0);
+                    sacc[t][u] = c4;
                 }
             }
         }
-        __syncthreads();
+        if (PETAL_ICA3_PREFETCH && blk + 1 < b1) load_a(blk + 1);  // next pass's rows land behind tanh and the second product
+        // sacc[t][u][r] = S[sample r0 + 16 t + 4 q + r][component 16 u + i]; G replaces S and is split in place
+        // rows past n were loaded as zeros: S = 0 and tanh(0) = 0 exactly, so only the g' sum needs masking (last pass)
+        bf16x8 gh[NT], gm[NT], gl[NT];
+        const bool tail = r0 + 32 > n;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            f32x8 g8;
+            float gs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float g = tanh_fast(sacc[t][u][r]);
+                    g8[4 * t + r] = g;
+                    gs = fmaf(-g, g, gs);
+                }
+            gpa[u] += gs + (tail ? (float)((n > r0 + 4 * q ? (int)min((int64_t)4, n - r0 - 4 * q) : 0) +
+                                           (n > r0 + 16 + 4 * q ? (int)min((int64_t)4, n - r0 - 16 - 4 * q) : 0))
+                                 : 8.0f);
+            split3(g8, gh[u], gm[u], gl[u]);
+        }
+        // D[component][x] += sum_samples G[sample][component] X1[sample][x]
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            // B operand: lane (j = i, q), slot e <- X1[r0 + (e < 4 ? 4 q + e : 16 + 4 q + e - 4)][16 b + j]
+            f32x8 xb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xb[e] = xt[((e < 4 ? 4 * q + e : 12 + 4 * q + e)) * XP + 16 * b + i];
+            bf16x8 bh, bm, bl;
+            split3(xb, bh, bm, bl);
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                f32x4 c4 = dacc[a][b];
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl[a], bh, c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm[a], bm, c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[a], bl, c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm[a], bh, c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[a], bm, c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[a], bh, c4, 0, 0, 0);
+                dacc[a][b] = c4;
+            }
+        }
     }
-    float* out = part + (int64_t)blockIdx.x * (NCP * NCP + NCP);
-    for (int e = threadIdx.x; e < NCP * NCP + NCP; e += 256) out[e] = s_slab[e];
+    __syncthreads();  // the slab aliases the transposition buffers
+    ica_write_slab<NT>(dacc, gpa, sX, part);
 }
 // combine the per-workgroup slabs in fp64 (fixed order) and drop the padding: GX_gp = [nc*nc | nc].
 // block = 32 outputs x 32 part-lanes (the reduction is latency-bound: many short independent load chains).
@@ -3276,6 +3442,33 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
         return;
     }
     const int NT = int((nc + 15) / 16), NCP = 16 * NT;
+    const int64_t slab = (int64_t)NCP * NCP + NCP;
+    if (gemm_split_product(d)) {
+        const int KCH = (NCP + 31) / 32;
+        bf16x8* Wpk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * KCH * NT * 192);
+        hipLaunchKernelGGL(k_pack_w3, dim3(cdiv(KCH * NT * 64, 256)), dim3(256), 0, d->stream, W, (int)nc, Wpk3, NT, KCH);
+        launch_check();
+        const int64_t nblk = (n + 31) / 32;
+        int64_t waves = std::min<int64_t>(2048, nblk);
+        const int64_t bpw = (nblk + waves - 1) / waves;
+        waves = (nblk + bpw - 1) / bpw;
+        const int blocks = cdiv(waves, 4);
+        float* part = (float*)dev_alloc(d, sizeof(float) * blocks * slab);
+        TagScope ts(d);
+        switch (NT) {
+            case 1: hipLaunchKernelGGL(k_ica3<1>, dim3(blocks), dim3(256), 0, d->stream, (const float*)X1T, n, ld, Wpk3, bpw, part, state); break;
+            case 2: hipLaunchKernelGGL(k_ica3<2>, dim3(blocks), dim3(256), 0, d->stream, (const float*)X1T, n, ld, Wpk3, bpw, part, state); break;
+            case 3: hipLaunchKernelGGL(k_ica3<3>, dim3(blocks), dim3(256), 0, d->stream, (const float*)X1T, n, ld, Wpk3, bpw, part, state); break;
+            default: hipLaunchKernelGGL(k_ica3<4>, dim3(blocks), dim3(256), 0, d->stream, (const float*)X1T, n, ld, Wpk3, bpw, part, state); break;
+        }
+        launch_check();
+        ts.stop();
+        hipLaunchKernelGGL(k_ica_reduce, dim3(cdiv(cnt, 32)), dim3(1024), 0, d->stream, part, (int64_t)blocks, NCP, (int)nc, GX_gp, state);
+        launch_check();
+        dev_free(d, part);
+        dev_free(d, Wpk3);
+        return;
+    }
     float* Wpk = (float*)dev_alloc(d, sizeof(float) * NT * NT * 64 * 4);
     hipLaunchKernelGGL(k_pack_w, dim3(cdiv(NT * NT * 64, 256)), dim3(256), 0, d->stream, W, (int)nc, Wpk, NT);
     launch_check();
@@ -3285,7 +3478,6 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
     waves = (tiles + tpw - 1) / tpw;
     const int blocks = cdiv(waves, 4);
     const int64_t nparts = (int64_t)blocks;  // one slab per workgroup
-    const int64_t slab = (int64_t)NCP * NCP + NCP;
     float* part = (float*)dev_alloc(d, sizeof(float) * nparts * slab);
     TagScope ts(d);
     switch (NT) {
