@@ -1561,9 +1561,6 @@ __global__ __launch_bounds__(256) void k_pack_w3(const double* __restrict__ W, i
     out[(tile * 3 + 2) * 64 + lane] = l;
 }
 
-#ifndef PETAL_ICA3_PREFETCH
-#define PETAL_ICA3_PREFETCH 1
-#endif
 template <int NT>
 __global__ __launch_bounds__(256, 2) void k_ica3(const float* __restrict__ X1T, int64_t n, int64_t ld,
                                                  const bf16x8* __restrict__ Wpk3, int64_t blocks_per_wave,
@@ -1606,53 +1603,88 @@ __global__ __launch_bounds__(256, 2) void k_ica3(const float* __restrict__ X1T, 
         }
     };
     if (b0 < b1) load_a(b0);
+    // Each group of MFMAs is written next to independent VALU work (chunk kc's MFMAs beside the split of chunk kc + 1 or
+    // of the transposed rows; component tile a's MFMAs beside tanh + split of tile a + 1).  Measured (dev/micro_coissue.hip):
+    // on a SIMD holding two such waves MFMA time and VALU time ADD rather than overlap, so the pass costs
+    // ~3070 (192 MFMAs) + ~3600 (730 VALU, 64 of them quarter-rate transcendentals) cycles; the kernel runs within 25 % of that.
     for (int64_t blk = b0; blk < b1; ++blk) {
         const int64_t r0 = blk * 32;
-        if (!PETAL_ICA3_PREFETCH && blk > b0) load_a(blk);
-        f32x4 sacc[2][NT];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) sacc[t][u] = z4;
-#pragma unroll
-        for (int kc = 0; kc < KCH; ++kc) {
-            bf16x8 ah[2], am[2], al[2];
+        bf16x8 ah[2], am[2], al[2];
+        auto split_a = [&](int kc) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const f32x8 x = {xa[t][kc][0][0], xa[t][kc][0][1], xa[t][kc][0][2], xa[t][kc][0][3],
                                  xa[t][kc][1][0], xa[t][kc][1][1], xa[t][kc][1][2], xa[t][kc][1][3]};
                 split3(x, ah[t], am[t], al[t]);
-                // the raw rows also go to the wave's LDS buffer, from which the second product reads them transposed
+            }
+        };
+        // the raw rows also go to the wave's LDS buffer, from which the second product reads them transposed
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc)
                 if ((32 * kc + 8 * q) < NCP) {
                     float* dst = xt + (16 * t + i) * XP + 32 * kc + 8 * q;
                     *reinterpret_cast<f32x4*>(dst) = xa[t][kc][0];
                     *reinterpret_cast<f32x4*>(dst + 4) = xa[t][kc][1];
                 }
+        bf16x8 nwh = sW[lane], nwm = sW[64 + lane], nwl = sW[128 + lane];
+        split_a(0);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 sacc[2][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) sacc[t][u] = z4;
+        bf16x8 bh[NT], bm[NT], bl[NT];
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 ch[2], cm[2], cl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { ch[t] = ah[t]; cm[t] = am[t]; cl[t] = al[t]; }
+            if (kc + 1 < KCH) {
+                split_a(kc + 1);
+            } else {
+                // B operand: lane (j = i, q), slot e <- X1[r0 + (e < 4 ? 4 q + e : 16 + 4 q + e - 4)][16 b + j]
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    f32x8 xb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xb[e] = xt[((e < 4 ? 4 * q + e : 12 + 4 * q + e)) * XP + 16 * b + i];
+                    split3(xb, bh[b], bm[b], bl[b]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
-                const bf16x8* sw = sW + (kc * NT + u) * 192 + lane;
-                const bf16x8 wh = sw[0], wm = sw[64], wl = sw[128];
+                const bf16x8 wh = nwh, wm = nwm, wl = nwl;
+                if (kc * NT + u + 1 < KCH * NT) {  // W's pieces are read one tile ahead (LDS latency off the MFMA path)
+                    const bf16x8* sw = sW + (kc * NT + u + 1) * 192 + lane;
+                    nwh = sw[0], nwm = sw[64], nwl = sw[128];
+                }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     f32x4 c4 = sacc[t][u];
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], wh, c4, 0, 0, 0);  // smallest terms first
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], wm, c4, 0, 0, 0);
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], wl, c4, 0, 0, 0);
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], wh, c4, 0, 0, 0);
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], wm, c4, 0, 0, 0);
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], wh, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cl[t], wh, c4, 0, 0, 0);  // smallest terms first
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm[t], wm, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[t], wl, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm[t], wh, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[t], wm, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[t], wh, c4, 0, 0, 0);
                     sacc[t][u] = c4;
                 }
             }
         }
-        if (PETAL_ICA3_PREFETCH && blk + 1 < b1) load_a(blk + 1);  // next pass's rows land behind tanh and the second product
-        // sacc[t][u][r] = S[sample r0 + 16 t + 4 q + r][component 16 u + i]; G replaces S and is split in place
-        // rows past n were loaded as zeros: S = 0 and tanh(0) = 0 exactly, so only the g' sum needs masking (last pass)
-        bf16x8 gh[NT], gm[NT], gl[NT];
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk + 1 < b1) load_a(blk + 1);  // next pass's rows land behind tanh and the second product
+        // sacc[t][u][r] = S[sample r0 + 16 t + 4 q + r][component 16 u + i].  Rows past n were loaded as zeros: S = 0
+        // and tanh(0) = 0 exactly, so only the g' sum needs masking (last pass).
         const bool tail = r0 + 32 > n;
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
+        const float nvalid = tail ? (float)((n > r0 + 4 * q ? (int)min((int64_t)4, n - r0 - 4 * q) : 0) +
+                                            (n > r0 + 16 + 4 * q ? (int)min((int64_t)4, n - r0 - 16 - 4 * q) : 0))
+                                  : 8.0f;
+        bf16x8 gh, gm, gl;
+        auto make_g = [&](int u) {
             f32x8 g8;
             float gs = 0.f;
 #pragma unroll
@@ -1663,33 +1695,29 @@ __global__ __launch_bounds__(256, 2) void k_ica3(const float* __restrict__ X1T, 
                     g8[4 * t + r] = g;
                     gs = fmaf(-g, g, gs);
                 }
-            gpa[u] += gs + (tail ? (float)((n > r0 + 4 * q ? (int)min((int64_t)4, n - r0 - 4 * q) : 0) +
-                                           (n > r0 + 16 + 4 * q ? (int)min((int64_t)4, n - r0 - 16 - 4 * q) : 0))
-                                 : 8.0f);
-            split3(g8, gh[u], gm[u], gl[u]);
-        }
+            gpa[u] += gs + nvalid;
+            split3(g8, gh, gm, gl);
+        };
+        make_g(0);
         // D[component][x] += sum_samples G[sample][component] X1[sample][x]
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int b = 0; b < NT; ++b) {
-            // B operand: lane (j = i, q), slot e <- X1[r0 + (e < 4 ? 4 q + e : 16 + 4 q + e - 4)][16 b + j]
-            f32x8 xb;
+        for (int a = 0; a < NT; ++a) {
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 fh = gh, fm = gm, fl = gl;
+            if (a + 1 < NT) make_g(a + 1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xb[e] = xt[((e < 4 ? 4 * q + e : 12 + 4 * q + e)) * XP + 16 * b + i];
-            bf16x8 bh, bm, bl;
-            split3(xb, bh, bm, bl);
-#pragma unroll
-            for (int a = 0; a < NT; ++a) {
+            for (int b = 0; b < NT; ++b) {
                 f32x4 c4 = dacc[a][b];
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl[a], bh, c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm[a], bm, c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[a], bl, c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm[a], bh, c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[a], bm, c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[a], bh, c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, bh[b], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm, bm[b], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, bl[b], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm, bh[b], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, bm[b], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, bh[b], c4, 0, 0, 0);
                 dacc[a][b] = c4;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // the slab aliases the transposition buffers
     ica_write_slab<NT>(dacc, gpa, sX, part);
