@@ -9,7 +9,7 @@ g = torch.Generator(device="cuda"); g.manual_seed(8)
 x = torch.randn((n, nc), generator=g, device="cuda", dtype=torch.float32)
 w0 = np.random.default_rng(7).standard_normal((nc, nc)).astype(np.float32)
 ctx = petal.Context(0)
-m = petal.FastIca(ctx=ctx, n_components=nc, tol=0.0, max_iter=6)
+m = petal.FastIca(ctx=ctx, n_components=nc, tol=0.0, max_iter=50)
 m.fit(x, w_init=w0)
 torch.cuda.synchronize()
 print("done", n, nc)

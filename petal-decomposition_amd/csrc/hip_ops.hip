@@ -2755,6 +2755,13 @@ __global__ __launch_bounds__(64 * JR_WAVES) void k_apply_rot(const jf64x2* __res
         for (int j = lane; j < L; j += 64) V[(int64_t)r * ldv + rank[j]] = row[j];
 }
 
+#ifndef PETAL_NS_CAP
+#define PETAL_NS_CAP 1.25
+#endif
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {  // v as seen through the DPP lane pattern CTRL (VALU speed, no LDS)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 // Wout = symmetric_decorrelation(Win) (ica.rs:363-381).  S (= W W^T, then destroyed) and the eigenvector accumulator
 // Zt are the Jacobi-hot matrices (LDS when nc <= 64); Z, Mm, w are scratch in global memory.
 template <int MB>
@@ -2832,6 +2839,7 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
                 const double* pa = X + (16 * ti + (lane & 15)) * ld + (lane >> 4);
                 const double* pb = X + (16 * tj + (lane & 15)) * ld + (lane >> 4);
                 f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
                 for (int k0 = 0; k0 < nc; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -2858,16 +2866,43 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
         // singular values <= 1 (the iteration stays monotone) but the largest one is pushed towards 1.  For a nearly
         // orthogonal D -- the FastICA case: D ~ beta W -- T is nearly diagonal, the bound is tight, and the iteration
         // turns quadratic after one step instead of crawling up from sigma = 1 / sqrt(nc) by factors of 1.5.
-        if (tid < nc) {
-            double rs = 0;
-            for (int j = 0; j < nc; ++j) rs += fabs(T[tid * ld + j]);
-            s_red[64 + tid] = rs;
+        // (LDS latency is ~110 cycles: a serial loop over nc entries costs microseconds, so the row sums use eight lanes per
+        // row and the maximum is a per-wave DPP reduction; fp32 is plenty for a scaling bound)
+        float* s_rs = reinterpret_cast<float*>(s_red + 64);
+        for (int row = tid >> 3; row < nc; row += nt >> 3) {
+            float rs = 0.f;
+            for (int j = tid & 7; j < nc; j += 8) rs += (float)fabs(T[row * ld + j]);
+            rs += dpp_f32<0xB1>(rs);   // quad_perm [1,0,3,2]
+            rs += dpp_f32<0x4E>(rs);   // quad_perm [2,3,0,1]
+            rs += dpp_f32<0x141>(rs);  // row_half_mirror
+            if ((tid & 7) == 0) { s_rs[row] = rs * 1.000001f; s_rs[64 + row] = 2.f * (float)T[row * ld + row] - rs * 1.000001f; }
         }
         __syncthreads();
-        double g = 0;
-        for (int i = 0; i < nc; ++i) g = fmax(g, s_red[64 + i]);
-        double ca = 1.5, cb = 0.5;
-        if (g > 0.0 && g < 1.0) { const double rg = 1.0 / sqrt(g); ca = 1.5 * rg; cb = 0.5 * rg / g; }
+        float gm = lane < nc ? s_rs[lane] : 0.f;
+        gm = fmaxf(gm, dpp_f32<0xB1>(gm));
+        gm = fmaxf(gm, dpp_f32<0x4E>(gm));
+        gm = fmaxf(gm, dpp_f32<0x141>(gm));
+        gm = fmaxf(gm, dpp_f32<0x140>(gm));  // row_mirror: every lane of a 16-lane row holds the row maximum
+        auto row_max = [&](int l0) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gm), l0)); };
+        const double g = (double)fmaxf(fmaxf(row_max(0), row_max(16)), fmaxf(row_max(32), row_max(48)));
+        // ... and a lower bound on lambda_min(T): Gershgorin's min_i (T_ii - sum_{j != i} |T_ij|), or 1 - ||T - I||_F
+        float gl = lane < nc ? s_rs[64 + lane] : 3.0e38f;
+        gl = fminf(gl, dpp_f32<0xB1>(gl));
+        gl = fminf(gl, dpp_f32<0x4E>(gl));
+        gl = fminf(gl, dpp_f32<0x141>(gl));
+        gl = fminf(gl, dpp_f32<0x140>(gl));
+        auto row_min = [&](int l0) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), l0)); };
+        const double glo = fmax(fmax((double)fminf(fminf(row_min(0), row_min(16)), fminf(row_min(32), row_min(48))), 1.0 - sqrt(terr)), 0.0);
+        // Over-relaxed step (Chen & Chow's scaled Newton-Schulz): with the singular values of X / sqrt(g) in [l, 1] the
+        // polynomial a x (3 - a^2 x^2) / 2 with a = sqrt(3 / (1 + l + l^2)) maps both ends to the same value and lifts the
+        // small ones by up to 1.5 a per step instead of 1.5.  l comes from the lower bound above (0 while T is far from
+        // diagonally dominant); a is capped at 1.25 (measured: 1.35 costs steps at nc = 64) so that an underestimated l cannot push the large singular values down
+        // by more than 10 % (a -> 1 as l -> 1: the last steps are the plain quadratic iteration).
+        const double gs = (g > 0.0 && g < 1.0) ? g : 1.0;
+        const double l = sqrt(fmin(glo / gs, 1.0));
+        const double al = fmin(PETAL_NS_CAP, sqrt(3.0 / (1.0 + l + l * l)));
+        const double rg = 1.0 / sqrt(gs);
+        const double ca = 1.5 * al * rg, cb = 0.5 * al * al * al * rg / gs;
         if (use_mfma) {
             // Y = ca X - cb T X: A[i][k] = T[16 ti + i][k], B[k][j] = X[k][16 tj + j]
             for (int tile = wv; tile < ntile * ntile; tile += nw) {
@@ -2875,6 +2910,7 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
                 const double* pa = T + (16 * ti + (lane & 15)) * ld + (lane >> 4);
                 const double* pb = X + (lane >> 4) * ld + 16 * tj + (lane & 15);
                 f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
                 for (int k0 = 0; k0 < nc; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0 * ld], acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
