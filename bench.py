@@ -32,6 +32,25 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 HBM_PEAK_GBS = 8000.0
 
 
+def rccl_probe(rank: int, world: int, local_rank: int, timeout_s: float = 180.0) -> bool:
+    """Runs petal-decomposition_amd/rccl_probe.py as a child of this rank (own rendezvous port); True if it exits 0 in time."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29531")) + 17)
+    env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
+    for key in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+        env.pop(key, None)
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "petal-decomposition_amd", "rccl_probe.py")
+    try:
+        res = subprocess.run([sys.executable, probe], env=env, timeout=timeout_s, capture_output=True, text=True)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] rank {rank}: RCCL probe timed out after {timeout_s:.0f} s", file=sys.stderr)
+        return False
+    if res.returncode != 0:
+        print(f"[bench] rank {rank}: RCCL probe exit code {res.returncode}: {res.stderr[-400:]}", file=sys.stderr)
+    return res.returncode == 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,7 +66,7 @@ def main():
                          "cores with fp32 accumulation (default, fp32-equivalent) or fp32 MFMA (petal_ctx_set_gemm_mode)")
     ap.add_argument("--collective", choices=["auto", "rccl", "torch"], default="auto",
                     help="N > 1: the library's built-in RCCL all-reduce (petal_ctx_init_rccl), or the torch.distributed "
-                         "hook; auto = built-in, falling back to the hook if RCCL cannot be bound")
+                         "hook; auto = built-in after a probe in a child process under a timeout (rccl_probe.py), else the hook")
     ap.add_argument("--single-rank-group", action="store_true",
                     help="development: at N = 1 still create a one-rank process group and run the sharded code path "
                          "(PETAL_FORCE_COLLECTIVE) to time its overhead")
@@ -56,6 +75,11 @@ def main():
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass "
                          "(default: the committed measurement in profiles/r01_pmc_traffic.json for this workload)")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON record: libraries that print banners to the C-level stdout (RCCL does, at
+    # communicator creation and again at exit) are pointed at stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import petal_decomposition_amd as petal
@@ -92,13 +116,25 @@ def main():
     if dist is not None:
         collective = "torch.distributed hook"
         if args.collective in ("auto", "rccl"):
-            try:  # every rank binds the same librccl, so success / failure is uniform across the group
-                ctx.use_rccl()
-                collective = "built-in RCCL (petal_ctx_init_rccl)"
-            except Exception as e:
-                if args.collective == "rccl":
-                    raise
-                print(f"[bench] built-in RCCL unavailable ({e}); using the torch.distributed hook", file=sys.stderr)
+            # The built-in collective is first exercised in a CHILD process per rank under a timeout (rccl_probe.py: its
+            # own communicator, one small sharded fit, results compared across ranks): a node on which it cannot
+            # complete costs a killed child and the torch.distributed hook instead of a hung job.
+            ok = 1
+            if args.collective == "auto":
+                ok = 1 if rccl_probe(rank, world, local_rank) else 0
+                t = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = int(t.item())
+                if not ok and rank == 0:
+                    print("[bench] built-in RCCL probe failed on some rank; using the torch.distributed hook", file=sys.stderr)
+            if ok:
+                try:  # every rank binds the same librccl, so success / failure is uniform across the group
+                    ctx.use_rccl()
+                    collective = "built-in RCCL (petal_ctx_init_rccl)"
+                except Exception as e:
+                    if args.collective == "rccl":
+                        raise
+                    print(f"[bench] built-in RCCL unavailable ({e}); using the torch.distributed hook", file=sys.stderr)
         if collective.startswith("torch"):
             ctx.use_torch_distributed()
     ctx.set_profiling(True)
@@ -177,7 +213,7 @@ def main():
 
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x_host, omega, k, n_iter)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
