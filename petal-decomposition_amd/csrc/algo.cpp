@@ -615,10 +615,13 @@ int64_t ica_loop(petal_ctx& c, int dt, const void* X1T, int64_t n, int64_t nc, i
     op_symdecorr(c.dev, nc, W0.f64(), W.f64(), mode);  // ica.rs:329
     dev_memset(c.dev, state.p, 0, state.bytes);
     int hstate[2] = {0, 0};
-    const int64_t check_every = 4;  // converged iterations turn into no-ops on the device; poll the flag in batches
+    // converged iterations turn into no-ops on the device; the flag is polled in batches of 4, 8, 16, 32, 32, ... iterations
+    // (a poll is a host round trip; a late poll costs a few no-op launches)
+    int64_t check_every = 4;
     int64_t it = 0;
     while (it < max_iter) {
         const int64_t stop = std::min(max_iter, it + check_every);
+        check_every = std::min<int64_t>(32, 2 * check_every);
         for (; it < stop; ++it) {
             dev_set_tag(c.dev, TAG_ICA);
             op_ica_step(c.dev, dt, X1T, n, nc, ld, W.f64(), GX.f64(), state.as<int>());  // ica.rs:332-333

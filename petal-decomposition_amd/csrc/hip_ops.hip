@@ -55,6 +55,13 @@ struct Dev {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int gemm_mode = [] { const char* e = getenv("PETAL_GEMM"); return (e && std::string(e) == "fp32") ? 1 : 0; }();
+    // FastICA: W's bf16 planes for the split-product step kernel; the tail kernel refreshes them with the W it writes, so only
+    // the first iteration of a fit runs the separate pack kernel
+    void* ica_wpk3 = nullptr;
+    size_t ica_wpk3_bytes = 0;
+    const double* ica_wpk3_for = nullptr;
+    int64_t ica_wpk3_nc = 0;
+    bool ica_wpk3_valid = false;
     int profiling = 0;  // 0 off, 1 = time ONE launch per tag and fit (rotating over the launches), 2 = every launch
     int tag = 0;
     int tag_seen[TAG_COUNT] = {};    // tagged launches so far in this fit
@@ -2958,7 +2965,8 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_symdecorr(const double* Wi
 }
 template <int MB>
 __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_total, double* W, const double* GX_gp, int mode,
-                                                               double tol, int* state, int iter, double* scratch) {
+                                                               double tol, int* state, int iter, double* scratch,
+                                                               bf16x8* __restrict__ wpk3) {
     if (state[0]) return;
     constexpr bool use_lds = MB > 0;
     extern __shared__ __attribute__((aligned(16))) double sm_tail[];
@@ -3013,6 +3021,22 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
     __syncthreads();
     if (res) { for (int e = tid; e < nc * nc; e += nt) W[e] = res[(e / nc) * ldl + (e % nc)]; }
     else { for (int e = tid; e < nc * nc; e += nt) W[e] = W1[e]; }
+    if (wpk3) {  // the next step kernel's operand planes (k_pack_w3's layout), straight from the new W
+        const int NT = (nc + 15) >> 4, KCH = (16 * NT + 31) >> 5;
+        for (int idx = tid; idx < KCH * NT * 64; idx += nt) {
+            const int lane = idx & 63, tile = idx >> 6, u = tile % NT, kc = tile / NT;
+            const int comp = 16 * u + (lane & 15), k0 = 32 * kc + 8 * (lane >> 4);
+            f32x8 x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                x[e] = (comp < nc && k0 + e < nc) ? (float)(res ? res[comp * ldl + k0 + e] : W1[comp * nc + k0 + e]) : 0.f;
+            bf16x8 h, m, l;
+            split3(x, h, m, l);
+            wpk3[(tile * 3 + 0) * 64 + lane] = h;
+            wpk3[(tile * 3 + 1) * 64 + lane] = m;
+            wpk3[(tile * 3 + 2) * 64 + lane] = l;
+        }
+    }
     if (tid == 0 && (tl < tol)) { state[0] = 1; state[1] = iter + 1; }  // ica.rs:355-357
 }
 
@@ -3489,6 +3513,8 @@ void op_logcosh_rows(Dev* d, int dt, const void* X, int64_t r, int64_t c, int64_
 void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t ld, const double* W, double* GX_gp,
                  const int* state) {
     const int64_t cnt = nc * nc + nc;
+    const bool planes_current = d->ica_wpk3_valid && d->ica_wpk3_for == W && d->ica_wpk3_nc == nc;
+    d->ica_wpk3_for = nullptr;  // (only the split-product path below asks the tail kernel to keep the planes current)
     if (n == 0) { dev_memset(d, GX_gp, 0, sizeof(double) * cnt); return; }
     const bool mfma = dt == F32 && nc <= 64 && ld % 4 == 0 && ld >= (nc + 15) / 16 * 16 && aligned16(X1T) && n >= 256;
     if (!mfma) {
@@ -3509,9 +3535,19 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
     const int64_t slab = (int64_t)NCP * NCP + NCP;
     if (gemm_split_product(d)) {
         const int KCH = (NCP + 31) / 32;
-        bf16x8* Wpk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * KCH * NT * 192);
-        hipLaunchKernelGGL(k_pack_w3, dim3(cdiv(KCH * NT * 64, 256)), dim3(256), 0, d->stream, W, (int)nc, Wpk3, NT, KCH);
-        launch_check();
+        const size_t need = sizeof(bf16x8) * KCH * NT * 192;
+        if (!d->ica_wpk3 || d->ica_wpk3_bytes < need) {
+            if (d->ica_wpk3) dev_free(d, d->ica_wpk3);
+            d->ica_wpk3 = dev_alloc(d, need);
+            d->ica_wpk3_bytes = need;
+            d->ica_wpk3_valid = false;
+        }
+        bf16x8* Wpk3 = (bf16x8*)d->ica_wpk3;
+        if (!planes_current) {
+            hipLaunchKernelGGL(k_pack_w3, dim3(cdiv(KCH * NT * 64, 256)), dim3(256), 0, d->stream, W, (int)nc, Wpk3, NT, KCH);
+            launch_check();
+        }
+        d->ica_wpk3_for = W; d->ica_wpk3_nc = nc; d->ica_wpk3_valid = false;  // valid again once the tail has refreshed them
         const int64_t nblk = (n + 31) / 32;
         int64_t waves = std::min<int64_t>(2048, nblk);
         const int64_t bpw = (nblk + waves - 1) / waves;
@@ -3530,7 +3566,6 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
         hipLaunchKernelGGL(k_ica_reduce, dim3(cdiv(cnt, 32)), dim3(1024), 0, d->stream, part, (int64_t)blocks, NCP, (int)nc, GX_gp, state);
         launch_check();
         dev_free(d, part);
-        dev_free(d, Wpk3);
         return;
     }
     float* Wpk = (float*)dev_alloc(d, sizeof(float) * NT * NT * 64 * 4);
@@ -3573,18 +3608,22 @@ static void set_max_lds(const void* fn) { HIP_CHECK(hipFuncSetAttribute(fn, hipF
 
 void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol, int* state, int iter) {
     double* scratch = (double*)dev_alloc(d, sizeof(double) * (6 * nc * nc + nc));
+    // refresh the step kernel's planes of W if the last step used them for this W
+    bf16x8* wpk3 = (d->ica_wpk3 && d->ica_wpk3_for == W && d->ica_wpk3_nc == nc) ? (bf16x8*)d->ica_wpk3 : nullptr;
     const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
     const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 4 * nc * (nc | 1) : 0));
     MB_DISPATCH(mb, {
         static bool once = false;
         if (!once) { set_max_lds(reinterpret_cast<const void*>(k_ica_tail<MBv>)); once = true; }
         hipLaunchKernelGGL(k_ica_tail<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, (int)nc, n_total, W, GX_gp, mode, tol,
-                           state, iter, scratch);
+                           state, iter, scratch, wpk3);
     });
     launch_check();
+    if (wpk3) d->ica_wpk3_valid = true;
     dev_free(d, scratch);
 }
 void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode) {
+    d->ica_wpk3_valid = false;
     double* scratch = (double*)dev_alloc(d, sizeof(double) * (4 * nc * nc + nc));
     const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
     const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 3 * nc * (nc | 1) : 0));
