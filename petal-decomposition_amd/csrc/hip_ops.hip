@@ -1248,9 +1248,23 @@ __global__ __launch_bounds__(256) void k_atb_f64(const T* __restrict__ A, int64_
     typedef T tx4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int m0 = (blockIdx.x * 4 + wave) * 32, n0 = blockIdx.y * 64;
+    // Gram matrix (sym): only the (128 x 64) blocks that reach the diagonal or lie above it are launched -- the grid's x index
+    // enumerates them row by row (block row bx keeps the panels by >= 2 bx); the rest is mirrored afterwards
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (sym) {
+        const int gy = (N + 63) / 64;
+        int t = blockIdx.x;
+        bx = 0;
+        for (;;) {
+            const int kept = gy - min(gy, 2 * bx);
+            if (t < kept) break;
+            t -= kept;
+            ++bx;
+        }
+        by = min(gy, 2 * bx) + t;
+    }
+    const int m0 = (bx * 4 + wave) * 32, n0 = by * 64;
     if (m0 >= M) return;
-    if (sym && n0 + 64 <= (int)blockIdx.x * 128) return;  // Gram matrix: tiles strictly below the diagonal are mirrored
     const int64_t rbeg = (int64_t)blockIdx.z * chunk, rend = min(n, rbeg + chunk);
     const int mc = min(m0 + 2 * i, M - 2), nc4 = min(n0 + 4 * i, N - 4);  // clamped: out-of-range outputs are never stored
     const T* ap = A + mc;
@@ -3347,15 +3361,31 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
                         (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
     if (mfma64) {
         const int mslices = cdiv(M, 32), npanels = cdiv(N, 64);
-        int64_t nsplit = std::max<int64_t>(1, 2048 / ((int64_t)mslices * npanels));
-        nsplit = std::min<int64_t>(nsplit, 64);
-        nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 256));
+        const int sym = (A == B && muA == muB && lda == ldb && M == N) ? 1 : 0;  // Gram matrix: upper tiles only, then mirror
+        const int gx = cdiv(M, 128);
+        int active = gx * npanels;  // workgroups per row chunk
+        if (sym) {
+            active = 0;
+            for (int bx = 0; bx < gx; ++bx) active += npanels - std::min(npanels, 2 * bx);
+        }
+        // row split: workgroups are dealt round-robin to the 256 CUs (up to three resident on each: the kernel's register
+        // budget), so the launch takes ceil(active * ns / 256) / ns of the single-split time; pick the ns that minimises it
+        // (ties: fewer fp64 slabs), as long as the slabs stay a fraction of the input traffic
+        const int64_t slab_cap = std::max<int64_t>(1, (int64_t)(0.4 * double(n) * double(M + (sym ? 0 : N)) * dtype_size(dt) / (double(M) * N * 8.0)));
+        const int64_t ns_max = std::min<int64_t>(std::min<int64_t>(64, slab_cap), std::max<int64_t>(1, n / 256));
+        int64_t nsplit = 1;
+        double best = 1e30;
+        for (int64_t ns = 1; ns <= ns_max; ++ns) {
+            // (a single workgroup per CU leaves one wave per SIMD and the load latency exposed: measured 312 vs 265 us)
+            const double cost = double((active * ns + 255) / 256) / double(ns) * (active * ns <= 256 ? 1.25 : 1.0);
+            if (cost < best * 0.97) { best = cost; nsplit = ns; }
+        }
+        (void)mslices;
         const int64_t chunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
         nsplit = (n + chunk - 1) / chunk;
         double* part = (double*)dev_alloc(d, sizeof(double) * nsplit * M * N);
-        const dim3 grid(cdiv(M, 128), npanels, (unsigned)nsplit), block(256);
+        const dim3 grid(sym ? active : gx, sym ? 1 : npanels, (unsigned)nsplit), block(256);
         TagScope ts(d);
-        const int sym = (A == B && muA == muB && lda == ldb && M == N) ? 1 : 0;  // Gram matrix: upper tiles only, then mirror
 #define ATB64_LAUNCH(TT)                                                                                                          \
         do {                                                                                                                      \
             const TT* Af = (const TT*)A; const TT* Bf = (const TT*)B; const TT* ma = (const TT*)muA; const TT* mb = (const TT*)muB; \
