@@ -62,6 +62,9 @@ struct Dev {
     const double* ica_wpk3_for = nullptr;
     int64_t ica_wpk3_nc = 0;
     bool ica_wpk3_valid = false;
+    // accepted ||W W^T - I||_F^2 of the decorrelation inside the loop: 1e-7 relative for fp32 data (whose outputs are fp32),
+    // fp64 round-off otherwise; set by op_ica_step from the data type it is handed
+    double ica_ortho_tol2 = 1e-26;
     int profiling = 0;  // 0 off, 1 = time ONE launch per tag and fit (rotating over the launches), 2 = every launch
     int tag = 0;
     int tag_seen[TAG_COUNT] = {};    // tagged launches so far in this fit
@@ -2826,7 +2829,7 @@ __device__ void wg_symdecorr(const double* Win, double* Wout, int nc, int mode, 
 // quadratically once the singular values are O(1); returns false (caller falls back to the eigen-solver) if D is
 // singular / non-finite or 60 steps do not reach ||X X^T - I||_F <= 1e-13.
 // On entry X (LDS, leading dimension nc | 1) holds D; returns the LDS buffer holding the polar factor, or nullptr.
-__device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* s_red) {
+__device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* s_red, double tol2 = 1e-26) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
     const int ld = nc | 1;
     // nc a multiple of 16: the two nc^3 products of a step run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, operands
@@ -2882,7 +2885,7 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
         }
         const double terr = block_sum(err);  // (its barriers also publish T)
         if (!(terr == terr)) return nullptr;
-        if (terr <= 1e-26) { ok = true; break; }
+        if (terr <= tol2) { ok = true; break; }  // tol2 = the square of the accepted ||X X^T - I||_F
         // Scaled step: g = max_i sum_j |T_ij| >= lambda_max(T) = sigma_max(X)^2 (Gershgorin), so X / sqrt(g) still has all
         // singular values <= 1 (the iteration stays monotone) but the largest one is pushed towards 1.  For a nearly
         // orthogonal D -- the FastICA case: D ~ beta W -- T is nearly diagonal, the bound is tight, and the iteration
@@ -2980,7 +2983,7 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_symdecorr(const double* Wi
 template <int MB>
 __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_total, double* W, const double* GX_gp, int mode,
                                                                double tol, int* state, int iter, double* scratch,
-                                                               bf16x8* __restrict__ wpk3) {
+                                                               bf16x8* __restrict__ wpk3, double ortho_tol2) {
     if (state[0]) return;
     constexpr bool use_lds = MB > 0;
     extern __shared__ __attribute__((aligned(16))) double sm_tail[];
@@ -3004,7 +3007,7 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
                 S[i * ldl + j] = GX[e] * pinv - gp[i] * pinv * wv_;
             }
             __syncthreads();
-            res = wg_polar_ns(nc, S, Zt, Zt + nc * ldl, ws.red);  // ica.rs:343
+            res = wg_polar_ns(nc, S, Zt, Zt + nc * ldl, ws.red, ortho_tol2);  // ica.rs:343
         }
     }
     double lim = 0;  // ica.rs:344-354
@@ -3544,6 +3547,7 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
                  const int* state) {
     const int64_t cnt = nc * nc + nc;
     const bool planes_current = d->ica_wpk3_valid && d->ica_wpk3_for == W && d->ica_wpk3_nc == nc;
+    d->ica_ortho_tol2 = dt == F32 ? 1e-14 : 1e-26;
     d->ica_wpk3_for = nullptr;  // (only the split-product path below asks the tail kernel to keep the planes current)
     if (n == 0) { dev_memset(d, GX_gp, 0, sizeof(double) * cnt); return; }
     const bool mfma = dt == F32 && nc <= 64 && ld % 4 == 0 && ld >= (nc + 15) / 16 * 16 && aligned16(X1T) && n >= 256;
@@ -3646,7 +3650,7 @@ void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX
         static bool once = false;
         if (!once) { set_max_lds(reinterpret_cast<const void*>(k_ica_tail<MBv>)); once = true; }
         hipLaunchKernelGGL(k_ica_tail<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, (int)nc, n_total, W, GX_gp, mode, tol,
-                           state, iter, scratch, wpk3);
+                           state, iter, scratch, wpk3, d->ica_ortho_tol2);
     });
     launch_check();
     if (wpk3) d->ica_wpk3_valid = true;
