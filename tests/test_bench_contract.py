@@ -1,0 +1,50 @@
+"""bench.py's output contract: stdout carries exactly one line, the JSON record, with the keys the driver reads and the
+`roofline` / `cpu_baseline` objects; the sharded code path (one-rank process group, built-in RCCL after the child-process
+probe) prints the same record."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"]
+
+
+def _run(*extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-northstar", *extra],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, f"stdout must be the JSON line only, got {len(lines)} lines: {res.stdout[:500]}"
+    rec = json.loads(lines[0])
+    for key in REQUIRED:
+        assert key in rec, key
+    assert rec["steps"] == 3 and rec["warmup"] == 1 and rec["n_gpus"] == 1
+    assert rec["value"] > 0 and rec["higher_is_better"] is True and rec["vs_baseline"] is None
+    assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(rec["roofline"])
+    assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-3
+    assert "workload" in rec["config"]
+    return rec
+
+
+def test_help_runs_without_a_gpu():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "--gpus" in res.stdout and "--steps" in res.stdout and "--warmup" in res.stdout
+
+
+@pytest.mark.gpu
+def test_single_gpu_record():
+    rec = _run()
+    cb = rec["cpu_baseline"]
+    assert set(["value", "unit", "cores", "kind", "sample"]) <= set(cb) and cb["kind"] in ("port", "reference") and cb["value"] > 0
+    assert rec["config"]["collective"] == "none"
+
+
+@pytest.mark.gpu
+def test_sharded_path_record_one_rank_group():
+    rec = _run("--single-rank-group", "--no-cpu-baseline")
+    assert rec["config"]["collective"].startswith("built-in RCCL"), rec["config"]["collective"]
