@@ -39,6 +39,7 @@ namespace petal {
     } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifdef PETAL_DEBUG_COUNTERS
 __device__ int g_dbg[4];
 __device__ long long g_cyc[16];
@@ -381,6 +382,38 @@ __global__ __launch_bounds__(256) void k_sum_parts2(const TP* __restrict__ part,
         for (int k = 0; k < 8; ++k) t += red[k][tx];
         double* o = out + (e / N) * ldc + (e % N);
         *o = accumulate ? *o + t : t;
+    }
+}
+// the same for fp32 slabs whose count and row length are even: a block owns 128 consecutive outputs (512 B contiguous in
+// every slab, one 8-B load per lane), its four waves each take a quarter of the slabs, eight loads in flight
+__global__ __launch_bounds__(256) void k_sum_parts4(const float* __restrict__ part, int64_t nparts, int64_t count,
+                                                    double* __restrict__ out, int64_t N, int64_t ldc) {
+    __shared__ double red[3][64][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * 2;
+    double s0 = 0, s1 = 0;
+    if (e < count) {
+        const float* src = part + e;
+        int64_t p = wave;
+        for (; p + 28 < nparts; p += 32) {
+            f32x2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x2*>(src + (p + 4 * k) * count);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s0 += (double)v[k][0]; s1 += (double)v[k][1]; }
+        }
+        for (; p < nparts; p += 4) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(src + p * count);
+            s0 += (double)v[0]; s1 += (double)v[1];
+        }
+    }
+    if (wave > 0) { red[wave - 1][lane][0] = s0; red[wave - 1][lane][1] = s1; }
+    __syncthreads();
+    if (wave == 0 && e < count) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { s0 += red[w][lane][0]; s1 += red[w][lane][1]; }
+        double* o = out + (e / N) * ldc + (e % N);
+        o[0] = s0; o[1] = s1;
     }
 }
 __global__ __launch_bounds__(256) void k_add_scalar_parts(const double* __restrict__ part, int64_t nparts, double* __restrict__ out) {
@@ -3488,7 +3521,10 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         nt0 += w;
     }
     ts.stop();
-    hipLaunchKernelGGL(k_sum_parts2<float>, dim3(cdiv(M * N, 32)), dim3(256), 0, d->stream, part, nslab, M * N, C, N, ldc, false);
+    if ((M * N) % 2 == 0 && N % 2 == 0)
+        hipLaunchKernelGGL(k_sum_parts4, dim3(cdiv(M * N, 128)), dim3(256), 0, d->stream, part, nslab, M * N, C, N, ldc);
+    else
+        hipLaunchKernelGGL(k_sum_parts2<float>, dim3(cdiv(M * N, 32)), dim3(256), 0, d->stream, part, nslab, M * N, C, N, ldc, false);
     launch_check();
     dev_free(d, part);
 }
