@@ -1485,24 +1485,26 @@ __global__ void k_pack_w(const double* __restrict__ W, int nc, float* __restrict
     reinterpret_cast<f32x4*>(Wpk)[e] = v;
 }
 
-// one partial slab per WORKGROUP: the four waves add their tiles into LDS in a fixed order (deterministic), then
-// the slab [NCP*NCP D | NCP gp] is written once, coalesced
+// one partial slab per WORKGROUP, deterministic: waves 0 and 1 store their tiles into two LDS slabs, waves 2 and 3 add
+// theirs on top, and the sum (w0 + w2) + (w1 + w3) of the two slabs [NCP*NCP D | NCP gp] is written once, coalesced.
+// s_slab holds 2 (NCP*NCP + NCP) floats.
 template <int NT>
 __device__ __forceinline__ void ica_write_slab(const f32x4 (&dacc)[NT][NT], const float (&gpa)[NT], float* s_slab,
                                                float* __restrict__ part) {
-    constexpr int NCP = 16 * NT;
+    constexpr int NCP = 16 * NT, SLAB = NCP * NCP + NCP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
+    float* mine = s_slab + (wave & 1) * SLAB;
+    for (int ph = 0; ph < 2; ++ph) {
+        if ((wave >> 1) == ph) {
 #pragma unroll
             for (int a = 0; a < NT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float* dst = &s_slab[(16 * a + 4 * q + r) * NCP + 16 * b + i];
-                        *dst = (w == 0 ? 0.f : *dst) + dacc[a][b][r];
+                        float* dst = &mine[(16 * a + 4 * q + r) * NCP + 16 * b + i];
+                        *dst = (ph == 0 ? 0.f : *dst) + dacc[a][b][r];
                     }
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
@@ -1510,15 +1512,15 @@ __device__ __forceinline__ void ica_write_slab(const f32x4 (&dacc)[NT][NT], cons
                 gsum += __shfl_xor(gsum, 16, 64);
                 gsum += __shfl_xor(gsum, 32, 64);
                 if (q == 0) {
-                    float* dst = &s_slab[NCP * NCP + 16 * a + i];
-                    *dst = (w == 0 ? 0.f : *dst) + gsum;
+                    float* dst = &mine[NCP * NCP + 16 * a + i];
+                    *dst = (ph == 0 ? 0.f : *dst) + gsum;
                 }
             }
         }
         __syncthreads();
     }
-    float* out = part + (int64_t)blockIdx.x * (NCP * NCP + NCP);
-    for (int e = threadIdx.x; e < NCP * NCP + NCP; e += 256) out[e] = s_slab[e];
+    float* out = part + (int64_t)blockIdx.x * SLAB;
+    for (int e = threadIdx.x; e < SLAB; e += 256) out[e] = s_slab[e] + s_slab[SLAB + e];
 }
 
 template <int NT>
@@ -1592,7 +1594,7 @@ __global__ __launch_bounds__(256) void k_ica_mfma(const float* __restrict__ X1T,
                 for (int b = 0; b < NT; ++b)
                     dacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[a][s], xb[s][b], dacc[a][b], 0, 0, 0);
     }
-    __shared__ float s_slab[NCP * NCP + NCP];
+    __shared__ float s_slab[2 * (NCP * NCP + NCP)];
     ica_write_slab<NT>(dacc, gpa, s_slab, part);
 }
 // K7, split-product form: both products of the step on the bf16 matrix cores (six piece products each, see K1).  One
@@ -1625,7 +1627,7 @@ __global__ __launch_bounds__(256, 2) void k_ica3(const float* __restrict__ X1T, 
     if (state && state[0]) return;
     constexpr int NCP = 16 * NT, KCH = (NCP + 31) / 32, WITEMS = KCH * NT * 192;
     constexpr int XP = NCP + 4;  // row pitch of the transposition buffer: 4 XP = 16 (mod 32) banks
-    constexpr int XT_FLOATS = 4 * 32 * XP, SLAB = NCP * NCP + NCP;
+    constexpr int XT_FLOATS = 4 * 32 * XP, SLAB = 2 * (NCP * NCP + NCP);
     __shared__ bf16x8 sW[WITEMS];
     __shared__ __attribute__((aligned(16))) float sX[XT_FLOATS > SLAB ? XT_FLOATS : SLAB];  // per wave [32 samples][XP]; the slab at the end
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
