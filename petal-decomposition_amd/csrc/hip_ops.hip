@@ -1211,10 +1211,13 @@ __global__ __launch_bounds__(256, 2) void k_atb3(const float* __restrict__ A, in
         const int buf = st & 1;
         __syncthreads();  // stage st of B is in sB[buf]; nobody still reads sB[buf ^ 1]
         bf16x8 ah[4], am[4], al[4];
+        if (CA) {  // centred in place (a centred COPY would keep 32 more registers alive across the four splits)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] -= ma;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            f32x8 x = f32x8{av[0][t], av[1][t], av[2][t], av[3][t], av[4][t], av[5][t], av[6][t], av[7][t]};
-            if (CA) x -= ma[t];
+            const f32x8 x = f32x8{av[0][t], av[1][t], av[2][t], av[3][t], av[4][t], av[5][t], av[6][t], av[7][t]};
             split3(x, ah[t], am[t], al[t]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -3175,6 +3178,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // split-product (bf16x3, see k_xp3) kernels unless the ctx asks for the fp32-MFMA ones (petal_ctx_set_gemm_mode /
 // PETAL_GEMM=fp32)
 static bool gemm_split_product(const Dev* d) { return d->gemm_mode == 0; }
+static void set_max_lds(const void* fn) { HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
 
 template <int RT, int NT>
 static void launch_xp(Dev* d, const float* X, int64_t n, int K, int64_t ldx, const float* mu, const float* Ppk, int NTtot,
@@ -3471,7 +3475,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 64));
     const bool split3_mode = gemm_split_product(d) && !muB && n >= 32 * nsplit;
     const int64_t cq = split3_mode ? 32 : 16;  // rows per pipeline stage
-    const int64_t n_main = split3_mode ? n / 32 * 32 : n, n_tail = n - n_main;  // split-product kernel: whole 32-row stages
+    const int64_t n_main = split3_mode ? n / cq * cq : n, n_tail = n - n_main;  // split-product kernels: whole stages
     const int64_t chunk = ((n_main + nsplit - 1) / nsplit + cq - 1) / cq * cq;
     nsplit = (n_main + chunk - 1) / chunk;
     const int64_t nslab = nsplit + (n_tail ? 1 : 0);
@@ -3499,15 +3503,17 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
             }
 #undef ATB3_LAUNCH
             launch_check();
-            if (n_tail) {  // the < 32 ragged rows: one more slab from the fp32 kernel
+        }
+        if (split3_mode) {
+            if (n_tail) {  // the ragged rows (< one stage): one more slab from the fp32 kernel
                 const float* At = Af + n_main * lda; const float* Bt = Bf + n_main * ldb;
                 float* pt = part + nsplit * M * N;
                 switch (w) {
-                    case 5: launch_atb<5>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 32, pt, 1); break;
-                    case 4: launch_atb<4>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 32, pt, 1); break;
-                    case 3: launch_atb<3>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 32, pt, 1); break;
-                    case 2: launch_atb<2>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 32, pt, 1); break;
-                    default: launch_atb<1>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 32, pt, 1); break;
+                    case 5: launch_atb<5>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 64, pt, 1); break;
+                    case 4: launch_atb<4>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 64, pt, 1); break;
+                    case 3: launch_atb<3>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 64, pt, 1); break;
+                    case 2: launch_atb<2>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 64, pt, 1); break;
+                    default: launch_atb<1>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 64, pt, 1); break;
                 }
             }
             nt0 += w;
@@ -3665,7 +3671,6 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
     dev_free(d, Wpk);
 }
 
-static void set_max_lds(const void* fn) { HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
 
 #define MB_DISPATCH(mb, CALL)            \
     switch (mb) {                        \
