@@ -1279,12 +1279,13 @@ __global__ __launch_bounds__(256, 2) void k_atb3(const float* __restrict__ A, in
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // T = float: the precise Gram of fp32 data; T = double: K2 for fp64 inputs (same kernel, 16-B / 32-B loads).
-template <class T, bool CA, bool CB>
+template <class T, bool CA, bool CB, int NE = 4>
 __global__ __launch_bounds__(256) void k_atb_f64(const T* __restrict__ A, int64_t lda, int M, const T* __restrict__ muA,
                                                  const T* __restrict__ B, int64_t ldb, int N, const T* __restrict__ muB,
                                                  int64_t n, int64_t chunk, double* __restrict__ part, int sym) {
+    // NE = B tiles per wave: lane i holds the NE consecutive columns n0 + NE i .. (tile e, col j <-> col = n0 + NE j + e).
+    // NE = 5 serves N = 80 (l = 74 padded) with one panel instead of two 64-wide ones, the second 75 % empty.
     typedef T tx2 __attribute__((ext_vector_type(2)));
-    typedef T tx4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     // Gram matrix (sym): only the (128 x 64) blocks that reach the diagonal or lie above it are launched -- the grid's x index
@@ -1302,41 +1303,53 @@ __global__ __launch_bounds__(256) void k_atb_f64(const T* __restrict__ A, int64_
         }
         by = min(gy, 2 * bx) + t;
     }
-    const int m0 = (bx * 4 + wave) * 32, n0 = by * 64;
+    const int m0 = (bx * 4 + wave) * 32, n0 = by * (16 * NE);
     if (m0 >= M) return;
     const int64_t rbeg = (int64_t)blockIdx.z * chunk, rend = min(n, rbeg + chunk);
-    const int mc = min(m0 + 2 * i, M - 2), nc4 = min(n0 + 4 * i, N - 4);  // clamped: out-of-range outputs are never stored
+    const int mc = min(m0 + 2 * i, M - 2), ncl = min(n0 + NE * i, N - NE);  // clamped: out-of-range outputs are never stored
     const T* ap = A + mc;
-    const T* bp = B + nc4;
+    const T* bp = B + ncl;
     tx2 ma = tx2{T(0), T(0)};
-    tx4 mb = tx4{T(0), T(0), T(0), T(0)};
+    T mb[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) mb[e] = CB ? muB[ncl + e] : T(0);
     if (CA) ma = *reinterpret_cast<const tx2*>(muA + mc);
-    if (CB) mb = *reinterpret_cast<const tx4*>(muB + nc4);
-    f64x4 acc[2][4];
+    f64x4 acc[2][NE];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[t][e] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int e = 0; e < NE; ++e) acc[t][e] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int64_t r0 = rbeg; r0 < rend; r0 += 16) {
         tx2 av[4];
-        tx4 bv[4];
+        T bv[4][NE];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t r = r0 + 4 * s + q;
             const int64_t rc = r < rend ? r : rend - 1;
             av[s] = *reinterpret_cast<const tx2*>(ap + rc * lda);
-            bv[s] = *reinterpret_cast<const tx4*>(bp + rc * ldb);
+            if constexpr (NE == 4) {  // one 16-B / 32-B load
+                typedef T tx4 __attribute__((ext_vector_type(4)));
+                const tx4 v = *reinterpret_cast<const tx4*>(bp + rc * ldb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[s][e] = v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) bv[s][e] = bp[rc * ldb + e];
+            }
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bool rv = (r0 + 4 * s + q) < rend;
             if (CA) av[s] -= ma;            // centred in the storage type, exactly like the crate's `input - &means`
-            if (CB) bv[s] -= mb;
-            if (!rv) bv[s] = tx4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                if (CB) bv[s][e] -= mb[e];
+                if (!rv) bv[s][e] = T(0);
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < NE; ++e)
                     acc[t][e] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[s][t], (double)bv[s][e], acc[t][e], 0, 0, 0);
         }
     }
@@ -1348,8 +1361,8 @@ __global__ __launch_bounds__(256) void k_atb_f64(const T* __restrict__ A, int64_
             const int m = m0 + 2 * (q + 4 * r) + t;
             if (m >= M) continue;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int col = n0 + 4 * i + e;
+            for (int e = 0; e < NE; ++e) {
+                const int col = n0 + NE * i + e;
                 if (col < N) out[(int64_t)m * N + col] = acc[t][e][r];
             }
         }
@@ -3402,8 +3415,9 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
                         M % 16 == 0 && N % 16 == 0 && aligned16(A) && aligned16(B) && (!muA || aligned16(muA)) &&
                         (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
     if (mfma64) {
-        const int mslices = cdiv(M, 32), npanels = cdiv(N, 64);
         const int sym = (A == B && muA == muB && lda == ldb && M == N) ? 1 : 0;  // Gram matrix: upper tiles only, then mirror
+        const bool ne5 = !sym && N % 80 == 0;  // l = 74 -> 80 columns: one 5-tile panel instead of two 4-tile ones
+        const int mslices = cdiv(M, 32), npanels = ne5 ? (int)(N / 80) : cdiv(N, 64);
         const int gx = cdiv(M, 128);
         int active = gx * npanels;  // workgroups per row chunk
         if (sym) {
@@ -3414,7 +3428,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         // budget), so the launch takes ceil(active * ns / 256) / ns of the single-split time; pick the ns that minimises it
         // (ties: fewer fp64 slabs), as long as the slabs stay a fraction of the input traffic
         const int64_t slab_cap = std::max<int64_t>(1, (int64_t)(0.4 * double(n) * double(M + (sym ? 0 : N)) * dtype_size(dt) / (double(M) * N * 8.0)));
-        const int64_t ns_max = std::min<int64_t>(std::min<int64_t>(64, slab_cap), std::max<int64_t>(1, n / 256));
+        const int64_t ns_max = std::min<int64_t>(std::min<int64_t>(128, slab_cap), std::max<int64_t>(1, n / 256));
         int64_t nsplit = 1;
         double best = 1e30;
         for (int64_t ns = 1; ns <= ns_max; ++ns) {
@@ -3428,15 +3442,16 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         double* part = (double*)dev_alloc(d, sizeof(double) * nsplit * M * N);
         const dim3 grid(sym ? active : gx, sym ? 1 : npanels, (unsigned)nsplit), block(256);
         TagScope ts(d);
-#define ATB64_LAUNCH(TT)                                                                                                          \
+#define ATB64_LAUNCH(TT, NEv)                                                                                                     \
         do {                                                                                                                      \
             const TT* Af = (const TT*)A; const TT* Bf = (const TT*)B; const TT* ma = (const TT*)muA; const TT* mb = (const TT*)muB; \
-            if (ma && mb) hipLaunchKernelGGL((k_atb_f64<TT, true, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
-            else if (ma) hipLaunchKernelGGL((k_atb_f64<TT, true, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
-            else if (mb) hipLaunchKernelGGL((k_atb_f64<TT, false, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
-            else hipLaunchKernelGGL((k_atb_f64<TT, false, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
+            if (ma && mb) hipLaunchKernelGGL((k_atb_f64<TT, true, true, NEv>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
+            else if (ma) hipLaunchKernelGGL((k_atb_f64<TT, true, false, NEv>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
+            else if (mb) hipLaunchKernelGGL((k_atb_f64<TT, false, true, NEv>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
+            else hipLaunchKernelGGL((k_atb_f64<TT, false, false, NEv>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, mb, n, chunk, part, sym); \
         } while (0)
-        if (dt == F64) ATB64_LAUNCH(double); else ATB64_LAUNCH(float);
+        if (dt == F64) { if (ne5) ATB64_LAUNCH(double, 5); else ATB64_LAUNCH(double, 4); }
+        else { if (ne5) ATB64_LAUNCH(float, 5); else ATB64_LAUNCH(float, 4); }
 #undef ATB64_LAUNCH
         launch_check();
         ts.stop();
