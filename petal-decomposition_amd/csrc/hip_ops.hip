@@ -3728,9 +3728,59 @@ void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode)
     dev_free(d, scratch);
 }
 
+// G = A^T A for a tall-skinny fp64 A (K x Mn, Mn a multiple of 16): the re-basing Gram matrices (l x l from a d x l
+// iterate).  One workgroup per upper 16 x 16 tile, its four waves take a quarter of K each on the fp64 matrix cores and
+// add through LDS; the mirror tile is written too.  (The general kernel needs a split-K launch plus a reduce launch here.)
+__global__ __launch_bounds__(256) void k_syrk_f64(const double* __restrict__ A, int64_t lda, int Mn, int64_t K,
+                                                  double* __restrict__ C, int64_t ldc) {
+    __shared__ double red[3][4][64];
+    const int nt = Mn >> 4;
+    int t = blockIdx.x, ti = 0;
+    while (t >= nt - ti) { t -= nt - ti; ++ti; }
+    const int tj = ti + t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+    const int64_t kq = ((K + 3) / 4 + 3) / 4 * 4, kbeg = wave * kq, kend = min(K, kbeg + kq);
+    const double* pa = A + 16 * ti + i;
+    const double* pb = A + 16 * tj + i;
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+    // the kernel is pure load latency (a wave's 32 MFMAs take 1 us): all operands of a 128-row batch are requested at once
+    for (int64_t kb = kbeg; kb < kend; kb += 128) {
+        double a[32], b[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int64_t k = kb + 4 * u + q;
+            const bool in = k < kend;
+            a[u] = in ? pa[k * lda] : 0.0;
+            b[u] = in ? pb[k * lda] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+            const int row = 16 * ti + q + 4 * r, col = 16 * tj + i;
+            C[(int64_t)row * ldc + col] = v;
+            if (ti != tj) C[(int64_t)col * ldc + row] = v;
+        }
+    }
+}
+
 void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
               const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
     if (M == 0 || N == 0) return;
+    if (ta && !tb && A == B && lda == ldb && M == N && M % 16 == 0 && M <= 256 && K >= 64 && alpha == 1.0 && beta == 0.0) {
+        const int nt = (int)(M / 16);
+        hipLaunchKernelGGL(k_syrk_f64, dim3(nt * (nt + 1) / 2), dim3(256), 0, d->stream, A, lda, (int)M, K, C, ldc);
+        launch_check();
+        return;
+    }
     const int64_t tiles = (int64_t)cdiv(N, 16) * cdiv(M, 16);
     int ks = 1;
     if (K >= 256 && tiles < 256) ks = (int)std::min<int64_t>(16, std::min<int64_t>(K / 64, (512 + tiles - 1) / tiles));
