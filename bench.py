@@ -334,7 +334,20 @@ def fastica_cfg3(petal, ctx, torch, dev, n=200000, d=256, nc=32):
     t0 = time.perf_counter()
     m200.fit(x, w_init=w0)
     fit200_ms = (time.perf_counter() - t0) * 1e3
+    # (ii) of SURVEY.md 8(d): the loop alone (ica_par, src/ica.rs:319-361) on already-whitened data X1 (nc x n), here the
+    # sample-major n x nc matrix handed over as its transposed view
+    xc = x - x.mean(dim=0, keepdim=True)
+    evals, evecs = torch.linalg.eigh((xc.T @ xc).double())
+    kmat = (evecs[:, -nc:] / evals[-nc:].sqrt()).float()             # d x nc
+    x1t = ((xc @ kmat) * float(np.sqrt(n))).contiguous()             # n x nc, unit covariance
+    for _ in range(3):
+        _w, it_loop = petal.ica_par(x1t.T, 1e-4, 200, w0, ctx=ctx)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        petal.ica_par(x1t.T, 1e-4, 200, w0, ctx=ctx)
+    loop_ms = (time.perf_counter() - t0) / reps * 1e3
     return {"shape": f"{n}x{d} fp32, n_components={nc}", "fit_ms": round(fit_ms, 3), "n_iter": m.n_iter,
+            "loop_only_on_whitened_ms": round(loop_ms, 3), "loop_only_n_iter": int(it_loop),
             "samples_per_s": round(n / (fit_ms * 1e-3), 1),
             "fit_fixed_200_iter_ms": round(fit200_ms, 3), "ms_per_iteration": round((fit200_ms - fit_ms) / max(200 - m.n_iter, 1), 4),
             "step_kernel": {"avg_launch_ms": round(step_ms, 5),
