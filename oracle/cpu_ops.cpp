@@ -42,6 +42,8 @@ void dev_sync(Dev*) {}
 void dev_set_profiling(Dev*, int) {}
 void dev_abort(Dev*) {}
 void dev_make_current(Dev*) {}
+int dev_push_current(Dev*) { return -1; }
+void dev_pop_current(Dev*, int) {}
 void dev_set_gemm_mode(Dev*, int) {}
 int dev_gemm_mode(const Dev*) { return 1; }
 void dev_reset_timing(Dev*) {}

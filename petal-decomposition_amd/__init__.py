@@ -265,10 +265,13 @@ class Context:
         self.rank, self.world_size = rank, world_size
 
     @staticmethod
-    def torch_allreduce_hook(group=None):
+    def torch_allreduce_hook(group=None, host_buffers=False):
         """The all-reduce hook as a Python callable ``hook(ptr, count, dtype, op, stream) -> 0``: wraps the raw
-        buffer zero-copy as a torch tensor and calls ``torch.distributed.all_reduce`` on ``group`` (backend "nccl" ==
-        RCCL over xGMI on ROCm, enqueued on the ctx stream; "gloo" for the host-simulation tests)."""
+        buffer zero-copy as a torch tensor and calls ``torch.distributed.all_reduce`` on ``group``.  Backend "nccl" ==
+        RCCL over xGMI on ROCm, enqueued on the ctx stream.  Backend "gloo" with DEVICE buffers (several ranks sharing one
+        GPU, where RCCL refuses to form a communicator; or a node without xGMI): the buffer is staged through the host in
+        stream order -- D2H on the ctx stream, gloo all-reduce, H2D on the ctx stream.  ``host_buffers=True`` is the
+        host-memory simulation of the CPU tests, whose "device" pointers are plain host pointers."""
         import torch
         import torch.distributed as dist
         ops = {PETAL_SUM: dist.ReduceOp.SUM, PETAL_MAX: dist.ReduceOp.MAX, PETAL_MIN: dist.ReduceOp.MIN}
@@ -280,13 +283,20 @@ class Context:
 
         def hook(ptr, count, dtype, op, stream):
             npdt = _np_dtype(dtype)
-            if backend == "gloo":
+            if host_buffers:
                 ctype = C.c_float if dtype == PETAL_F32 else C.c_double
                 view = np.ctypeslib.as_array((ctype * count).from_address(ptr))
                 t = torch.from_numpy(view)
                 dist.all_reduce(t, op=ops[op], group=group)
                 return 0
             t = torch.as_tensor(_Cai(ptr, count, np.dtype(npdt).str), device="cuda")
+            if backend == "gloo":
+                ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream()
+                with torch.cuda.stream(ext):
+                    h = t.cpu()                      # ordered behind the kernels queued on the ctx stream; blocks the host
+                    dist.all_reduce(h, op=ops[op], group=group)
+                    t.copy_(h)                       # pageable source: returns once staged, ordered on the ctx stream
+                return 0
             if stream:
                 with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
                     dist.all_reduce(t, op=ops[op], group=group)
@@ -316,7 +326,8 @@ class Context:
     def use_torch_distributed(self, group=None):
         """Sample-sharded multi-GPU: sum the small replicated buffers with torch.distributed."""
         import torch.distributed as dist
-        self.set_collective(self.torch_allreduce_hook(group), dist.get_rank(group), dist.get_world_size(group))
+        host_buffers = bool(getattr(self.lib, "_petal_host_buffers", False))
+        self.set_collective(self.torch_allreduce_hook(group, host_buffers), dist.get_rank(group), dist.get_world_size(group))
 
 
 _default_ctx = None

@@ -48,6 +48,15 @@ RankInfo rank_info(petal_ctx& c, int64_t n_local) {
     return r;
 }
 
+// Replicated random inputs (Omega, pca.rs:701-705; w_init, ica.rs:210-214): in the crate ONE model-owned generator draws
+// them; with one process per GPU every rank has its own generator, so rank 0's draw is the one every rank uses (the other
+// ranks' buffers are zeroed and the SUM all-reduce hands them rank 0's values bit for bit: x + 0 + ... + 0 = x).
+void replicate_from_rank0(petal_ctx& c, double* dev_buf, int64_t count) {
+    if (!sharded(c) || count == 0) return;
+    if (c.rank != 0) dev_memset(c.dev, dev_buf, 0, sizeof(double) * size_t(count));
+    allreduce_f64(c, dev_buf, count, PETAL_SUM);
+}
+
 // column means (pca.rs:520-528 / ica.rs:174): mu64 (device f64[dp]) and muT (device dtype[dp]); zeros if !centering
 // with_sq (centering only): mu64 has 2 dp entries, the second half holds the column sums of squares over all ranks,
 // from the same pass over X (total variance = sum_j (sq_j - n mu_j^2), formed in fp64 by the caller).
@@ -349,6 +358,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         dev_h2d_async(c.dev, raw.p, omega, raw.bytes);
         op_pad_to_f64(c.dev, dt, P.f64(), dp, LP, raw.p, d, L, l_req);
     }
+    replicate_from_rank0(c, P.f64(), dp * LP);
     DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
     DBuf ndead(c.dev, sizeof(int));
     c.stats.pass_flops = 2.0 * double(n) * double(d) * double(l_req);
@@ -697,6 +707,7 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
         dev_h2d(c.dev, W.p, h.data(), W.bytes);
     }
+    replicate_from_rank0(c, W.f64(), nc * nc);
     const int64_t iters = ica_loop(c, dt, X1T.p, n, nc, ncp, ri.n_total, W, tol, max_iter, mode);  // ica.rs:216
     if (n_iter) *n_iter = iters;
 
@@ -744,6 +755,7 @@ void ica_par(petal_ctx& c, const petal_matrix& x1, double tol, int64_t max_iter,
     std::vector<double> h(size_t(nc) * nc);
     for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
     dev_h2d(c.dev, W.p, h.data(), W.bytes);
+    replicate_from_rank0(c, W.f64(), nc * nc);
     const int64_t iters = ica_loop(c, dt, xp, n, nc, X1T.ld, ri.n_total, W, tol, max_iter, mode);
     dev_d2h(c.dev, h.data(), W.p, W.bytes);
     dev_sync(c.dev);

@@ -10,11 +10,22 @@ using namespace petal;
 
 namespace {
 
+// makes the ctx's device current on the calling thread for the duration of an entry point (the ctx may live on a device
+// other than the thread's current one, or be used from a thread that never called hipSetDevice) and restores the
+// previous device afterwards
+struct DeviceScope {
+    petal::Dev* dev;
+    int prev = -1;
+    explicit DeviceScope(petal::Dev* d) : dev(d) { if (dev) prev = dev_push_current(dev); }
+    ~DeviceScope() { if (dev) dev_pop_current(dev, prev); }
+};
+
 template <class F>
 int guarded(petal_ctx* ctx, F&& f) {
     if (!ctx) return PETAL_INVALID_INPUT;
     try {
         ctx->err.clear();
+        DeviceScope scope(ctx->dev);
         f();
         return PETAL_OK;
     } catch (const Error& e) {

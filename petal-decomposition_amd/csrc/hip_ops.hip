@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -83,6 +84,9 @@ struct Dev {
     struct Rec { int tag; hipEvent_t a, b; };
     std::vector<Rec> recs;
     KernelTiming acc;
+    // per-DEVICE launch state (hipFuncSetAttribute is per device: a second ctx on another GPU of the same process needs its own)
+    std::set<const void*> max_lds_set;
+    int num_cu = 0;
 };
 
 Dev* dev_create(int device, void* stream, char* err, size_t errlen) {
@@ -129,6 +133,15 @@ void dev_destroy(Dev* d) {
 
 void* dev_stream(Dev* d) { return d->stream; }
 void dev_make_current(Dev* d) { HIP_CHECK(hipSetDevice(d->device)); }
+int dev_push_current(Dev* d) {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != d->device) HIP_CHECK(hipSetDevice(d->device));
+    return prev;
+}
+void dev_pop_current(Dev* d, int prev) {
+    if (prev >= 0 && prev != d->device) (void)hipSetDevice(prev);
+}
 
 void* dev_alloc(Dev* d, size_t bytes) {
     const size_t sz = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
@@ -3191,7 +3204,16 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // split-product (bf16x3, see k_xp3) kernels unless the ctx asks for the fp32-MFMA ones (petal_ctx_set_gemm_mode /
 // PETAL_GEMM=fp32)
 static bool gemm_split_product(const Dev* d) { return d->gemm_mode == 0; }
-static void set_max_lds(const void* fn) { HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+// kernels that ask for more than 64 KB of dynamic LDS: the attribute is set once per device (ctx)
+static void set_max_lds(Dev* d, const void* fn) {
+    if (d->max_lds_set.count(fn)) return;
+    HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    d->max_lds_set.insert(fn);
+}
+static int num_cus(Dev* d) {
+    if (!d->num_cu) { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, d->device)); d->num_cu = prop.multiProcessorCount; }
+    return d->num_cu;
+}
 
 template <int RT, int NT>
 static void launch_xp(Dev* d, const float* X, int64_t n, int K, int64_t ldx, const float* mu, const float* Ppk, int NTtot,
@@ -3313,8 +3335,7 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
     }
     static const bool use_classic = [] { const char* e = getenv("PETAL_K1_CLASSIC"); return e && e[0] == '1'; }();
     static const bool force_pers = [] { const char* e = getenv("PETAL_K1_PERS"); return e && e[0] == '1'; }();
-    static int num_cu = 0;
-    if (!num_cu) { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, d->device)); num_cu = prop.multiProcessorCount; }
+    const int num_cu = num_cus(d);
     // Form selection (measured, MI355X): with fewer than two 64-row tiles per wave slot the grid form leaves SIMDs
     // a whole 64-row tile apart (100000 x 512: 74 TFLOP/s) and the balanced persistent form wins (84); with many tiles
     // per slot the hardware dispatcher balances the grid form dynamically and it is the faster one (1e6 x 512: 95 vs 76).
@@ -3481,8 +3502,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     // kernel: paced by loads in flight -- 512 workgroups = two per CU measured 67 vs 75 us at 100000 x 512)
     const int mslices = cdiv(M, 64);
     static const int waves_env = [] { const char* e = getenv("PETAL_K2_WAVES"); return e ? atoi(e) : 0; }();
-    static int num_cu2 = 0;
-    if (!num_cu2) { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, d->device)); num_cu2 = prop.multiProcessorCount; }
+    const int num_cu2 = num_cus(d);
     // (at 100000 rows the extra 128 slabs cost k_sum_parts2 what the kernel gains: two per CU only for long row ranges)
     const int waves_target = waves_env > 0 ? waves_env : num_cu2 * ((gemm_split_product(d) && !muB && n >= 400000) ? 8 : 4);
     int64_t nsplit = std::max<int64_t>(1, waves_target / mslices);
@@ -3705,8 +3725,7 @@ void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX
     const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
     const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 4 * nc * (nc | 1) : 0));
     MB_DISPATCH(mb, {
-        static bool once = false;
-        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_ica_tail<MBv>)); once = true; }
+        set_max_lds(d, reinterpret_cast<const void*>(k_ica_tail<MBv>));
         hipLaunchKernelGGL(k_ica_tail<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, (int)nc, n_total, W, GX_gp, mode, tol,
                            state, iter, scratch, wpk3, d->ica_ortho_tol2);
     });
@@ -3720,8 +3739,7 @@ void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode)
     const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
     const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 3 * nc * (nc | 1) : 0));
     MB_DISPATCH(mb, {
-        static bool once = false;
-        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_symdecorr<MBv>)); once = true; }
+        set_max_lds(d, reinterpret_cast<const void*>(k_symdecorr<MBv>));
         hipLaunchKernelGGL(k_symdecorr<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, Win, Wout, (int)nc, mode, scratch);
     });
     launch_check();
@@ -3806,8 +3824,7 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     if (Lz < L) Lz = L;
     static const bool force_old = getenv("PETAL_CHOL_OLD") != nullptr;
     if (L <= CHOL2_MAXL && !force_old) {
-        static bool attr2 = false;
-        if (!attr2) { set_max_lds(reinterpret_cast<const void*>(k_chol_inv2)); attr2 = true; }
+        set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
         hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol,
                            ndead, (int)Lz);
         launch_check();
@@ -3818,8 +3835,7 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     const size_t cap = 160 * 1024 - 256;
     const int t_mode = full <= cap ? 1 : (packed <= cap ? 2 : 0);
     const size_t lds = t_mode == 1 ? full : (t_mode == 2 ? packed : base);
-    static bool attr_set = false;
-    if (!attr_set) { set_max_lds(reinterpret_cast<const void*>(k_chol_inv)); attr_set = true; }
+    set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv));
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_mode, ndead, (int)Lz);
     launch_check();
 }
@@ -3844,8 +3860,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         const size_t lds = jaca_lds_bytes((int)L);
 #define JACA_CASE(M, G)                                                                                                  \
     case 10 * M + (G == 32 ? 1 : 0): {                                                                                   \
-        static bool once = false;                                                                                        \
-        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_jacobi_a<M, G>)); once = true; }                        \
+        set_max_lds(d, reinterpret_cast<const void*>(k_jacobi_a<M, G>));                        \
         hipLaunchKernelGGL((k_jacobi_a<M, G>), dim3(1), dim3(threads), lds, d->stream, A, (int)L, lda, log_cs, nrounds, w, rank, pw); \
     } break;
         switch (10 * std::min(mb2, 5) + (gw == 32 ? 1 : 0)) {
@@ -3867,8 +3882,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     double* Vtmp = (double*)dev_alloc(d, sizeof(double) * L * L);
     const size_t lds = sizeof(double) * jac_ws_doubles((int)L, 1024);
     {
-        static bool once = false;
-        if (!once) { set_max_lds(reinterpret_cast<const void*>(k_eigh<0>)); once = true; }
+        set_max_lds(d, reinterpret_cast<const void*>(k_eigh<0>));
         hipLaunchKernelGGL(k_eigh<0>, dim3(1), dim3(1024), lds, d->stream, A, (int)L, lda, Vtmp, V, ldv, w);
     }
     launch_check();

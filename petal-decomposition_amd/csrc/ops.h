@@ -43,6 +43,8 @@ void  dev_set_profiling(Dev*, int level);   // 0 off, 1 one sampled launch per t
 void  dev_set_gemm_mode(Dev*, int mode);    // 0 = split-product (bf16x3) GEMM kernels for fp32 data, 1 = fp32-MFMA kernels
 int   dev_gemm_mode(const Dev*);
 void  dev_make_current(Dev*);               // hipSetDevice(the ctx's device) on the calling thread
+int   dev_push_current(Dev*);               // the same, returning the thread's previous device (-1: none) ...
+void  dev_pop_current(Dev*, int prev);      // ... which this restores: every ABI entry point brackets its work with the pair
 void  dev_abort(Dev*);                     // error path: wait for the stream, drop queued device-to-host hand-overs
 void  dev_reset_timing(Dev*);
 void  dev_set_tag(Dev*, int tag);

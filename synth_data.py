@@ -3,15 +3,18 @@ oracle; numpy only)."""
 import numpy as np
 
 
-def synth_pca(n, d, k, seed, dtype=np.float32, noise=0.01):
+def synth_pca(n, d, k, seed, dtype=np.float32, noise=0.01, row_seed=None):
     """Planted low-rank + noise + means:  X = (G diag(s)) V^T + noise*N + 1 mu^T,  G n x r iid N(0,1)/sqrt(n),
-    r = 2k, V d x r orthonormal, s_i = 100 sqrt(n) rho^i, rho = 10^(-3/k)  (sigma_1 / sigma_k = 1e3)."""
+    r = 2k, V d x r orthonormal, s_i = 100 sqrt(n) rho^i, rho = 10^(-3/k)  (sigma_1 / sigma_k = 1e3).
+    row_seed (sample-sharded runs): V and mu come from `seed` (shared by all row blocks), the rows from `row_seed`."""
     rng = np.random.default_rng(seed)
     r = min(2 * k, d, n)
     rho = 10.0 ** (-3.0 / max(k, 1))
     v, _ = np.linalg.qr(rng.standard_normal((d, r)))
     s = 100.0 * np.sqrt(n) * rho ** np.arange(r)
     mu = rng.standard_normal(d)
+    if row_seed is not None:
+        rng = np.random.default_rng(row_seed)
     x = np.empty((n, d), dtype=dtype)
     step = 65536
     for i in range(0, n, step):
@@ -21,10 +24,13 @@ def synth_pca(n, d, k, seed, dtype=np.float32, noise=0.01):
     return x
 
 
-def synth_ica(n, d, nc, seed, dtype=np.float32, noise=0.01):
-    """Laplace sources through a Gaussian mixing matrix + noise:  X = S A + noise*N."""
+def synth_ica(n, d, nc, seed, dtype=np.float32, noise=0.01, row_seed=None):
+    """Laplace sources through a Gaussian mixing matrix + noise:  X = S A + noise*N.
+    row_seed (sample-sharded runs): A comes from `seed` (shared by all row blocks), the rows from `row_seed`."""
     rng = np.random.default_rng(seed)
     a = rng.standard_normal((nc, d))
+    if row_seed is not None:
+        rng = np.random.default_rng(row_seed)
     x = np.empty((n, d), dtype=dtype)
     step = 65536
     for i in range(0, n, step):

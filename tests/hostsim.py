@@ -27,4 +27,6 @@ def build() -> str:
 
 def context():
     import petal_decomposition_amd as petal
-    return petal.Context(0, lib=petal.load_library(build(), preload_torch=False))
+    lib = petal.load_library(build(), preload_torch=False)
+    lib._petal_host_buffers = True   # this library's "device" pointers are host pointers (collective hook)
+    return petal.Context(0, lib=lib)

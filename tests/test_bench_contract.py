@@ -13,8 +13,13 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "dtype", "data", "config", "roofline"]
 
 
-def _run(*extra):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+def _run(*extra, launcher_env=True, n_gpus=1):
+    env = dict(os.environ)
+    if launcher_env:
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    else:  # as the driver runs it at N = 1 / as a user runs `python bench.py --gpus N`: no launcher variables at all
+        for key in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(key, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-northstar", *extra],
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -23,7 +28,7 @@ def _run(*extra):
     rec = json.loads(lines[0])
     for key in REQUIRED:
         assert key in rec, key
-    assert rec["steps"] == 3 and rec["warmup"] == 1 and rec["n_gpus"] == 1
+    assert rec["steps"] == 3 and rec["warmup"] == 1 and rec["n_gpus"] == n_gpus
     assert rec["value"] > 0 and rec["higher_is_better"] is True and rec["vs_baseline"] is None
     assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(rec["roofline"])
     assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-3
@@ -48,3 +53,37 @@ def test_single_gpu_record():
 def test_sharded_path_record_one_rank_group():
     rec = _run("--single-rank-group", "--no-cpu-baseline")
     assert rec["config"]["collective"].startswith("built-in RCCL"), rec["config"]["collective"]
+
+
+def test_gpus_flag_disagreeing_with_the_launcher_is_refused():
+    """--gpus N must equal WORLD_SIZE when a launcher set it: never a one-GPU measurement labelled otherwise"""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode != 0 and res.stdout.strip() == "" and "WORLD_SIZE" in res.stderr
+
+
+def test_self_launch_refuses_when_gpus_are_missing():
+    """`python bench.py --gpus N` with no launcher starts the ranks itself -- and refuses, before touching any GPU, when the node
+    shows fewer than N devices (this container: 0; the one-GPU box: 1)."""
+    import torch
+    want = torch.cuda.device_count() + 1
+    if want < 2:
+        want = 2
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want)], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert res.returncode != 0 and res.stdout.strip() == "" and "refusing" in res.stderr
+
+
+@pytest.mark.gpu
+def test_self_launch_single_gpu_without_launcher_variables():
+    rec = _run("--no-cpu-baseline", launcher_env=False)
+    assert rec["config"]["collective"] == "none" and rec["roofline"]["traffic_measured_at"]
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_sharing_the_gpu():
+    """The launcher path end to end with N = 2 on the one-GPU box: bench.py starts two rank processes itself (fresh children,
+    before any GPU call), they share GPU 0 and all-reduce over gloo; rank 0 prints the one record with n_gpus = 2."""
+    rec = _run("--gpus", "2", "--share-gpu", "--no-cpu-baseline", launcher_env=False, n_gpus=2)
+    assert "SHARE GPU 0" in rec["config"]["collective"] and rec["config"]["parallelism"] == "sample-sharded x2"

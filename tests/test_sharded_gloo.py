@@ -54,6 +54,12 @@ def _worker(rank, world, port, out_dir):
     ica = petal.FastIca(ctx=ctx)
     res["ica_y"] = ica.fit_transform(xis, w_init=w0)
     res["ica_components"], res["ica_n_iter"] = ica.components, np.array([ica.n_iter])
+    # no explicit Omega / w_init: every rank's model owns a differently seeded generator; the library must replicate
+    # rank 0's draw or the ranks diverge (FastICA: different stop iterations -> a hung all-reduce)
+    m2 = petal.RandomizedPca(k, ctx=ctx, n_iter=4, rng=np.random.default_rng(100 + rank)).fit(xs)
+    res["own_rpca_components"], res["own_rpca_singular"] = m2.components(), m2.singular_values()
+    ica2 = petal.FastIca(np.random.default_rng(200 + rank), ctx).fit(xis)
+    res["own_ica_components"], res["own_ica_n_iter"] = ica2.components, np.array([ica2.n_iter])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -76,7 +82,8 @@ def test_two_rank_sharded_matches_single(tmp_path):
     ctx = hostsim.context()
     # every replicated result is identical on both ranks
     for key in ("rpca_components", "rpca_singular", "rpca_mean", "rpca_evr", "pca_components", "pca_singular",
-                "ica_components", "ica_n_iter"):
+                "ica_components", "ica_n_iter", "own_rpca_components", "own_rpca_singular", "own_ica_components",
+                "own_ica_n_iter"):
         assert np.array_equal(r0[key], r1[key]), key
 
     n, d, k = 3001, 48, 6
@@ -93,6 +100,10 @@ def test_two_rank_sharded_matches_single(tmp_path):
     o = po.RandomizedPcaOracle(k, n_iter=4).fit(x.astype(np.float64), omega=om.astype(np.float64))
     assert pc.rowwise_rel(r0["rpca_components"].astype(np.float64), o.components).max() < 1e-5
 
+    own = petal.RandomizedPca(k, ctx=ctx, n_iter=4, rng=np.random.default_rng(100)).fit(x)   # rank 0's generator
+    assert pc.rowwise_rel(r0["own_rpca_components"], own.components()).max() < 2e-6
+    assert np.allclose(r0["own_rpca_singular"], own.singular_values(), rtol=2e-6)
+
     x64 = synth_pca(900, 12, 3, seed=78, dtype=np.float64)
     o = po.PcaOracle(3)
     yo = o.fit_transform(x64)
@@ -107,3 +118,6 @@ def test_two_rank_sharded_matches_single(tmp_path):
     assert int(r0["ica_n_iter"][0]) == si.n_iter
     assert np.allclose(r0["ica_components"], si.components, atol=1e-9)
     assert np.allclose(np.concatenate([r0["ica_y"], r1["ica_y"]]), ysi, atol=1e-9)
+    own = petal.FastIca(np.random.default_rng(200), ctx).fit(xi)
+    assert int(r0["own_ica_n_iter"][0]) == own.n_iter
+    assert np.allclose(r0["own_ica_components"], own.components, atol=1e-9)
