@@ -197,16 +197,20 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
         }
     }
 }
-void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w) {
+void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel) {
     for (int64_t i = 0; i < L; ++i)
         for (int64_t j = 0; j < L; ++j) V[i * ldv + j] = (i == j);
-    bool last = false;
     for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0, diag = 0;
+        // the device's stopping rule (hip_ops.hip, wg_jacobi_violation): a_pq^2 <= tol^2 |a_pp a_qq| or below the rounding floor
+        double diag = 0, viol = 0;
+        for (int64_t i = 0; i < L; ++i) diag += A[i * lda + i] * A[i * lda + i];
+        if (!(diag > 0) || !(diag < 1e300)) break;
         for (int64_t i = 0; i < L; ++i)
-            for (int64_t j = 0; j < L; ++j) (i == j ? diag : off) += A[i * lda + j] * A[i * lda + j];
-        if (off <= 1e-30 * diag || off == 0 || last) break;
-        if (off <= 1e-14 * diag) last = true;
+            for (int64_t j = i + 1; j < L; ++j) {
+                const double v = A[i * lda + j];
+                if (v != 0) viol = std::max(viol, v * v / std::max(tol_rel * tol_rel * std::fabs(A[i * lda + i] * A[j * lda + j]), 1e-32 * diag));
+            }
+        if (!(viol > 1.0)) break;
         for (int64_t p = 0; p < L - 1; ++p)
             for (int64_t q = p + 1; q < L; ++q) {
                 const double apq = A[p * lda + q];
@@ -281,6 +285,15 @@ void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode)
     // That form depends on LAPACK's eigenvector signs; for nc == 2 LAPACK's 2x2 solver (dlaev2 + ascending
     // sort) returns a SYMMETRIC Z for any PSD input, which makes the literal form equal the textbook one.
     const bool literal = mode == 1 && nc > 2;
+    std::vector<double> sg(nc, 1.0);  // sign normalisation of the eigenvectors (first largest component positive), see hip_ops.hip
+    if (literal)
+        for (int64_t c = 0; c < nc; ++c) {
+            double best = -1.0;
+            for (int64_t k = 0; k < nc; ++k) {
+                const double v = Z[k * nc + c];
+                if (std::fabs(v) > best) { best = std::fabs(v); sg[c] = v < 0.0 ? -1.0 : 1.0; }
+            }
+        }
     for (int64_t i = 0; i < nc; ++i)
         for (int64_t j = 0; j < nc; ++j) {
             double acc = 0;
@@ -292,7 +305,7 @@ void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode)
                     acc += Z[i * nc + k] * (1.0 / std::sqrt(w[k])) * Z[j * nc + k];
                 }
             }
-            M[i * nc + j] = acc;
+            M[i * nc + j] = literal ? acc * sg[nc - 1 - i] * sg[nc - 1 - j] : acc;
         }
     op_dgemm(d, false, false, nc, nc, nc, 1.0, M.data(), nc, Win, nc, 0.0, Wout, nc);
 }

@@ -279,7 +279,14 @@ def logcosh(wx: np.ndarray):
     return g, gp
 
 
-def symmetric_decorrelation(w: np.ndarray, literal: bool = False) -> np.ndarray:
+def _normalise_eigenvector_signs(v: np.ndarray) -> np.ndarray:
+    """rows of v (= eigenvectors, lapack_eigh's convention) with their first largest-magnitude component made positive"""
+    idx = np.argmax(np.abs(v), axis=1)
+    sg = np.where(v[np.arange(v.shape[0]), idx] < 0, -1.0, 1.0)
+    return v * sg[:, None]
+
+
+def symmetric_decorrelation(w: np.ndarray, literal: bool = False, normalise_signs: bool = False) -> np.ndarray:
     """symmetric_decorrelation (ica.rs:363-381).
 
     literal=True reproduces the crate's arithmetic exactly: ``v`` is the heev buffer read
@@ -288,6 +295,11 @@ def symmetric_decorrelation(w: np.ndarray, literal: bool = False) -> np.ndarray:
     (W W^T)^(-1/2) W = Z D Z^T W the crate documents.  Identical whenever Z is symmetric (all
     2x2 reference tests)."""
     e, v = lapack_eigh(w @ w.T)
+    if normalise_signs:
+        # The literal form changes under eigenvector sign flips; LAPACK's raw signs are backend artefacts (MKL in the
+        # crate's CI, OpenBLAS here).  normalise_signs=True fixes them the way the device's literal mode does, so the
+        # two can be compared element by element for nc > 2 (the textbook form is sign-invariant).
+        v = _normalise_eigenvector_signs(v)
     s = 1.0 / np.sqrt(e)
     if literal:
         v_t = v.T.copy()
@@ -296,17 +308,18 @@ def symmetric_decorrelation(w: np.ndarray, literal: bool = False) -> np.ndarray:
     return (z * s[None, :]) @ z.T @ w
 
 
-def ica_par(x1: np.ndarray, tol: float, max_iter: int, w_init: np.ndarray, literal: bool = False):
+def ica_par(x1: np.ndarray, tol: float, max_iter: int, w_init: np.ndarray, literal: bool = False,
+            normalise_signs: bool = False):
     """ica_par (ica.rs:319-361).  x1 is nc x n (whitened).  Returns (W, n_iter).
 
     literal=True uses the crate's convergence test rows(W1) . columns(W) (ica.rs:345-349, Q4)
     and the literal decorrelation; literal=False the textbook rows . rows."""
-    w = symmetric_decorrelation(w_init, literal)
+    w = symmetric_decorrelation(w_init, literal, normalise_signs)
     p_inv = 1.0 / x1.shape[1]
     for i in range(max_iter):
         g, gp = logcosh(w @ x1)
         d = g @ x1.T * p_inv - gp[:, None] * w
-        w1 = symmetric_decorrelation(d, literal)
+        w1 = symmetric_decorrelation(d, literal, normalise_signs)
         if literal:
             dots = np.einsum("ij,ji->i", w1, w)
         else:

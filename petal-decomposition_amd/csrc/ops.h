@@ -109,8 +109,11 @@ void op_dgemm(Dev*, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double al
 // Lz > L: T is additionally zero-filled out to Lz x Lz (the padded extent of the caller's buffers).
 void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead = nullptr,
                  int64_t Lz = 0);
-// symmetric A (L x L) -> eigenvalues w (descending) and eigenvectors in the COLUMNS of V.  A may be destroyed.
-void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w);
+// symmetric PSD A (L x L) -> eigenvalues w (descending) and eigenvectors in the COLUMNS of V.  A may be destroyed.
+// tol_rel: off-diagonal elements are annihilated down to |a_pq| <= tol_rel sqrt(a_pp a_qq) (graded matrices keep the
+// relative accuracy of their small eigenvalues) or to the 1e-16 ||diag|| rounding floor; 1e-15 for fp64 data, 1e-8 is
+// ample when the matrix was formed from fp32 data.
+void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel = 1e-15);
 // x[i] *= alpha
 void op_dscal(Dev*, double* x, int64_t count, double alpha);
 // y[i] += alpha * x[i]

@@ -52,3 +52,12 @@ def test_topk_subspace_eigensolver_paths(ctx):
 
 def test_edge_cases(ctx):
     pc.edge_cases(ctx)
+
+
+@pytest.mark.parametrize("nc", [3, 4, 8])
+def test_ica_literal_mode_matches_the_literal_oracle(ctx, nc):
+    pc.ica_literal_parity(ctx, nc, seed=nc)
+
+
+def test_ica_literal_convergence_test_at_nc2(ctx):
+    pc.ica_literal_convergence_nc2(ctx)
