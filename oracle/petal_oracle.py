@@ -214,7 +214,16 @@ class _PcaBase:
 
 
 class PcaOracle(_PcaBase):
-    """Pca<A> (pca.rs:41-232): centre -> gesvd('A','A') -> svd_flip -> top-k."""
+    """Pca<A> (pca.rs:41-232): centre -> gesvd('A','A') -> svd_flip -> top-k.
+
+    thin=True takes the same decomposition from the economy driver (gesdd 'S'): only the first min(n, d) columns of U are
+    ever read (svd_flip zips U columns with V^T rows; transform_with_u takes k of them), so every output is the same -- but
+    the O(n^2) full U of the crate is not formed, which keeps the oracle to seconds at d = 2048.
+    tests/test_oracle_golden.py checks thin against the literal path."""
+
+    def __init__(self, n_components, centering=True, thin=False):
+        super().__init__(n_components, centering)
+        self.thin = thin
 
     def _inner_fit(self, x):
         self._check(x)
@@ -227,7 +236,10 @@ class PcaOracle(_PcaBase):
         else:
             means = np.zeros(d, dtype=x.dtype)
             xc = x.copy()
-        u, sigma, vt = lapack_svd_full(np.ascontiguousarray(xc))   # pca.rs:216-220
+        if self.thin:
+            u, sigma, vt = lapack_svddc(np.ascontiguousarray(xc))
+        else:
+            u, sigma, vt = lapack_svd_full(np.ascontiguousarray(xc))   # pca.rs:216-220
         svd_flip(u, vt)                                        # pca.rs:223
         self.total_variance = float(sigma @ sigma)             # pca.rs:224
         self.components = vt[: self.n_components].copy()

@@ -2135,8 +2135,11 @@ constexpr int CHOL2_MAXL = 140;
 __host__ __device__ inline size_t chol2_lds_bytes(int L) {
     return sizeof(double) * ((size_t)L * (L + 1) + 2 * (size_t)L) + sizeof(int) * (size_t)L;
 }
+// gd_ref (nullable): the diagonal the pivots are compared with (rel_tol * gd_ref[j]) when G is a Schur complement of a
+// larger matrix (blocked factorisation of L > 200: the dependence test stays relative to the ORIGINAL diagonal)
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T,
-                                                            int64_t ldt, double rel_tol, int* __restrict__ ndead_out, int Lz) {
+                                                            int64_t ldt, double rel_tol, int* __restrict__ ndead_out, int Lz,
+                                                            const double* __restrict__ gd_ref) {
     extern __shared__ __attribute__((aligned(16))) double sm_chol[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int np = L * (L + 1) / 2;
@@ -2151,7 +2154,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
             const double g = G[(int64_t)r * ldg + c];
             Rc[cp(r, c)] = g;
             Tc[cp(r, c)] = 0.0;
-            if (c == r) gd[r] = g;
+            if (c == r) gd[r] = gd_ref ? gd_ref[r] : g;
         }
     }
     for (int e = tid; e < Lz * Lz; e += nt) {  // zero padding of the output beyond the factored block
@@ -2565,7 +2568,7 @@ __device__ void wg_sort_eig(const double* A, int64_t lda, const double* V, int64
     __syncthreads();
 }
 
-constexpr int EIG_MAXL = 1024;
+constexpr int EIG_MAXL = 8192;
 struct JacWs { double* c; double* s; double* red; int* p; int* q; int* rank; };
 __host__ __device__ inline size_t jac_ws_doubles(int L, int nthreads) {
     const int half = ((L + 1) & ~1) / 2;
@@ -3180,6 +3183,27 @@ __global__ void k_cvt_to_f64(double* dst, const T* src, int64_t count) {
     if (e < count) dst[e] = (double)src[e];
 }
 
+// ---- FastICA step with more than 64 components: the pieces around the two GEMM kernels -------------------------------
+__global__ void k_transpose_pad(const double* __restrict__ W, int64_t nc, double* __restrict__ WT, int64_t ncp) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ncp * ncp) return;
+    const int64_t k = e / ncp, i = e - k * ncp;  // WT[k][i] = W[i][k]
+    WT[e] = (k < nc && i < nc) ? W[i * nc + k] : 0.0;
+}
+template <class T>
+__global__ void k_tanh_inplace(T* __restrict__ x, int64_t count) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) x[e] = (T)tanh((double)x[e]);
+}
+// GX_gp = [ GXp[:nc, :nc] | n - sum_s g_si^2 ]   (sum_s (1 - g^2) = n - sum g^2, fp64)
+__global__ void k_ica_big_out(const double* __restrict__ GXp, const double* __restrict__ sumsq, double n, int64_t nc, int64_t ncp,
+                              double* __restrict__ GX_gp, const int* __restrict__ state) {
+    if (state && state[0]) return;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nc * nc) GX_gp[e] = GXp[(e / nc) * ncp + (e % nc)];
+    else if (e < nc * nc + nc) GX_gp[e] = n - sumsq[e - nc * nc];
+}
+
 // ================================================================================================
 // host-side launchers
 // ================================================================================================
@@ -3651,8 +3675,32 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
     d->ica_wpk3_for = nullptr;  // (only the split-product path below asks the tail kernel to keep the planes current)
     if (n == 0) { dev_memset(d, GX_gp, 0, sizeof(double) * cnt); return; }
     const bool mfma = dt == F32 && nc <= 64 && ld % 4 == 0 && ld >= (nc + 15) / 16 * 16 && aligned16(X1T) && n >= 256;
+    if (nc > 64) {
+        // more than 64 components (the crate's default is min(n, d) of them, src/ica.rs:173): the step as it stands in the
+        // reference -- S = X1^T W^T (ica.rs:332), g = tanh (ica.rs:388-396), G^T X1 (ica.rs:333) -- on the two X-streaming
+        // GEMM kernels, with g' from the column sums of g^2.  Unfused: S makes one round trip through HBM.
+        const int64_t ncp = (nc + 15) / 16 * 16;
+        if (ld < ncp) throw std::runtime_error("ica_step: leading dimension below the padded component count");
+        double* WT = (double*)dev_alloc(d, sizeof(double) * ncp * ncp);
+        hipLaunchKernelGGL(k_transpose_pad, dim3(cdiv(ncp * ncp, 256)), dim3(256), 0, d->stream, W, nc, WT, ncp);
+        launch_check();
+        void* S = dev_alloc(d, dtype_size(dt) * (size_t)n * ncp);
+        op_gemm_xp(d, dt, X1T, n, ncp, ld, nullptr, WT, ncp, ncp, nullptr, S, ncp, nullptr);
+        const int saved_tag = d->tag;
+        d->tag = TAG_NONE;  // (only the first product is bracketed as "the step kernel")
+        DISPATCH_T(dt, hipLaunchKernelGGL(k_tanh_inplace<T>, dim3(cdiv((int64_t)n * ncp, 256)), dim3(256), 0, d->stream, (T*)S, (int64_t)n * ncp));
+        launch_check();
+        double* cs = (double*)dev_alloc(d, sizeof(double) * 2 * ncp);
+        op_colsum(d, dt, S, n, ncp, ncp, cs, true);
+        double* GXp = (double*)dev_alloc(d, sizeof(double) * ncp * ncp);
+        op_gemm_atb(d, dt, S, ncp, ncp, nullptr, X1T, ld, ncp, nullptr, n, GXp, ncp);
+        hipLaunchKernelGGL(k_ica_big_out, dim3(cdiv(cnt, 256)), dim3(256), 0, d->stream, GXp, cs + ncp, (double)n, nc, ncp, GX_gp, state);
+        launch_check();
+        d->tag = saved_tag;
+        dev_free(d, GXp); dev_free(d, cs); dev_free(d, S); dev_free(d, WT);
+        return;
+    }
     if (!mfma) {
-        if (nc > 64) throw std::runtime_error("FastICA on the device supports at most 64 components in this build");
         const int64_t nparts = cdiv(n, 64);
         double* part = (double*)dev_alloc(d, sizeof(double) * nparts * cnt);
         TagScope ts(d);
@@ -3839,15 +3887,56 @@ void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double 
                        beta, C, ldc, K, (double*)nullptr);
     launch_check();
 }
+__global__ void k_copy_diag(const double* __restrict__ G, int64_t ldg, int64_t L, double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < L) out[j] = G[j * ldg + j];
+}
+// L beyond the one-workgroup kernels (k + n_oversample > 200): blocked right-looking factorisation on the chip-wide fp64
+// GEMM kernel, 128-wide diagonal blocks by k_chol_inv2 (which hands back T_JJ = R_JJ^-1 directly):
+//   G_J,J.. -= sum_{K<J} R_KJ^T R_K,J..;  T_JJ = chol_inv(G_JJ);  R_J,rest = T_JJ^T G_J,rest;
+//   T_IJ = -T_II sum_{K=I+1..J} R_IK T_KJ, block super-diagonal by block super-diagonal.
+static void chol_inv_blocked(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead,
+                             int64_t Lz) {
+    constexpr int64_t B = 128;
+    const int64_t nb = (L + B - 1) / B;
+    double* W = (double*)dev_alloc(d, sizeof(double) * L * L);      // working copy of G (Schur complements of the diagonal blocks)
+    double* R = (double*)dev_alloc(d, sizeof(double) * L * L);      // off-diagonal blocks of the factor
+    double* gd = (double*)dev_alloc(d, sizeof(double) * L);
+    double* tmp = (double*)dev_alloc(d, sizeof(double) * B * B);
+    HIP_CHECK(hipMemcpy2DAsync(W, L * sizeof(double), G, ldg * sizeof(double), L * sizeof(double), L, hipMemcpyDeviceToDevice, d->stream));
+    hipLaunchKernelGGL(k_copy_diag, dim3(cdiv(L, 256)), dim3(256), 0, d->stream, G, ldg, L, gd);
+    launch_check();
+    HIP_CHECK(hipMemset2DAsync(T, ldt * sizeof(double), 0, Lz * sizeof(double), Lz, d->stream));
+    set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
+    for (int64_t J = 0; J < nb; ++J) {
+        const int64_t j0 = J * B, bj = std::min(B, L - j0), rest = L - j0 - bj;
+        if (j0 > 0)  // block row J of the Schur complement (its diagonal block and everything right of it)
+            op_dgemm(d, true, false, bj, L - j0, j0, -1.0, R + j0, L, R + j0, L, 1.0, W + j0 * L + j0, L);
+        hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)bj), d->stream, W + j0 * L + j0, (int)bj, L,
+                           T + j0 * ldt + j0, ldt, rel_tol, ndead, (int)bj, (const double*)(gd + j0));
+        launch_check();
+        if (rest > 0)
+            op_dgemm(d, true, false, bj, rest, bj, 1.0, T + j0 * ldt + j0, ldt, W + j0 * L + j0 + bj, L, 0.0, R + j0 * L + j0 + bj, L);
+    }
+    for (int64_t dl = 1; dl < nb; ++dl)
+        for (int64_t I = 0; I + dl < nb; ++I) {
+            const int64_t Jb = I + dl, i0 = I * B, bi = std::min(B, L - i0), j0 = Jb * B, bj = std::min(B, L - j0);
+            const int64_t k0 = i0 + bi, kk = j0 + bj - k0;  // rows k0 .. j0 + bj of column block J of T are final
+            op_dgemm(d, false, false, bi, bj, kk, 1.0, R + i0 * L + k0, L, T + k0 * ldt + j0, ldt, 0.0, tmp, bj);
+            op_dgemm(d, false, false, bi, bj, bi, -1.0, T + i0 * ldt + i0, ldt, tmp, bj, 0.0, T + i0 * ldt + j0, ldt);
+        }
+    dev_free(d, tmp); dev_free(d, gd); dev_free(d, R); dev_free(d, W);
+}
+
 void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz) {
     if (L == 0) return;
-    if (L > CHOL_MAXL) throw std::runtime_error("chol_inv: matrix too large for the one-workgroup LDS kernel (L <= 200)");
     if (Lz < L) Lz = L;
+    if (L > CHOL_MAXL) { chol_inv_blocked(d, G, L, ldg, T, ldt, rel_tol, ndead, Lz); return; }
     static const bool force_old = getenv("PETAL_CHOL_OLD") != nullptr;
     if (L <= CHOL2_MAXL && !force_old) {
         set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
         hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol,
-                           ndead, (int)Lz);
+                           ndead, (int)Lz, (const double*)nullptr);
         launch_check();
         return;
     }
@@ -3900,7 +3989,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         dev_free(d, buf);
         return;
     }
-    double* Vtmp = (double*)dev_alloc(d, sizeof(double) * L * L);
+    double* Vtmp = (double*)dev_alloc(d, sizeof(double) * L * lda);  // (the kernel indexes it with A's leading dimension)
     const size_t lds = sizeof(double) * jac_ws_doubles((int)L, 1024);
     {
         set_max_lds(d, reinterpret_cast<const void*>(k_eigh<0>));

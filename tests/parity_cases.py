@@ -197,7 +197,7 @@ def gemm_exact(ctx, n, K, N, seed=0, device=False, dtype=np.float32):
 
 
 # ---- model parity against the oracle on seeded synthetic inputs -----------------------------------
-def rpca_parity(ctx, n, d, k, n_iter, seed, dtype=np.float32, tol=1e-5, device=False, centering=True):
+def rpca_parity(ctx, n, d, k, n_iter, seed, dtype=np.float32, tol=1e-5, device=False, centering=True, tol_sigma=None):
     """same X, same Omega, same n_iter: fp64 LAPACK oracle vs the library (BASELINE.md parity metric)"""
     x = po.synth_pca(n, d, k, seed=seed, dtype=dtype)
     om = np.random.default_rng(seed + 1000).standard_normal((d, k + 10))
@@ -214,8 +214,9 @@ def rpca_parity(ctx, n, d, k, n_iter, seed, dtype=np.float32, tol=1e-5, device=F
         y = y.cpu().numpy()
     rel = rowwise_rel(m.components().astype(np.float64), o.components)
     assert rel.max() <= tol, f"components rel-err {rel.max():.3e} > {tol}"
-    assert np.allclose(m.singular_values(), o.singular, rtol=tol, atol=0), np.abs(m.singular_values() / o.singular - 1).max()
-    assert np.allclose(m.explained_variance_ratio(), o.explained_variance_ratio(), rtol=4 * tol, atol=0)
+    ts = tol if tol_sigma is None else tol_sigma   # (vectors of closely spaced singular values are less well determined than the values)
+    assert np.allclose(m.singular_values(), o.singular, rtol=ts, atol=0), np.abs(m.singular_values() / o.singular - 1).max()
+    assert np.allclose(m.explained_variance_ratio(), o.explained_variance_ratio(), rtol=4 * ts, atol=0)
     assert np.abs(m.mean() - o.means).max() <= 1e-6 * max(1.0, np.abs(o.means).max())
     s = np.sign(np.sum(y.astype(np.float64) * yo, axis=0))
     assert np.abs(y * s - yo).max() <= 20 * tol * np.abs(yo).max(), np.abs(y * s - yo).max() / np.abs(yo).max()
@@ -228,9 +229,9 @@ def rpca_parity(ctx, n, d, k, n_iter, seed, dtype=np.float32, tol=1e-5, device=F
     return rel.max()
 
 
-def pca_parity(ctx, n, d, k, seed, dtype=np.float64, tol=1e-9):
+def pca_parity(ctx, n, d, k, seed, dtype=np.float64, tol=1e-9, thin_oracle=False):
     x = po.synth_pca(n, d, k, seed=seed, dtype=dtype)
-    o = po.PcaOracle(k)
+    o = po.PcaOracle(k, thin=thin_oracle)
     yo = o.fit_transform(x.astype(np.float64))
     m = petal.Pca.new(k, ctx)
     y = m.fit_transform(x)

@@ -119,6 +119,21 @@ def test_ica_literal_convergence_test_at_nc2(ctx):
     pc.ica_literal_convergence_nc2(ctx)
 
 
+def test_sizes_beyond_the_one_workgroup_kernels(ctx):
+    """Shapes the crate accepts and round 1 refused (its only shape errors are src/pca.rs:199-204, 513-518): k + 10 > 200
+    (blocked Cholesky re-basing, global-memory eigen-solver), more than 1024 features (exact Pca / FastICA whitening through
+    the subspace iteration), more than 64 independent components (FastICA step on the two GEMM kernels)."""
+    # l = 266.  The planted spectrum has sigma_1 / sigma_256 = 1e3, i.e. neighbours 2.7 % apart: in fp32 the VECTORS of such close
+    # values are determined to ~1e-7 sigma_1 / gap ~ 4e-3 only (values: 1e-5); fp64 data shows the path itself is exact
+    pc.rpca_parity(ctx, 20000, 1024, 256, 5, seed=41, dtype=np.float64, tol=1e-8, device=True)
+    pc.rpca_parity(ctx, 20000, 1024, 256, 5, seed=41, tol=5e-3, tol_sigma=1e-5, device=True)
+    pc.pca_parity(ctx, 6000, 2048, 8, seed=42, dtype=np.float64, tol=1e-8, thin_oracle=True)              # d = 2048, fp64
+    pc.pca_parity(ctx, 6000, 2048, 8, seed=43, dtype=np.float32, tol=2e-5, thin_oracle=True)
+    pc.ica_parity(ctx, 20000, 2048, 8, seed=44, dtype=np.float32, n_components=8)       # whitening at d = 2048
+    pc.ica_parity(ctx, 20000, 96, 96, seed=45, dtype=np.float32, tol_src=2e-2)          # nc = min(n, d) = 96 > 64 (crate default)
+    pc.ica_par_parity(ctx, 20000, 80, seed=46, dtype=np.float64, tol=1e-7)              # the loop itself at nc = 80, fp64
+
+
 def test_edge_cases(ctx):
     pc.edge_cases(ctx)
 

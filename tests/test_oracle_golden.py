@@ -146,3 +146,15 @@ def test_oracle_fp32_vs_fp64_same_omega():
     rel = np.linalg.norm(a.components - b.components, axis=1) / np.linalg.norm(a.components, axis=1)
     assert rel.max() < 1e-5
     assert np.allclose(a.singular, b.singular, rtol=1e-5)
+
+
+def test_thin_pca_oracle_equals_the_literal_full_svd_path():
+    """PcaOracle(thin=True) (gesdd 'S', used where the crate's full n x n U would take minutes) gives the outputs of the
+    literal gesvd('A','A') path: components, singular values, ratios, fit_transform -- signs included."""
+    x = po.synth_pca(300, 40, 5, seed=9, dtype=np.float64)
+    a, b = po.PcaOracle(5), po.PcaOracle(5, thin=True)
+    ya, yb = a.fit_transform(x), b.fit_transform(x)
+    assert np.allclose(a.components, b.components, atol=1e-10)
+    assert np.allclose(a.singular, b.singular, rtol=1e-12)
+    assert np.allclose(a.explained_variance_ratio(), b.explained_variance_ratio(), rtol=1e-10)
+    assert np.allclose(ya, yb, atol=1e-9 * np.abs(ya).max())
