@@ -329,8 +329,9 @@ void op_ica_step(Dev*, int dt, const void* X1T, int64_t n, int64_t nc, int64_t l
     }
 }
 
+volatile int* dev_host_progress(Dev*) { static int p[4]; return p; }
 void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol, int* state,
-                 int iter) {
+                 int iter, int* progress) {
     if (state[0]) return;
     const double* GX = GX_gp;
     const double* gp = GX_gp + nc * nc;
@@ -348,6 +349,7 @@ void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX
     }
     for (int64_t i = 0; i < nc * nc; ++i) W[i] = W1[i];
     if (lim < tol) { state[0] = 1; state[1] = iter + 1; }  // ica.rs:355-357
+    if (progress) { progress[1] = iter + 1; if (state[0]) progress[0] = iter + 1; }
 }
 
 }  // namespace petal

@@ -369,6 +369,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     DBuf lam(c.dev, sizeof(double) * LP), sig(c.dev, sizeof(double) * LP), inv(c.dev, sizeof(double) * LP);
     DBuf V(c.dev, sizeof(double) * dp * LP), M2(c.dev, sizeof(double) * LP * LP);
     std::vector<double> sg, hflip;
+    void* Uout = nullptr;  // where the pipeline left U (n x LP)
     // The whole device pipeline.  It runs OPTIMISTICALLY first (robust = false): every power iteration re-bases with
     // the single-Cholesky fast path and no host round trip; the kernels record the worst pivot breakdown in `ndead`,
     // which is read together with the results.  Only if a breakdown happened is the fit redone with robust = true.
@@ -413,17 +414,38 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         dev_set_tag(c.dev, TAG_NONE);
     }
 
-    // thin QR of Z (pca.rs:716) as Cholesky-QR2: Z1 = Z T1, Q = Z1 T2 with T2 folded into the small side
-    op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP);
-    allreduce_f64(c, G, LP * LP, PETAL_SUM);
-    op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);
-    op_gemm_xp(c.dev, dt, Z.p, n, LP, LP, nullptr, T.f64(), LP, LP, nullptr, Z1.p, LP, nullptr);
-    op_gemm_atb(c.dev, dt, Z1.p, LP, LP, nullptr, Z1.p, LP, LP, nullptr, n, G, LP);
-    dev_set_tag(c.dev, TAG_ATB);
-    op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z1.p, LP, LP, nullptr, n, Yp, LP);  // B^T = Xc^T Q (pca.rs:681)
-    dev_set_tag(c.dev, TAG_NONE);
-    allreduce_f64(c, GY.f64(), LP * LP + dp * LP + 1, PETAL_SUM);
-    op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);  // T2
+    // thin QR of Z (pca.rs:716) and B = Q^T Xc (pca.rs:681).
+    const void* Usrc;  // the n x LP matrix U is formed from (U = Usrc . M2) ...
+    void* Ubuf;        // ... and the buffer it goes to
+    if (n_iter > 0 && !robust) {
+        // ONE more pass over X serves both.  Z = Xc Pcur, so Z^T Z = Pcur^T (Xc^T Z) = Pcur^T Yp with Yp = Xc^T Z, the very
+        // product B needs: with H = Pcur^T Yp = R^T R and T = R^-1, Q = Z T and B = Q^T Xc = (Yp T)^T.  No pass over Z, no
+        // second Gram matrix.  Why one Cholesky suffices here although cond(Z)^2 ~ 1e7 exceeds fp32: Pcur is orthonormal and
+        // spans a nearly invariant subspace of Xc^T Xc, so the fp32 rounding of Pcur and Z perturbs Z^T Z MULTIPLICATIVELY,
+        // (I + E)^T H with ||E|| ~ 1e-8, and ||Q^T Q - I|| ~ ||E|| cond(R) ~ 1e-5 instead of eps cond(Z)^2 (measured 1e-6 ..
+        // 1e-5 up to cond(Z) = 2.5e4; the singular values match the two-pass Cholesky-QR2 form to its own accuracy).  Not so
+        // for a non-orthonormal Pcur (n_iter = 0: the raw Omega) and on the robust redo: those keep Cholesky-QR2 below.
+        dev_set_tag(c.dev, TAG_ATB);
+        op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z.p, LP, LP, nullptr, n, Yp, LP);
+        dev_set_tag(c.dev, TAG_NONE);
+        allreduce_f64(c, Yp, dp * LP + 1, PETAL_SUM);  // [ Xc^T Z | sum Xc^2 ]
+        op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Pcur, LP, Yp, LP, 0.0, G, LP);
+        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);
+        Usrc = Z.p; Ubuf = Z1.p;
+    } else {
+        // Cholesky-QR2: Z1 = Z T1, Q = Z1 T2 with T2 folded into the small side
+        op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP);
+        allreduce_f64(c, G, LP * LP, PETAL_SUM);
+        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);
+        op_gemm_xp(c.dev, dt, Z.p, n, LP, LP, nullptr, T.f64(), LP, LP, nullptr, Z1.p, LP, nullptr);
+        op_gemm_atb(c.dev, dt, Z1.p, LP, LP, nullptr, Z1.p, LP, LP, nullptr, n, G, LP);
+        dev_set_tag(c.dev, TAG_ATB);
+        op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z1.p, LP, LP, nullptr, n, Yp, LP);  // B^T = Xc^T Q (pca.rs:681)
+        dev_set_tag(c.dev, TAG_NONE);
+        allreduce_f64(c, GY.f64(), LP * LP + dp * LP + 1, PETAL_SUM);
+        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);  // T2
+        Usrc = Z1.p; Ubuf = Z.p;
+    }
     op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Bt.f64(), LP);
 
     // economy SVD of B (l x d) (svddc, pca.rs:682): eigen-decomposition of B B^T in fp64
@@ -438,10 +460,11 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Bt.f64(), LP, Uh.f64(), LP, 0.0, V.f64(), LP);
     op_dscale_cols(c.dev, V.f64(), dp, LP, LP, inv.f64());
 
-    // U = Q Uh = Z1 (T2 Uh) (pca.rs:683) and svd_flip (pca.rs:684)
+    // U = Q Uh = Usrc (T Uh) (pca.rs:683) and svd_flip (pca.rs:684)
     op_dgemm(c.dev, false, false, LP, LP, LP, 1.0, T.f64(), LP, Uh.f64(), LP, 0.0, M2.f64(), LP);
-    op_gemm_xp(c.dev, dt, Z1.p, n, LP, LP, nullptr, M2.f64(), LP, LP, nullptr, Z.p, LP, nullptr);  // Z now holds U
-    sg = flip_signs(c, dt, Z.p, n, LP, LP, ri.row_offset, &hflip);
+    op_gemm_xp(c.dev, dt, Usrc, n, LP, LP, nullptr, M2.f64(), LP, LP, nullptr, Ubuf, LP, nullptr);
+    Uout = Ubuf;
+    sg = flip_signs(c, dt, Uout, n, LP, LP, ri.row_offset, &hflip);
     };  // pipeline
 
     // results (pca.rs:543-547): queued behind the pipeline together with the breakdown flag, ONE synchronisation
@@ -474,8 +497,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         for (int64_t j = 0; j < k; ++j) sc[j] = sg[j] * hs[j];
         DBuf dsc(c.dev, sizeof(double) * LP);
         dev_h2d(c.dev, dsc.p, sc.data(), dsc.bytes);
-        op_scale_cols(c.dev, dt, Z.p, n, k, LP, dsc.f64());
-        emit(c, dt, Z.p, n, k, LP, *y_out);
+        op_scale_cols(c.dev, dt, Uout, n, k, LP, dsc.f64());
+        emit(c, dt, Uout, n, k, LP, *y_out);
     }
     finish_stats(c, timer);
 }
@@ -622,24 +645,46 @@ int64_t ica_loop(petal_ctx& c, int dt, const void* X1T, int64_t n, int64_t nc, i
     op_symdecorr(c.dev, nc, W0.f64(), W.f64(), mode);  // ica.rs:329
     dev_memset(c.dev, state.p, 0, state.bytes);
     int hstate[2] = {0, 0};
-    // converged iterations turn into no-ops on the device; the flag is polled in batches of 4, 8, 16, 32, 32, ... iterations
-    // (a poll is a host round trip; a late poll costs a few no-op launches)
-    int64_t check_every = 4;
-    int64_t it = 0;
-    while (it < max_iter) {
-        const int64_t stop = std::min(max_iter, it + check_every);
-        check_every = std::min<int64_t>(32, 2 * check_every);
-        for (; it < stop; ++it) {
-            dev_set_tag(c.dev, TAG_ICA);
-            op_ica_step(c.dev, dt, X1T, n, nc, ld, W.f64(), GX.f64(), state.as<int>());  // ica.rs:332-333
-            dev_set_tag(c.dev, TAG_NONE);
-            allreduce_f64(c, GX.f64(), nc * nc + nc, PETAL_SUM);
-            op_ica_tail(c.dev, nc, n_total, W.f64(), GX.f64(), mode, tol, state.as<int>(), int(it));  // ica.rs:334-358
+    auto enqueue = [&](int64_t it, int* progress) {
+        dev_set_tag(c.dev, TAG_ICA);
+        op_ica_step(c.dev, dt, X1T, n, nc, ld, W.f64(), GX.f64(), state.as<int>());  // ica.rs:332-333
+        dev_set_tag(c.dev, TAG_NONE);
+        allreduce_f64(c, GX.f64(), nc * nc + nc, PETAL_SUM);
+        op_ica_tail(c.dev, nc, n_total, W.f64(), GX.f64(), mode, tol, state.as<int>(), int(it), progress);  // ica.rs:334-358
+    };
+    if (!sharded(c)) {
+        // Converged iterations are no-ops on the device.  The host follows the loop WITHOUT synchronising: the tail kernel
+        // stores {converged at, iterations done} to pinned host memory, the host enqueues iteration `it` once the device has
+        // finished iteration it - RUN_AHEAD (so the queue never runs dry and never runs far ahead) and stops at the flag: at
+        // most RUN_AHEAD no-op iterations are launched after convergence (the round-1 schedule synchronised after 4, 12, 28,
+        // ... iterations: two round trips and up to three wasted iterations for a fit that converges at iteration 9).
+        constexpr int64_t RUN_AHEAD = 2;
+        volatile int* hp = dev_host_progress(c.dev);
+        hp[0] = 0; hp[1] = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int64_t it = 0; it < max_iter && !hp[0]; ++it) {
+            int spins = 0;
+            while (!hp[0] && it - int64_t(hp[1]) >= RUN_AHEAD) {
+                if ((++spins & 0xFFFF) == 0 &&   // a device that stopped reporting: fall back to a blocking wait
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) { dev_sync(c.dev); break; }
+            }
+            if (hp[0]) break;
+            enqueue(it, const_cast<int*>(hp));
         }
-        dev_d2h(c.dev, hstate, state.p, sizeof(hstate));
-        dev_sync(c.dev);
-        if (hstate[0]) break;
+    } else {
+        // several ranks: every rank must enqueue the SAME number of iterations (each carries an all-reduce), so the flag --
+        // identical on all ranks after the replicated tail -- is read at fixed iteration counts, every fourth iteration
+        int64_t it = 0;
+        while (it < max_iter) {
+            const int64_t stop = std::min<int64_t>(max_iter, it + 4);
+            for (; it < stop; ++it) enqueue(it, nullptr);
+            dev_d2h(c.dev, hstate, state.p, sizeof(hstate));
+            dev_sync(c.dev);
+            if (hstate[0]) break;
+        }
     }
+    dev_d2h(c.dev, hstate, state.p, sizeof(hstate));
+    dev_sync(c.dev);
     const int64_t n_iter = hstate[0] ? hstate[1] : max_iter;
     c.stats.n_iter = n_iter;
     c.stats.ica_step_flops = 4.0 * double(nc) * nc * double(n);

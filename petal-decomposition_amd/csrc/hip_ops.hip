@@ -87,6 +87,7 @@ struct Dev {
     // per-DEVICE launch state (hipFuncSetAttribute is per device: a second ctx on another GPU of the same process needs its own)
     std::set<const void*> max_lds_set;
     int num_cu = 0;
+    int* progress = nullptr;  // pinned, device-writable: FastICA's tail kernel reports {converged at, iterations done} here
 };
 
 Dev* dev_create(int device, void* stream, char* err, size_t errlen) {
@@ -127,11 +128,19 @@ void dev_destroy(Dev* d) {
     for (auto& r : d->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : d->ev_pool) (void)hipEventDestroy(ev);
     if (d->pin) (void)hipHostFree(d->pin);
+    if (d->progress) (void)hipHostFree(d->progress);
     if (d->own_stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
 
 void* dev_stream(Dev* d) { return d->stream; }
+volatile int* dev_host_progress(Dev* d) {
+    if (!d->progress) {
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->progress), 64, hipHostMallocMapped));
+        std::memset(d->progress, 0, 64);
+    }
+    return d->progress;
+}
 void dev_make_current(Dev* d) { HIP_CHECK(hipSetDevice(d->device)); }
 int dev_push_current(Dev* d) {
     int prev = -1;
@@ -3071,7 +3080,7 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_symdecorr(const double* Wi
 template <int MB>
 __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_total, double* W, const double* GX_gp, int mode,
                                                                double tol, int* state, int iter, double* scratch,
-                                                               bf16x8* __restrict__ wpk3, double ortho_tol2) {
+                                                               bf16x8* __restrict__ wpk3, double ortho_tol2, int* progress) {
     if (state[0]) return;
     constexpr bool use_lds = MB > 0;
     extern __shared__ __attribute__((aligned(16))) double sm_tail[];
@@ -3143,6 +3152,10 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
         }
     }
     if (tid == 0 && (tl < tol)) { state[0] = 1; state[1] = iter + 1; }  // ica.rs:355-357
+    if (tid == 0 && progress) {  // host-visible progress: plain stores to pinned memory, the host polls without a sync
+        if (tl < tol) __hip_atomic_store(progress, iter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(progress + 1, iter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ void k_dscal(double* x, int64_t count, double alpha) {
@@ -3787,7 +3800,8 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
         default: { constexpr int MBv = 6; CALL; } break; \
     }
 
-void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol, int* state, int iter) {
+void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol, int* state, int iter,
+                 int* progress) {
     double* scratch = (double*)dev_alloc(d, sizeof(double) * (6 * nc * nc + nc));
     // refresh the step kernel's planes of W if the last step used them for this W
     bf16x8* wpk3 = (d->ica_wpk3 && d->ica_wpk3_for == W && d->ica_wpk3_nc == nc) ? (bf16x8*)d->ica_wpk3 : nullptr;
@@ -3796,7 +3810,7 @@ void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX
     MB_DISPATCH(mb, {
         set_max_lds(d, reinterpret_cast<const void*>(k_ica_tail<MBv>));
         hipLaunchKernelGGL(k_ica_tail<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, (int)nc, n_total, W, GX_gp, mode, tol,
-                           state, iter, scratch, wpk3, d->ica_ortho_tol2);
+                           state, iter, scratch, wpk3, d->ica_ortho_tol2, progress);
     });
     launch_check();
     if (wpk3) d->ica_wpk3_valid = true;

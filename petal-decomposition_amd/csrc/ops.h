@@ -95,8 +95,12 @@ void op_ica_step(Dev*, int dtype, const void* X1T, int64_t n, int64_t nc, int64_
                  const double* W, double* GX_gp /* nc*nc + nc contiguous */, const int* state);
 // ica.rs:334-358 on one workgroup: D = GX/n_total - gp/n_total (.) W; W1 = symdecorr(D); lim; update.
 // state = {done, n_iter}; iter is the 0-based index of this iteration.  W is replaced by W1 unless done.
+// progress (nullable): dev_host_progress()'s array; the kernel publishes {n_iter if converged else 0, iter + 1} there when it
+// finishes, so the host can follow the loop without a synchronisation.
 void op_ica_tail(Dev*, int64_t nc, double n_total, double* W, const double* GX_gp, int mode, double tol,
-                 int* state, int iter);
+                 int* state, int iter, int* progress = nullptr);
+// four ints of pinned host memory that kernels can store to (system-scope stores over PCIe); the host reads them directly
+volatile int* dev_host_progress(Dev*);
 // Wout = symmetric_decorrelation(Win) (ica.rs:363-381)
 void op_symdecorr(Dev*, int64_t nc, const double* Win, double* Wout, int mode);
 
