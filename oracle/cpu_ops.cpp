@@ -157,13 +157,18 @@ void op_logcosh_rows(Dev*, int dt, const void* X, int64_t r, int64_t c, int64_t 
 
 // ---- small f64 ops ---------------------------------------------------------------------------
 void op_dgemm(Dev*, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
-              const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+              const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const double* colscale) {
     for (int64_t i = 0; i < M; ++i)
         for (int64_t j = 0; j < N; ++j) {
             double s = 0;
             for (int64_t k = 0; k < K; ++k) s += (ta ? A[k * lda + i] : A[i * lda + k]) * (tb ? B[j * ldb + k] : B[k * ldb + j]);
-            C[i * ldc + j] = alpha * s + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
+            C[i * ldc + j] = alpha * s * (colscale ? colscale[j] : 1.0) + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
         }
+}
+void op_sigma_inv(Dev*, const double* lam, double* sig, double* inv, int64_t count, double thr) {
+    for (int64_t i = 0; i < count; ++i) sig[i] = std::sqrt(std::max(lam[i], 0.0));
+    const double s0 = count ? sig[0] : 0.0;
+    for (int64_t i = 0; i < count; ++i) inv[i] = (sig[i] > thr * s0 && sig[i] > 0) ? 1.0 / sig[i] : 0.0;
 }
 void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz) {
     if (Lz < L) Lz = L;
@@ -272,6 +277,21 @@ void op_pad_to_f64(Dev*, int dt, double* dst, int64_t rows_p, int64_t cols_p, co
 }
 void op_cvt_to_f64(Dev*, int dt, double* dst, const void* src, int64_t count) {
     for (int64_t i = 0; i < count; ++i) dst[i] = ld(src, dt, i);
+}
+
+void op_colmean(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx, double n_total, double* mu64, void* muT, bool with_sq) {
+    op_colsum(d, dt, X, n, dd, ldx, mu64, with_sq);
+    for (int64_t j = 0; j < dd; ++j) mu64[j] /= n_total;
+    op_cvt_from_f64(d, dt, muT, mu64, dd);
+}
+void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* A, int64_t M,
+                     int64_t lda, const double* T, int64_t N, int64_t ldt, double* P_out, int64_t ldpo, void* Z, int64_t ldz) {
+    std::vector<double> tmp;
+    double* P = P_out;
+    int64_t ldp = ldpo;
+    if (!P) { tmp.resize(size_t(K) * N); P = tmp.data(); ldp = N; }
+    op_dgemm(d, false, false, K, N, M, 1.0, A, lda, T, ldt, 0.0, P, ldp);
+    op_gemm_xp(d, dt, X, n, K, ldx, mu, P, N, ldp, nullptr, Z, ldz, nullptr);
 }
 
 // ---- FastICA ---------------------------------------------------------------------------------

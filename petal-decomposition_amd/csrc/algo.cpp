@@ -60,19 +60,26 @@ void replicate_from_rank0(petal_ctx& c, double* dev_buf, int64_t count) {
 // column means (pca.rs:520-528 / ica.rs:174): mu64 (device f64[dp]) and muT (device dtype[dp]); zeros if !centering
 // with_sq (centering only): mu64 has 2 dp entries, the second half holds the column sums of squares over all ranks,
 // from the same pass over X (total variance = sum_j (sq_j - n mu_j^2), formed in fp64 by the caller).
-void column_means(petal_ctx& c, const DevMat& X, double n_total, bool centering, DBuf& mu64, DBuf& muT, bool with_sq = false) {
+void column_means_into(petal_ctx& c, const DevMat& X, double n_total, bool centering, double* mu64, DBuf& muT, bool with_sq) {
     const int64_t w = (with_sq && centering) ? 2 * X.dp : X.dp;
-    mu64 = DBuf(c.dev, sizeof(double) * w);
     muT = DBuf(c.dev, dtype_size(X.dtype) * X.dp);
     if (!centering) {
-        dev_memset(c.dev, mu64.p, 0, mu64.bytes);
+        dev_memset(c.dev, mu64, 0, sizeof(double) * w);
         dev_memset(c.dev, muT.p, 0, muT.bytes);
         return;
     }
-    op_colsum(c.dev, X.dtype, X.p, X.n, X.dp, X.ld, mu64.f64(), w > X.dp);
-    allreduce_f64(c, mu64.f64(), w, PETAL_SUM);
-    op_dscal(c.dev, mu64.f64(), X.dp, 1.0 / n_total);
-    op_cvt_from_f64(c.dev, X.dtype, muT.p, mu64.f64(), X.dp);
+    if (!sharded(c)) {  // one pass + one finishing launch (sum of the block partials, 1 / n, the dtype copy)
+        op_colmean(c.dev, X.dtype, X.p, X.n, X.dp, X.ld, n_total, mu64, muT.p, w > X.dp);
+        return;
+    }
+    op_colsum(c.dev, X.dtype, X.p, X.n, X.dp, X.ld, mu64, w > X.dp);
+    allreduce_f64(c, mu64, w, PETAL_SUM);
+    op_dscal(c.dev, mu64, X.dp, 1.0 / n_total);
+    op_cvt_from_f64(c.dev, X.dtype, muT.p, mu64, X.dp);
+}
+void column_means(petal_ctx& c, const DevMat& X, double n_total, bool centering, DBuf& mu64, DBuf& muT, bool with_sq = false) {
+    mu64 = DBuf(c.dev, sizeof(double) * ((with_sq && centering) ? 2 * X.dp : X.dp));
+    column_means_into(c, X, n_total, centering, mu64.f64(), muT, with_sq);
 }
 
 // svd_flip's decision (pca.rs:826-839) for the columns of a row-sharded U: sign of the first
@@ -92,6 +99,18 @@ std::vector<double> signs_from_triple(const std::vector<double>& h, int64_t L) {
 }
 // `deferred` given (single rank, or sharded fp32): the decision data is only QUEUED for the host (no sync here); the
 // caller decodes it with signs_from_triple() after its own dev_sync, so a fit ends with one synchronisation.
+// `slot` (device, 4 L doubles): the decision data is only WRITTEN there -- [absmax | row | sign] in the first 3 L, the
+// all-reduced keys of the sharded fp32 form in the last L -- for a caller that ships it to the host with its other results
+// (flip_slot_keys() says which part to decode with signs_from_triple()).  Not for sharded fp64 (three dependent rounds).
+bool flip_slot_keys(const petal_ctx& c, int dtype) { return sharded(c) && dtype == F32; }
+void flip_signs_to_slot(petal_ctx& c, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* slot) {
+    if (L == 0) return;
+    op_col_absmax(c.dev, dtype, U, n, L, ldu, row_offset, slot, slot + L, slot + 2 * L);
+    if (flip_slot_keys(c, dtype)) {
+        op_flip_key(c.dev, slot, slot + 3 * L, L);
+        allreduce_f64(c, slot + 3 * L, L, PETAL_MAX);
+    }
+}
 std::vector<double> flip_signs(petal_ctx& c, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu,
                                int64_t row_offset, std::vector<double>* deferred = nullptr) {
     std::vector<double> h(3 * L), sg(L, 1.0);
@@ -341,12 +360,27 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     const size_t esz = dtype_size(dt);
     const double tol_drop = (dt == F32 ? 1e-6 : 1e-13);
 
-    DBuf mu64, muT;
+    // Everything the host reads back sits in ONE device buffer behind the all-reduced [Yp | tv] pair, so a fit ends with one
+    // device-to-host copy (five separate small copies cost 4 us each):
+    //   res = [ Yp (dp LP) | tv | ndead | lam (LP) | V (dp LP) | sig (LP) | mu64 (2 dp) | flip (4 LP) ]
+    const int64_t o_tv = dp * LP, o_dead = o_tv + 1, o_lam = o_dead + 1, o_V = o_lam + LP, o_sig = o_V + dp * LP, o_mu = o_sig + LP,
+                  o_flip = o_mu + 2 * dp, res_len = o_flip + 4 * LP;
+    DBuf res(c.dev, sizeof(double) * res_len);
+    double* const Yp = res.f64();
+    double* const tvp = res.f64() + o_tv;
+    int* const ndead = reinterpret_cast<int*>(res.f64() + o_dead);
+    double* const lam = res.f64() + o_lam;
+    double* const V = res.f64() + o_V;
+    double* const sig = res.f64() + o_sig;
+    double* const mu64 = res.f64() + o_mu;
+    double* const flip = res.f64() + o_flip;
+    DBuf muT;
     // fp32 input: the total variance comes from column sums of squares gathered in the means pass (exact products, fp64
     // sums: the cancellation in sum x^2 - n mu^2 costs (mu / sigma)^2 ulps of fp64, far below fp32 resolution); fp64 input
     // keeps the centred sum fused into the first product
     const bool tv_from_sq = centering && dt == F32;
-    column_means(c, X, ri.n_total, centering, mu64, muT, tv_from_sq);
+    if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
+    column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq);
 
     // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64.  The raw draw goes
     // up through the pinned ring without a host wait (it overlaps the column-means pass) and is widened on the device.
@@ -358,31 +392,25 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     }
     replicate_from_rank0(c, P.f64(), dp * LP);
     DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
-    DBuf ndead(c.dev, sizeof(int));
     c.stats.pass_flops = 2.0 * double(n) * double(d) * double(l_req);
     c.stats.pass_bytes = double(esz) * (double(n) * d + double(n) * l_req + double(d) * l_req);
 
-    DBuf GY(c.dev, sizeof(double) * (LP * LP + dp * LP + 1));  // [ Z^T Z | Xc^T Z | sum Xc^2 ]: one all-reduce
-    double* const tvp = GY.f64() + LP * LP + dp * LP;
+    DBuf Gb(c.dev, sizeof(double) * LP * LP);
+    double* const G = Gb.f64();
     DBuf T(c.dev, sizeof(double) * LP * LP), Y(c.dev, sizeof(double) * dp * LP);
     DBuf Bt(c.dev, sizeof(double) * dp * LP), S(c.dev, sizeof(double) * LP * LP), Uh(c.dev, sizeof(double) * LP * LP);
-    DBuf lam(c.dev, sizeof(double) * LP), sig(c.dev, sizeof(double) * LP), inv(c.dev, sizeof(double) * LP);
-    DBuf V(c.dev, sizeof(double) * dp * LP), M2(c.dev, sizeof(double) * LP * LP);
-    std::vector<double> sg, hflip;
+    DBuf inv(c.dev, sizeof(double) * LP), M2(c.dev, sizeof(double) * LP * LP);
     void* Uout = nullptr;  // where the pipeline left U (n x LP)
     // The whole device pipeline.  It runs OPTIMISTICALLY first (robust = false): every power iteration re-bases with
     // the single-Cholesky fast path and no host round trip; the kernels record the worst pivot breakdown in `ndead`,
     // which is read together with the results.  Only if a breakdown happened is the fit redone with robust = true.
     auto pipeline = [&](bool robust) {
-    dev_memset(c.dev, tvp, 0, sizeof(double));
-    dev_memset(c.dev, ndead.p, 0, sizeof(int));
+    dev_memset(c.dev, tvp, 0, sizeof(double) * (2 + LP));  // tv, ndead, lam (only lam[0 .. L) is written below)
     // Z = Xc . Omega (pca.rs:707); total_variance = sum Xc^2 (pca.rs:533) is fused into this product unless tv_from_sq
     dev_set_tag(c.dev, TAG_XP);
     op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv_from_sq ? nullptr : tvp);
     dev_set_tag(c.dev, TAG_NONE);
 
-    double* G = GY.f64();
-    double* Yp = GY.f64() + LP * LP;
     double* Pcur = P.f64();  // the orthonormal basis the current Z was formed with
     for (int64_t it = 0; it < n_iter; ++it) {  // pca.rs:708-715
         dev_set_tag(c.dev, TAG_ATB);
@@ -395,10 +423,13 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         // final thin QR restores orthonormality).
         if (!robust) {
             // fast path: one fp64 Cholesky of Yp^T Yp, valid while every pivot stays positive (cond(Yp) <~ 3e7: errors
-            // of a few per cent in the weakest pivots merely leave cond(P) ~ 1.x); breakdowns are recorded in ndead
+            // of a few per cent in the weakest pivots merely leave cond(P) ~ 1.x); breakdowns are recorded in ndead.
+            // Y = Yp T is formed inside the next product's operand-packing kernel (op_gemm_xp_prod), not by a launch of its own.
             op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Yp, LP, Yp, LP, 0.0, G, LP);
-            op_chol_inv(c.dev, G, L, LP, T.f64(), LP, 1e-15, ndead.as<int>(), LP);
-            op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
+            op_chol_inv(c.dev, G, L, LP, T.f64(), LP, 1e-15, ndead, LP);
+            dev_set_tag(c.dev, TAG_XP);
+            op_gemm_xp_prod(c.dev, dt, X.p, n, dp, X.ld, muT.p, Yp, LP, LP, T.f64(), LP, LP, Y.f64(), LP, Z.p, LP);  // pca.rs:714
+            dev_set_tag(c.dev, TAG_NONE);
         } else {
             // ill-conditioned iterate: precondition with the tall side first.  Z = Xc P gives Z^T Z = P^T (Xc^T Z) =
             // P^T Yp without a pass over Z (op_chol_inv reads the upper triangle only); T = chol(Z^T Z)^-1 is applied on
@@ -407,11 +438,11 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
             op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);
             op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
             orthonormalize_small(c, Y, dp, L, LP, 1e-13);
+            dev_set_tag(c.dev, TAG_XP);
+            op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Y.f64(), LP, LP, nullptr, Z.p, LP, nullptr);  // pca.rs:714
+            dev_set_tag(c.dev, TAG_NONE);
         }
         Pcur = Y.f64();
-        dev_set_tag(c.dev, TAG_XP);
-        op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Y.f64(), LP, LP, nullptr, Z.p, LP, nullptr);  // pca.rs:714
-        dev_set_tag(c.dev, TAG_NONE);
     }
 
     // thin QR of Z (pca.rs:716) and B = Q^T Xc (pca.rs:681).
@@ -442,7 +473,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         dev_set_tag(c.dev, TAG_ATB);
         op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z1.p, LP, LP, nullptr, n, Yp, LP);  // B^T = Xc^T Q (pca.rs:681)
         dev_set_tag(c.dev, TAG_NONE);
-        allreduce_f64(c, GY.f64(), LP * LP + dp * LP + 1, PETAL_SUM);
+        allreduce_f64(c, G, LP * LP, PETAL_SUM);
+        allreduce_f64(c, Yp, dp * LP + 1, PETAL_SUM);
         op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);  // T2
         Usrc = Z1.p; Ubuf = Z.p;
     }
@@ -452,36 +484,40 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Bt.f64(), LP, Bt.f64(), LP, 0.0, S.f64(), LP);
     // only the leading L x L block of S is non-zero (columns L..LP-1 of every iterate are exact zero padding)
     dev_memset(c.dev, Uh.p, 0, Uh.bytes);
-    dev_memset(c.dev, lam.p, 0, lam.bytes);
-    op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
-    op_dvec(c.dev, 0, lam.f64(), sig.f64(), LP, 0.0);
-    op_dvec(c.dev, 1, sig.f64(), inv.f64(), LP, dt == F32 ? 1e-7 : 1e-12);
+    op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15);
+    op_sigma_inv(c.dev, lam, sig, inv.f64(), LP, dt == F32 ? 1e-7 : 1e-12);
     // V[:, j] = B^T u_j / sigma_j
-    op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Bt.f64(), LP, Uh.f64(), LP, 0.0, V.f64(), LP);
-    op_dscale_cols(c.dev, V.f64(), dp, LP, LP, inv.f64());
+    op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Bt.f64(), LP, Uh.f64(), LP, 0.0, V, LP, inv.f64());
 
     // U = Q Uh = Usrc (T Uh) (pca.rs:683) and svd_flip (pca.rs:684)
     op_dgemm(c.dev, false, false, LP, LP, LP, 1.0, T.f64(), LP, Uh.f64(), LP, 0.0, M2.f64(), LP);
     op_gemm_xp(c.dev, dt, Usrc, n, LP, LP, nullptr, M2.f64(), LP, LP, nullptr, Ubuf, LP, nullptr);
     Uout = Ubuf;
-    sg = flip_signs(c, dt, Uout, n, LP, LP, ri.row_offset, &hflip);
     };  // pipeline
 
-    // results (pca.rs:543-547): queued behind the pipeline together with the breakdown flag, ONE synchronisation
-    std::vector<double> hV(size_t(dp) * LP), hs(LP), hmu(mu64.bytes / sizeof(double));
-    double htv = 0;
+    // results (pca.rs:543-547): one copy queued behind the pipeline, ONE synchronisation
+    const bool slot_flip = !sharded(c) || dt == F32;  // (sharded fp64 decides the signs in three dependent all-reduce rounds)
+    std::vector<double> hres(size_t(res_len - o_tv)), sg;
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
-        int hdead = 0;
-        dev_d2h(c.dev, &hdead, ndead.p, sizeof(int));
-        dev_d2h(c.dev, hV.data(), V.p, V.bytes);
-        dev_d2h(c.dev, hs.data(), sig.p, sig.bytes);
-        dev_d2h(c.dev, hmu.data(), mu64.p, mu64.bytes);
-        dev_d2h(c.dev, &htv, tvp, sizeof(double));
+        if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, LP, LP, ri.row_offset, flip);
+        dev_d2h(c.dev, hres.data(), tvp, sizeof(double) * hres.size());
         dev_sync(c.dev);
+        int hdead = 0;
+        std::memcpy(&hdead, &hres[o_dead - o_tv], sizeof(int));
         if (attempt == 1 || hdead == 0) break;
     }
-    if (!hflip.empty()) sg = signs_from_triple(hflip, LP);  // deferred svd_flip decision (single rank / sharded fp32)
+    if (slot_flip) {
+        const double* hf = &hres[o_flip - o_tv];
+        sg = flip_slot_keys(c, dt) ? signs_from_triple(std::vector<double>(hf + 3 * LP, hf + 4 * LP), LP)
+                                   : signs_from_triple(std::vector<double>(hf, hf + 3 * LP), LP);
+    } else {
+        sg = flip_signs(c, dt, Uout, n, LP, LP, ri.row_offset);
+    }
+    const double* hV = &hres[o_V - o_tv];
+    const double* hs = &hres[o_sig - o_tv];
+    const double* hmu = &hres[o_mu - o_tv];
+    double htv = hres[0];
     if (tv_from_sq) {  // sum (x - mu)^2 = sum x^2 - n mu^2 per column, in fp64
         htv = 0;
         for (int64_t j = 0; j < d; ++j) htv += std::max(0.0, hmu[dp + j] - ri.n_total * hmu[j] * hmu[j]);

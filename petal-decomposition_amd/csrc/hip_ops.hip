@@ -1897,7 +1897,8 @@ __global__ void k_sum_parts_state(const double* __restrict__ part, int64_t npart
 __global__ __launch_bounds__(256) void k_dgemm(bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha,
                                                const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
                                                double beta, double* __restrict__ C, int64_t ldc, int64_t kchunk,
-                                               double* __restrict__ part) {
+                                               double* __restrict__ part, const double* __restrict__ colscale,
+                                               bf16x8* __restrict__ pk3, int NTtot) {
     constexpr int BK = 32;
     __shared__ double sa[16][BK + 1], sb[BK][17];
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -1935,17 +1936,39 @@ __global__ __launch_bounds__(256) void k_dgemm(bool ta, bool tb, int64_t M, int6
     const int64_t i = i0 + ty, j = j0 + tx;
     if (i < M && j < N) {
         if (part) part[((int64_t)blockIdx.z * M + i) * N + j] = acc;
-        else C[i * ldc + j] = alpha * acc + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
+        else C[i * ldc + j] = alpha * acc * (colscale ? colscale[j] : 1.0) + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
+    }
+    if (pk3) {
+        // the product is the small operand of the next split-product GEMM (op_gemm_xp_prod): emit its three bf16 planes in
+        // k_pack_p3's layout straight from this tile -- rows i0 .. i0 + 15 are two 8-row operand groups of chunk i0 / 32,
+        // columns j0 .. j0 + 15 one column tile.  (M, N multiples of 16; beta = 0, no split-K.)
+        __syncthreads();
+        float* sv = reinterpret_cast<float*>(&sa[0][0]);  // [16][17] floats
+        sv[ty * 17 + tx] = (i < M && j < N) ? (float)(alpha * acc) : 0.f;
+        __syncthreads();
+        if ((ty & 7) == 0) {
+            f32x8 x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = sv[(ty + e) * 17 + tx];
+            bf16x8 h, m, l;
+            split3(x, h, m, l);
+            const int64_t c = i0 >> 5, tile = c * NTtot + (j0 >> 4);
+            const int lane = tx + 16 * (int)(((i0 & 31) + ty) >> 3);
+            pk3[(tile * 3 + 0) * 64 + lane] = h;
+            pk3[(tile * 3 + 1) * 64 + lane] = m;
+            pk3[(tile * 3 + 2) * 64 + lane] = l;
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_dgemm_reduce(const double* __restrict__ part, int ks, int64_t M, int64_t N, double alpha,
-                                                      double beta, double* __restrict__ C, int64_t ldc) {
+                                                      double beta, double* __restrict__ C, int64_t ldc,
+                                                      const double* __restrict__ colscale) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= M * N) return;
     double acc = 0;
     for (int z = 0; z < ks; ++z) acc += part[(int64_t)z * M * N + e];
     const int64_t i = e / N, j = e - i * N;
-    C[i * ldc + j] = alpha * acc + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
+    C[i * ldc + j] = alpha * acc * (colscale ? colscale[j] : 1.0) + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
 }
 
 // One workgroup.  The working copy of G lives in LDS as a packed upper triangle (L (L+1) / 2 doubles, 83.5 KB at
@@ -3172,6 +3195,34 @@ __global__ void k_dvec(int mode, const double* x, double* y, int64_t count, doub
     if (mode == 0) y[e] = sqrt(fmax(x[e], 0.0));
     else y[e] = (x[e] > thr * x[0] && x[e] > 0.0) ? 1.0 / x[e] : 0.0;
 }
+__global__ void k_sigma_inv(const double* __restrict__ lam, double* __restrict__ sig, double* __restrict__ inv, int64_t count, double thr) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    const double s = sqrt(fmax(lam[e], 0.0)), s0 = sqrt(fmax(lam[0], 0.0));
+    sig[e] = s;
+    inv[e] = (s > thr * s0 && s > 0.0) ? 1.0 / s : 0.0;
+}
+// column means from the per-block partial sums of k_colsum_part2, in one launch: fixed-order fp64 sum of the parts,
+// mu64[j] = sum / n_total for j < d (the sums of squares at d <= j < w stay unscaled), muT[j] = (T)mu64[j]
+template <class T>
+__global__ __launch_bounds__(256) void k_colmean_final(const double* __restrict__ part, int64_t nparts, int64_t w, int64_t d,
+                                                       double inv_n, double* __restrict__ mu64, T* __restrict__ muT) {
+    __shared__ double red[32][9];
+    const int e = threadIdx.x & 7, pl = threadIdx.x >> 3;  // 8 outputs x 32 part-lanes per block
+    const int64_t j = (int64_t)blockIdx.x * 8 + e;
+    double acc = 0;
+    if (j < w)
+        for (int64_t p = pl; p < nparts; p += 32) acc += part[p * w + j];
+    red[pl][e] = acc;
+    __syncthreads();
+    if (pl == 0 && j < w) {
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += red[k][e];
+        if (j < d) { t *= inv_n; muT[j] = (T)t; }
+        mu64[j] = t;
+    }
+}
 __global__ void k_dscale_cols(double* A, int64_t M, int64_t N, int64_t lda, const double* s) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e < M * N) A[(e / N) * lda + (e % N)] *= s[e % N];
@@ -3258,6 +3309,29 @@ void op_colsum(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx
     dev_free(d, part);
 }
 
+void op_colmean(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx, double n_total, double* mu64, void* muT, bool with_sq) {
+    if (dd == 0) return;
+    const int64_t w = with_sq ? 2 * dd : dd;
+    if (n == 0) { dev_memset(d, mu64, 0, sizeof(double) * w); dev_memset(d, muT, 0, dtype_size(dt) * dd); return; }
+    const int64_t rows = scan_rows_per_block(n), nparts = cdiv(n, rows);
+    double* part = (double*)dev_alloc(d, sizeof(double) * nparts * w);
+    const dim3 grid((unsigned)nparts, cdiv(dd, 64));
+    if (with_sq) {
+        DISPATCH_T(dt, hipLaunchKernelGGL((k_colsum_part2<T, true>), grid, dim3(256), 0, d->stream, (const T*)X, n, dd, ldx, rows, part));
+    } else {
+        DISPATCH_T(dt, hipLaunchKernelGGL((k_colsum_part2<T, false>), grid, dim3(256), 0, d->stream, (const T*)X, n, dd, ldx, rows, part));
+    }
+    launch_check();
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_colmean_final<T>, dim3(cdiv(w, 8)), dim3(256), 0, d->stream, part, nparts, w, dd, 1.0 / n_total, mu64, (T*)muT));
+    launch_check();
+    dev_free(d, part);
+}
+void op_sigma_inv(Dev* d, const double* lam, double* sig, double* inv, int64_t count, double thr) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_sigma_inv, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, lam, sig, inv, count, thr);
+    launch_check();
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // split-product (bf16x3, see k_xp3) kernels unless the ctx asks for the fp32-MFMA ones (petal_ctx_set_gemm_mode /
 // PETAL_GEMM=fp32)
@@ -3286,8 +3360,36 @@ static void launch_xp(Dev* d, const float* X, int64_t n, int K, int64_t ldx, con
     launch_check();
 }
 
+// prod_A != nullptr: the small operand is the product prod_A (K x prod_M) . P (prod_M x N) (op_gemm_xp_prod); only the
+// split-product path forms it inside its pack kernel, every other path gets it from a GEMM launch first
+static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
+                         int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo);
 void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                 int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq) {
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, P, N, ldp, bias, Z, ldz, sumsq, nullptr, 0, 0, nullptr, 0);
+}
+void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* A, int64_t M,
+                     int64_t lda, const double* T, int64_t N, int64_t ldt, double* P_out, int64_t ldpo, void* Z, int64_t ldz) {
+    const bool fused = dt == F32 && gemm_split_product(d) && n >= 64 && K % 16 == 0 && K > 0 && N % 16 == 0 && ldx % 4 == 0 &&
+                       aligned16(X) && (!mu || aligned16(mu)) && ldz % 4 == 0 && aligned16(Z) && K < (1 << 24) && N < (1 << 24);
+    if (fused) {
+        double* tmpo = P_out ? nullptr : (double*)dev_alloc(d, sizeof(double) * K * N);
+        gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, N, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out ? P_out : tmpo, P_out ? ldpo : N);
+        if (tmpo) dev_free(d, tmpo);
+        return;
+    }
+    double* tmp = nullptr;
+    double* P = P_out;
+    int64_t ldp = ldpo;
+    if (!P) { tmp = (double*)dev_alloc(d, sizeof(double) * K * N); P = tmp; ldp = N; }
+    op_dgemm(d, false, false, K, N, M, 1.0, A, lda, T, ldt, 0.0, P, ldp);
+    op_gemm_xp(d, dt, X, n, K, ldx, mu, P, N, ldp, nullptr, Z, ldz, nullptr);
+    if (tmp) dev_free(d, tmp);
+}
+static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
+                         int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo) {
     if (n == 0 || N == 0) return;
     const bool mfma = dt == F32 && K % 16 == 0 && K > 0 && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
                       K < (1 << 24) && N < (1 << 24) && N % 16 == 0 && ldz % 4 == 0 && aligned16(Z) && (!bias || aligned16(bias));
@@ -3355,7 +3457,15 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
         // split-product (bf16x3) form: grid of 64-row wave tiles, column panels of <= 5 tiles
         const int64_t nch = (K + 31) / 32, total = nch * NTtot * 64;
         bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
-        hipLaunchKernelGGL(k_pack_p3, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk3, NTtot, total);
+        if (prod_A) {
+            // P = prod_A . P: the fp64 GEMM kernel writes the product (prod_out) AND its operand planes from its epilogue
+            if (K % 32 == 16) HIP_CHECK(hipMemsetAsync(Ppk3 + (total - (int64_t)NTtot * 64) * 3, 0, sizeof(bf16x8) * NTtot * 192, d->stream));
+            hipLaunchKernelGGL(k_dgemm, dim3(cdiv(N, 16), cdiv(K, 16)), dim3(16, 16), 0, d->stream, false, false, K, N, prod_M, 1.0,
+                               prod_A, prod_lda, P, ldp, 0.0, prod_out, prod_ldo, prod_M, (double*)nullptr, (const double*)nullptr,
+                               Ppk3, NTtot);
+        } else {
+            hipLaunchKernelGGL(k_pack_p3, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk3, NTtot, total);
+        }
         launch_check();
         constexpr int RTv = PETAL_XP3_RT, DPv = PETAL_XP3_DEPTH;
         const int blocks = cdiv(n, 64 * RTv);
@@ -3874,9 +3984,9 @@ __global__ __launch_bounds__(256) void k_syrk_f64(const double* __restrict__ A, 
 }
 
 void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
-              const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+              const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const double* colscale) {
     if (M == 0 || N == 0) return;
-    if (ta && !tb && A == B && lda == ldb && M == N && M % 16 == 0 && M <= 256 && K >= 64 && alpha == 1.0 && beta == 0.0) {
+    if (!colscale && ta && !tb && A == B && lda == ldb && M == N && M % 16 == 0 && M <= 256 && K >= 64 && alpha == 1.0 && beta == 0.0) {
         const int nt = (int)(M / 16);
         hipLaunchKernelGGL(k_syrk_f64, dim3(nt * (nt + 1) / 2), dim3(256), 0, d->stream, A, lda, (int)M, K, C, ldc);
         launch_check();
@@ -3890,15 +4000,15 @@ void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double 
         ks = cdiv(K, kchunk);
         double* part = (double*)dev_alloc(d, sizeof(double) * ks * M * N);
         hipLaunchKernelGGL(k_dgemm, dim3(cdiv(N, 16), cdiv(M, 16), ks), dim3(16, 16), 0, d->stream, ta, tb, M, N, K, alpha, A, lda, B,
-                           ldb, beta, C, ldc, kchunk, part);
+                           ldb, beta, C, ldc, kchunk, part, colscale, (bf16x8*)nullptr, 0);
         launch_check();
-        hipLaunchKernelGGL(k_dgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, d->stream, part, ks, M, N, alpha, beta, C, ldc);
+        hipLaunchKernelGGL(k_dgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, d->stream, part, ks, M, N, alpha, beta, C, ldc, colscale);
         launch_check();
         dev_free(d, part);
         return;
     }
     hipLaunchKernelGGL(k_dgemm, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(16, 16), 0, d->stream, ta, tb, M, N, K, alpha, A, lda, B, ldb,
-                       beta, C, ldc, K, (double*)nullptr);
+                       beta, C, ldc, K, (double*)nullptr, colscale, (bf16x8*)nullptr, 0);
     launch_check();
 }
 __global__ void k_copy_diag(const double* __restrict__ G, int64_t ldg, int64_t L, double* __restrict__ out) {

@@ -60,12 +60,20 @@ void op_unpack_strided(Dev*, int dtype, const void* src, int64_t n, int64_t d, i
 // out[j] = sum_i X[i][j]  (fp64, deterministic order)
 // with_sq: out has 2 d entries, [column sums | column sums of squares]
 void op_colsum(Dev*, int dtype, const void* X, int64_t n, int64_t d, int64_t ldx, double* out, bool with_sq = false);
+// single-rank column means in one go: mu64[j] = (sum_i X_ij) / n_total, mu64[d + j] = sum_i X_ij^2 (with_sq), muT = the means in dtype
+void op_colmean(Dev*, int dtype, const void* X, int64_t n, int64_t d, int64_t ldx, double n_total, double* mu64, void* muT, bool with_sq);
 // Z[n x N] = (X[n x K] - mu) . P[K x N] * 1 + bias        (mu, bias nullable; mu/bias in dtype)
 // P is an f64 small matrix (ldp).  sumsq (nullable, fp64 scalar): += sum_ij (X_ij - mu_j)^2.
 // colscale (nullable, f64[N]): Z[:, j] *= colscale[j].
 void op_gemm_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
                 const double* P, int64_t N, int64_t ldp, const void* bias,
                 void* Z, int64_t ldz, double* sumsq);
+// op_gemm_xp with P = A . T formed on the fly (A: K x M, lda; T: M x N, ldt; both fp64 small matrices): the re-basing
+// product Y = Yp T of the power iteration goes straight into the GEMM kernel's operand planes instead of through a GEMM
+// launch of its own.  P_out (nullable, K x N fp64, ldpo) also receives the product.
+void op_gemm_xp_prod(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
+                     const double* A, int64_t M, int64_t lda, const double* T, int64_t N, int64_t ldt,
+                     double* P_out, int64_t ldpo, void* Z, int64_t ldz);
 // C[M x N] (f64, ldc) = (A - muA)^T . (B - muB),  A: n x M (lda), B: n x N (ldb), reduction over n rows.
 // precise: every product and the whole accumulation in fp64 (needed where the result's small eigenvalues
 // matter: exact Pca, FastICA whitening); otherwise fp32 MFMA chunks combined in fp64.
@@ -105,8 +113,13 @@ volatile int* dev_host_progress(Dev*);
 void op_symdecorr(Dev*, int64_t nc, const double* Win, double* Wout, int mode);
 
 // ---- f64 small-matrix ops ----------------------------------------------------------------------
+// colscale (nullable, N values): column j of alpha op(A) op(B) is multiplied by colscale[j] (beta must be 0)
 void op_dgemm(Dev*, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha,
-              const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+              const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+              const double* colscale = nullptr);
+// sig[i] = sqrt(max(lam[i], 0)); inv[i] = sig[i] > thr * sig[0] ? 1 / sig[i] : 0   (the two op_dvec steps of an SVD from
+// eigenvalues, in one launch)
+void op_sigma_inv(Dev*, const double* lam, double* sig, double* inv, int64_t count, double thr);
 // G (L x L, SPD up to rounding) = R^T R;  T = R^{-1} (upper triangular, L x L, ldt).
 // A pivot with r_jj^2 <= rel_tol * G_jj (or G_jj <= 0) marks column j as dependent: T[:, j] = 0.
 // Only the upper triangle of G is read.  ndead (nullable, device int): *ndead = max(*ndead, number of dependent columns).
