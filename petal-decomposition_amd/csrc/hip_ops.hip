@@ -45,6 +45,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ int g_dbg[4];
 __device__ long long g_cyc[16];
 #define DBG_T(i) do { if (threadIdx.x == 0) { long long _t = clock64(); g_cyc[i] += _t - _t0; _t0 = _t; } } while (0)
+}  // namespace petal
+// development builds only (-DPETAL_DEBUG_COUNTERS): read and clear the in-kernel phase counters
+extern "C" void petal_debug_counters(long long* cyc16, int* dbg4) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(cyc16, HIP_SYMBOL(petal::g_cyc), sizeof(long long) * 16);
+    (void)hipMemcpyFromSymbol(dbg4, HIP_SYMBOL(petal::g_dbg), sizeof(int) * 4);
+    long long z[16] = {0}; int zi[4] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(petal::g_cyc), z, sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(petal::g_dbg), zi, sizeof(zi));
+}
+namespace petal {
 #else
 #define DBG_T(i) do {} while (0)
 #endif
@@ -2758,9 +2769,10 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
                 itme.get(tid, Le, L, p, q);
                 double c = 1.0, sn = 0.0;
                 if (p != q) {
-                    const double apq = A[p * LD + q];
+                    // (all three operands requested at once: a dependent second LDS round trip costs ~100 cycles of the
+                    // angle chain, which is the longest leg of a round)
+                    const double apq = A[p * LD + q], app = A[p * LD + p], aqq = A[q * LD + q];
                     if (apq != 0.0) {
-                        const double app = A[p * LD + p], aqq = A[q * LD + q];
                         double t;
                         jacobi_angle(app, aqq, apq, c, sn, t);
                         A[p * LD + p] = app - t * apq;
