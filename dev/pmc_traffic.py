@@ -1,7 +1,7 @@
-"""Builds profiles/r01_pmc_traffic.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over dev/pmc_kernels.py
+"""Builds profiles/r<NN>_pmc_traffic.json (usage: python dev/pmc_traffic.py r02) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over dev/pmc_kernels.py
 (directories gpurun_out/pmc_tr_<mode>_<rows>_<counter>), see the "_how" entry.
 usage: python dev/pmc_traffic.py"""
-import csv, glob, json, os, collections
+import csv, glob, json, os, collections, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d, l = 512, 74
 KIND = {"k_xp3": "K1", "k_xp_pers": "K1", "k_xp_mfma": "K1", "k_atb3": "K2", "k_atb_mfma": "K2"}
@@ -31,5 +31,10 @@ for mode in ("bf16x3", "fp32"):
                              "hbm_bytes_corrected": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
                              "algorithmic_bytes": 4 * (n * d + n * l + d * l)}
         out.setdefault(f"{n}x{d} l={l}", {})[mode] = ent
-json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), "w"), indent=1)
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+try:
+    out["measured_at"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    out["measured_at"] = "unknown"
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])

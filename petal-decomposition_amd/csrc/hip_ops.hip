@@ -2218,8 +2218,18 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
             const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
             for (int Ct = J + (tid >> 6); Ct < nb; Ct += nt >> 6) {
                 cf64x4 acc = cf64x4{0.0, 0.0, 0.0, 0.0};
-                for (int k0 = 0; k0 < jb; k0 += 4)  // rows k0 + lk of R: (R_KJ^T)[i][k] = R[k][jb + i]
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ld_up(Rc, k0 + lk, jb + li, L), ld_up(Rc, k0 + lk, 16 * Ct + li, L), acc, 0, 0, 0);
+                // (jb is a multiple of 16: the operands of a whole 16-row block are requested before its four MFMAs, so the
+                // LDS latency is paid once per block instead of once per k-step)
+                for (int k0 = 0; k0 < jb; k0 += 16) {
+                    double pa[4], pb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {  // rows k0 + 4 u + lk of R: (R_KJ^T)[i][k] = R[k][jb + i]
+                        pa[u] = ld_up(Rc, k0 + 4 * u + lk, jb + li, L);
+                        pb[u] = ld_up(Rc, k0 + 4 * u + lk, 16 * Ct + li, L);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[u], pb[u], acc, 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rr = jb + lk + 4 * r, cc = 16 * Ct + li;
@@ -2317,10 +2327,16 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
             while (bI >= nb - dl) { bI -= nb - dl; ++dl; }
             const int bK = bI + dl;
             cf64x4 acc = cf64x4{0.0, 0.0, 0.0, 0.0};
+            {
+                double pa[4], pb[4];
 #pragma unroll
-            for (int k0 = 0; k0 < 16; k0 += 4)  // A = T_II (upper triangular), B = R_IK
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ld_up(Tc, 16 * bI + li, 16 * bI + k0 + lk, L),
-                                                           ld_up(Rc, 16 * bI + k0 + lk, 16 * bK + li, L), acc, 0, 0, 0);
+                for (int u = 0; u < 4; ++u) {  // A = T_II (upper triangular), B = R_IK
+                    pa[u] = ld_up(Tc, 16 * bI + li, 16 * bI + 4 * u + lk, L);
+                    pb[u] = ld_up(Rc, 16 * bI + 4 * u + lk, 16 * bK + li, L);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[u], pb[u], acc, 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = 16 * bI + lk + 4 * r, cc = 16 * bK + li;
@@ -2333,11 +2349,16 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
             for (int bI = wv; bI < nb - dl; bI += nw) {
                 const int bJ = bI + dl;
                 cf64x4 acc = cf64x4{0.0, 0.0, 0.0, 0.0};
-                for (int bK = bI + 1; bK <= bJ; ++bK)
+                for (int bK = bI + 1; bK <= bJ; ++bK) {
+                    double pa[4], pb[4];
 #pragma unroll
-                    for (int k0 = 0; k0 < 16; k0 += 4)  // A = R~_IK, B = T_KJ (upper triangular when K == J)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ld_up(Rc, 16 * bI + li, 16 * bK + k0 + lk, L),
-                                                                   ld_up(Tc, 16 * bK + k0 + lk, 16 * bJ + li, L), acc, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) {  // A = R~_IK, B = T_KJ (upper triangular when K == J)
+                        pa[u] = ld_up(Rc, 16 * bI + li, 16 * bK + 4 * u + lk, L);
+                        pb[u] = ld_up(Tc, 16 * bK + 4 * u + lk, 16 * bJ + li, L);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[u], pb[u], acc, 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rr = 16 * bI + lk + 4 * r, cc = 16 * bJ + li;
