@@ -1183,16 +1183,20 @@ __global__ __launch_bounds__(256, 2) void k_atb_mfma(const float* __restrict__ A
 // four waves: the workgroup converts it once -- thread <-> one operand item (tile u, lane (j, q): B[r0 + 8 q + e][16 u + j],
 // e < 8), split into three bf16 planes -- into a double-buffered LDS image in MFMA operand order, one barrier per stage.
 // n must be a multiple of 32 here: the host gives the ragged remainder to the fp32 kernel as one more slab.
-template <int NT, bool CA>
-__global__ __launch_bounds__(256, 2) void k_atb3(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
-                                                 const float* __restrict__ B, int64_t ldb, int N, int n0col, int64_t n,
-                                                 int64_t chunk, float* __restrict__ part, int Npart) {
+// WV = waves per workgroup (4 or 8).  Every wave owns its own 64 columns of A but all of them share the workgroup's
+// 32-row stage of B, which is read from memory and converted ONCE per workgroup: with 4-wave workgroups a 512-column A
+// makes two workgroups per row chunk read and convert the same stage (K2's PMC traffic was 1.16-1.23x algorithmic, most
+// of it this); 8-wave workgroups cover 512 columns with one.
+template <int NT, bool CA, int WV>
+__global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
+                                                     const float* __restrict__ B, int64_t ldb, int N, int n0col, int64_t n,
+                                                     int64_t chunk, float* __restrict__ part, int Npart) {
     constexpr int BITEMS = NT * 64;                       // operand items of one B stage (8 elements each)
-    constexpr bool Z2 = BITEMS > 256;                     // wave 0 carries a second item when NT = 5
+    constexpr bool Z2 = BITEMS > 64 * WV;                 // wave 0 carries a second item when NT = 5 and there are 4 waves
     __shared__ bf16x8 sB[2][NT * 192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int m0 = (blockIdx.x * 4 + wave) * 64;
+    const int m0 = (blockIdx.x * WV + wave) * 64;
     const int64_t rbeg = (int64_t)blockIdx.y * chunk, rend = min(n, rbeg + chunk);
     const int nstage = (int)((rend - rbeg) >> 5);
     // uniform row bases (advance 32 rows per stage) + ONE 32-bit per-lane offset each: no per-load address arithmetic
@@ -3724,11 +3728,15 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         const float* Af = (const float*)A; const float* Bf = (const float*)B;
         const float* ma = (const float*)muA; const float* mb = (const float*)muB;
         if (split3_mode) {
-            const dim3 grid(cdiv(M, 256), (unsigned)nsplit), block(256);
+            // 8-wave workgroups (one B stage per 512 columns of A) where the row split already puts two waves on every SIMD
+            const bool wv8 = M >= 512 && nsplit * mslices >= (int64_t)num_cu2 * 8;
+            const dim3 grid(cdiv(M, wv8 ? 512 : 256), (unsigned)nsplit), block(wv8 ? 512 : 256);
 #define ATB3_LAUNCH(NTv)                                                                                                              \
             do {                                                                                                                      \
-                if (ma) hipLaunchKernelGGL((k_atb3<NTv, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
-                else hipLaunchKernelGGL((k_atb3<NTv, false>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+                if (ma && wv8) hipLaunchKernelGGL((k_atb3<NTv, true, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+                else if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, 4>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+                else if (wv8) hipLaunchKernelGGL((k_atb3<NTv, false, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+                else hipLaunchKernelGGL((k_atb3<NTv, false, 4>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
             } while (0)
             switch (w) {
                 case 5: ATB3_LAUNCH(5); break;
