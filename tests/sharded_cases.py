@@ -70,6 +70,39 @@ def run_ica(explicit):
     return run
 
 
+# ---- the per-rank workloads of BASELINE configs[3] / configs[4], split over the ranks of the test ------------------------
+CFG4 = dict(n=250000, d=1024, k=128, n_iter=7)    # one of the eight ranks' rows of configs[3]
+CFG5 = dict(n=500000, d=512, nc=64)               # one of the eight ranks' rows of configs[4]
+
+
+def x_cfg4():
+    return synth_pca(CFG4["n"], CFG4["d"], CFG4["k"], seed=4, dtype=np.float32)
+
+
+def omega_cfg4():
+    return np.random.default_rng(3).standard_normal((CFG4["d"], CFG4["k"] + 10)).astype(np.float32)
+
+
+def run_cfg4(petal, ctx, xs, rank):
+    m = petal.RandomizedPca(CFG4["k"], ctx=ctx, n_iter=CFG4["n_iter"])
+    m.fit(xs, omega=omega_cfg4())
+    return {"components": m.components(), "singular": m.singular_values(), "evr": m.explained_variance_ratio(), "mean": m.mean()}
+
+
+def x_cfg5():
+    return synth_ica(CFG5["n"], CFG5["d"], CFG5["nc"], seed=8, dtype=np.float32)
+
+
+def w0_cfg5():
+    return np.random.default_rng(7).standard_normal((CFG5["nc"], CFG5["nc"])).astype(np.float32)
+
+
+def run_cfg5(petal, ctx, xs, rank):
+    ica = petal.FastIca(ctx=ctx, n_components=CFG5["nc"])
+    ica.fit(xs, w_init=w0_cfg5())
+    return {"components": ica.components, "mean": ica.means, "n_iter": np.array([ica.n_iter])}
+
+
 CASES = {
     "rpca32": {"x": x_rpca32, "run": run_rpca(np.float32, True), "both_modes": True},
     "rpca32_own_omega": {"x": x_rpca32, "run": run_rpca(np.float32, False)},
@@ -78,4 +111,6 @@ CASES = {
     "pca32": {"x": lambda: x_pca().astype(np.float32), "run": run_pca},
     "ica32": {"x": x_ica, "run": run_ica(True), "both_modes": True},
     "ica32_own_w": {"x": x_ica, "run": run_ica(False)},
+    "cfg4_share": {"x": x_cfg4, "run": run_cfg4},
+    "cfg5_share": {"x": x_cfg5, "run": run_cfg5},
 }
