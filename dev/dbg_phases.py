@@ -10,7 +10,7 @@ from synth_data import synth_pca
 x = torch.from_numpy(synth_pca(n, d, k, seed=2)).cuda()
 om = np.random.default_rng(3).standard_normal((d, k + 10)).astype(np.float32)
 m = petal.RandomizedPca(k, ctx=ctx, n_iter=5)
-cyc = (C.c_longlong * 16)(); dbg = (C.c_int * 4)()
+cyc = (C.c_longlong * 32)(); dbg = (C.c_int * 4)()
 for rep in range(3):
     m.fit(x, omega=om)
     lib.petal_debug_counters(cyc, dbg)

@@ -28,12 +28,12 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%-28s L=%d  %.2f us\n", name, L, ms * 100.0);
     };
-    timeit("eigh(copy+jacobi)", [&] { dev_d2d(d, dA, dS, 8 * L * L); op_eigh(d, dA, L, L, dV, L, dw); });
+    timeit("eigh(copy+jacobi)", [&] { dev_d2d(d, dA, dS, 8 * L * L); op_eigh(d, dA, L, L, dV, L, dw, 1e-8); });
     timeit("chol_inv", [&] { op_chol_inv(d, dS, L, L, dT, L, 1e-13); });
     timeit("dgemm 512xLxL", [&] { op_dgemm(d, false, false, 512, L, L, 1.0, dS, L, dT, L, 0.0, dA, L); });
     timeit("symdecorr", [&] { if (L <= 1024) op_symdecorr(d, L, dS, dA, 0); });
     std::vector<double> w(L), V(L * L), T(L * L);
-    dev_d2d(d, dA, dS, 8 * L * L); op_eigh(d, dA, L, L, dV, L, dw);
+    dev_d2d(d, dA, dS, 8 * L * L); op_eigh(d, dA, L, L, dV, L, dw, 1e-8);
     dev_d2h(d, w.data(), dw, 8 * L); dev_d2h(d, V.data(), dV, 8 * L * L); dev_sync(d);
     double maxres = 0;
     for (int j = 0; j < L; ++j) for (int i = 0; i < L; ++i) { double s = 0; for (int k = 0; k < L; ++k) s += S[i * L + k] * V[k * L + j]; maxres = fmax(maxres, fabs(s - w[j] * V[i * L + j])); }

@@ -43,15 +43,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifdef PETAL_DEBUG_COUNTERS
 __device__ int g_dbg[4];
-__device__ long long g_cyc[16];
+__device__ long long g_cyc[32];
 #define DBG_T(i) do { if (threadIdx.x == 0) { long long _t = clock64(); g_cyc[i] += _t - _t0; _t0 = _t; } } while (0)
 }  // namespace petal
 // development builds only (-DPETAL_DEBUG_COUNTERS): read and clear the in-kernel phase counters
-extern "C" void petal_debug_counters(long long* cyc16, int* dbg4) {
+extern "C" void petal_debug_counters(long long* cyc16, int* dbg4) {  // (32 counters)
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(cyc16, HIP_SYMBOL(petal::g_cyc), sizeof(long long) * 16);
+    (void)hipMemcpyFromSymbol(cyc16, HIP_SYMBOL(petal::g_cyc), sizeof(long long) * 32);
     (void)hipMemcpyFromSymbol(dbg4, HIP_SYMBOL(petal::g_dbg), sizeof(int) * 4);
-    long long z[16] = {0}; int zi[4] = {0};
+    long long z[32] = {0}; int zi[4] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(petal::g_cyc), z, sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(petal::g_dbg), zi, sizeof(zi));
 }
@@ -2652,7 +2652,8 @@ __device__ __forceinline__ JacWs jac_carve(double* base, int L, int nthreads) {
 // MB > 0: A and the eigenvector accumulator live in LDS (2 L^2 doubles; L <= 16 MB, L <= 88); MB == 0: global memory
 template <int MB>
 __global__ __launch_bounds__(MB > 0 ? 768 : 1024) void k_eigh(double* A, int L, int64_t lda, double* Vtmp, double* V, int64_t ldv, double* w,
-                                                                  double tol_rel) {
+                                                                  double tol_rel, const int* flag) {
+    if (flag && *flag == 0) return;
     extern __shared__ __attribute__((aligned(16))) double sm_eig[];
     const int tid = threadIdx.x, nt = blockDim.x;
     JacWs ws = jac_carve(sm_eig, L, nt);
@@ -2747,7 +2748,8 @@ __device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq,
 template <int MB2, int GW>  // GW-wide batches of partner pairs per lane: half - 1 <= GW MB2
 __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ain, int L, int64_t lda, jf64x2* __restrict__ log_cs,
                                                    int* __restrict__ nrounds_out, double* __restrict__ w,
-                                                   int* __restrict__ rank_out, int PW, double tol_rel) {
+                                                   int* __restrict__ rank_out, int PW, double tol_rel, const int* __restrict__ flag) {
+    if (flag && *flag == 0) return;  // the two-stage solver in front of this launch has already delivered (k_trieig_verdict)
     extern __shared__ __attribute__((aligned(16))) double sm_ja[];
     const int LD = L | 1;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
@@ -2869,12 +2871,712 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
         w[rank] = wj;
     }
 }
+
+// ================================================================================================
+// two-stage symmetric eigen-solver: Householder tridiagonalisation, then per eigenpair (one wave each, spread over the
+// chip) multisection on the Sturm count, the eigenvector from the twisted factorisation, and the back-transformation.
+// ================================================================================================
+// The Jacobi solvers above spend ~1 us per round on a chain of on-chip latencies, (L - 1) rounds per sweep, 4-5 sweeps:
+// 0.36 ms at L = 74, 1.8 ms at L = 138, all on ONE workgroup.  Here the only serial part is the reduction to tridiagonal
+// form T = Q^T A Q (L - 2 Householder steps on one workgroup); everything after it is independent per eigenpair:
+//   lambda_j   64-way multisection of the Sturm count of T (6 bits per pass, 10 passes to fp64 resolution),
+//   z_j        twisted factorisation (Parlett-Dhillon): the two Sturm recurrences from the top and from the bottom meet at
+//              the index of smallest |gamma|; one sweep each way gives the eigenvector of T without iteration,
+//   v_j        = H_0 ... H_{L-3} z_j, the reflectors applied to that one column.
+// Accuracy is that of a backward-stable dense method, eps ||A|| absolute in the eigenvalues.  Eigenvectors of eigenvalues
+// closer than 1e-10 ||A|| (rank deficiency, exact multiplicities) are not guaranteed orthogonal by this route: k_trieig
+// leaves the verdict in `flag` and the Jacobi solver, launched behind it, runs only then (it returns at once otherwise).
+constexpr int TRI_THREADS = 512;
+template <bool INLDS>
+__global__ __launch_bounds__(TRI_THREADS) void k_tridiag(const double* __restrict__ A, int L, int64_t lda, double* __restrict__ Wg,
+                                                         double* __restrict__ dd, double* __restrict__ ee, double* __restrict__ HV,
+                                                         double* __restrict__ tau) {
+    extern __shared__ __attribute__((aligned(16))) double sm_tri[];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    const int ld = L | 1;
+    double* W = INLDS ? sm_tri : Wg;                          // working copy of A (full symmetric), leading dimension ld
+    double* sv = INLDS ? sm_tri + (size_t)L * ld : sm_tri;    // Householder vector of the step
+    double* sp = sv + L;                                      // p = tau A22 v
+    double* s_red = sp + L;                                   // 2 x 16 partial sums
+    for (int e = tid; e < L * L; e += nt) {
+        const int r = e / L, c = e - r * L;
+        W[(size_t)r * ld + c] = A[(int64_t)r * lda + c];
+    }
+    for (int e = tid; e < L * L; e += nt) HV[e] = 0.0;
+    __syncthreads();
+    auto block_sum2 = [&](double a, double b, double& ta, double& tb) {  // two sums at once, to every thread
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+        if (lane == 0) { s_red[wv] = a; s_red[16 + wv] = b; }
+        __syncthreads();
+        ta = 0; tb = 0;
+        for (int x = 0; x < nw; ++x) { ta += s_red[x]; tb += s_red[16 + x]; }
+        __syncthreads();
+    };
+    for (int k = 0; k + 2 < L; ++k) {
+        const int m = L - k - 1;                               // order of the trailing block, rows / columns k + 1 ..
+        const double* colk = W + (size_t)(k + 1) * ld + k;     // x_i = W[k + 1 + i][k]
+        double xi = 0, sq = 0;
+        if (tid < m) { xi = colk[(size_t)tid * ld]; sq = tid > 0 ? xi * xi : 0.0; }
+        double sigma, dummy;
+        block_sum2(sq, 0.0, sigma, dummy);
+        const double alpha = colk[0];
+        double beta = alpha, tk = 0.0, scale = 0.0;
+        if (sigma > 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
+            tk = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        if (tid < m) {
+            const double vi = tid == 0 ? 1.0 : xi * scale;
+            sv[tid] = vi;
+            HV[(size_t)k * L + k + 1 + tid] = vi;              // reflector k: row k of HV, entries k + 1 .. L - 1
+        }
+        if (tid == 0) { dd[k] = W[(size_t)k * ld + k]; ee[k] = beta; tau[k] = tk; }
+        __syncthreads();
+        if (tk != 0.0) {                                        // (uniform)
+            // p = tau A22 v, eight lanes per row; and p^T v
+            double pv = 0;
+            for (int i = tid >> 3; i < m; i += nt >> 3) {
+                const double* row = W + (size_t)(k + 1 + i) * ld + k + 1;
+                double acc = 0;
+                for (int j = tid & 7; j < m; j += 8) acc += row[j] * sv[j];
+                acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+                if ((tid & 7) == 0) { const double pi = tk * acc; sp[i] = pi; pv += pi * sv[i]; }
+            }
+            double tpv;
+            block_sum2(pv, 0.0, tpv, dummy);                    // (its barriers also publish sp)
+            const double K = -0.5 * tk * tpv;
+            // A22 -= v w^T + w v^T with w = p + K v
+            for (int e = tid; e < m * m; e += nt) {
+                const int i = e / m, j = e - i * m;
+                const double vi = sv[i], vj = sv[j];
+                const double wi = sp[i] + K * vi, wj = sp[j] + K * vj;
+                W[(size_t)(k + 1 + i) * ld + k + 1 + j] -= vi * wj + wi * vj;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        if (L >= 2) {
+            dd[L - 2] = W[(size_t)(L - 2) * ld + L - 2];
+            ee[L - 2] = W[(size_t)(L - 1) * ld + L - 2];
+            tau[L - 2] = 0.0;
+        }
+        dd[L - 1] = W[(size_t)(L - 1) * ld + L - 1];
+        ee[L - 1] = 0.0;
+        tau[L - 1] = 0.0;
+    }
+}
+
+// one wave per eigenpair j (descending): lambda_j, z_j, v_j.  d, e in LDS; q+ / q- / z per wave in LDS.
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_trieig(const double* __restrict__ dd, const double* __restrict__ ee,
+                                                     const double* __restrict__ HV, const double* __restrict__ tau, int L,
+                                                     double* __restrict__ w, double* __restrict__ V, int64_t ldv) {
+    extern __shared__ __attribute__((aligned(16))) double sm_te[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double* sd = sm_te;                 // d
+    double* se = sd + L;                // e (sub-diagonal), e[L - 1] = 0
+    double* s2 = se + L;                // e^2
+    double* qp = s2 + L + (size_t)wv * 3 * L;   // per wave: q+, q-, z
+    double* qm = qp + L;
+    double* z = qm + L;
+    for (int i = tid; i < L; i += 64 * WPB) { const double ev = ee[i]; sd[i] = dd[i]; se[i] = ev; s2[i] = ev * ev; }
+    __syncthreads();
+    const int j = blockIdx.x * WPB + wv;                         // descending index
+    if (j >= L) return;
+    // Gershgorin interval and the scale of T
+    double glo = 1e300, ghi = -1e300;
+    for (int i = lane; i < L; i += 64) {
+        const double r = (i > 0 ? fabs(se[i - 1]) : 0.0) + (i + 1 < L ? fabs(se[i]) : 0.0);
+        glo = fmin(glo, sd[i] - r); ghi = fmax(ghi, sd[i] + r);
+    }
+    for (int off = 32; off > 0; off >>= 1) { glo = fmin(glo, __shfl_xor(glo, off, 64)); ghi = fmax(ghi, __shfl_xor(ghi, off, 64)); }
+    const double tnorm = fmax(fabs(glo), fabs(ghi));
+    const double tiny = fmax(tnorm, 1e-300) * 1e-30;            // stands for an exact zero pivot in the recurrences
+    const int kth = L - 1 - j;                                    // 0-based ascending index of the wanted eigenvalue
+    auto sturm = [&](double x) {                                  // number of eigenvalues of T below x
+        double q = sd[0] - x;
+        if (fabs(q) < tiny) q = -tiny;
+        int cnt = q < 0.0 ? 1 : 0;
+        for (int i = 1; i < L; ++i) {
+            q = sd[i] - x - s2[i - 1] / q;
+            if (fabs(q) < tiny) q = -tiny;
+            cnt += q < 0.0 ? 1 : 0;
+        }
+        return cnt;
+    };
+    double lo = glo - 1e-12 * tnorm - tiny, hi = ghi + 1e-12 * tnorm + tiny;
+    if (!(tnorm < 1e300)) { lo = 0; hi = 0; }                     // non-finite input: leave a NaN-free nonsense, the flag catches it
+    for (int pass = 0; pass < 11; ++pass) {                       // 65-way split per pass
+        const double h = (hi - lo) * (1.0 / 65.0);
+        const double x = lo + h * (lane + 1);
+        const int c = sturm(x);
+        const unsigned long long mask = __ballot(c > kth);        // lanes whose point has more than kth eigenvalues below it
+        if (mask) {
+            const int first = __ffsll((long long)mask) - 1;
+            const double nhi = lo + h * (first + 1), nlo = lo + h * first;
+            hi = nhi; lo = nlo;
+        } else {
+            lo = lo + h * 64;
+        }
+    }
+    const double lam = 0.5 * (lo + hi);
+    if (lane == 0) w[j] = lam;
+    // eigenvector of T: twisted factorisation at the index of smallest |gamma| (two independent recurrences: one lane each)
+    if (lane == 0) {
+        double q = sd[0] - lam;
+        if (fabs(q) < tiny) q = tiny;
+        qp[0] = q;
+        for (int i = 1; i < L; ++i) { q = sd[i] - lam - s2[i - 1] / q; if (fabs(q) < tiny) q = tiny; qp[i] = q; }
+    } else if (lane == 1) {
+        double q = sd[L - 1] - lam;
+        if (fabs(q) < tiny) q = tiny;
+        qm[L - 1] = q;
+        for (int i = L - 2; i >= 0; --i) { q = sd[i] - lam - s2[i] / q; if (fabs(q) < tiny) q = tiny; qm[i] = q; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double gbest = 1e300;
+    int rbest = 0;
+    for (int i = lane; i < L; i += 64) {
+        const double g = fabs(qp[i] + qm[i] - (sd[i] - lam));
+        if (g < gbest) { gbest = g; rbest = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double og = __shfl_xor(gbest, off, 64);
+        const int orr = __shfl_xor(rbest, off, 64);
+        if (og < gbest || (og == gbest && orr < rbest)) { gbest = og; rbest = orr; }
+    }
+    if (lane == 0) {
+        z[rbest] = 1.0;
+        double zi = 1.0;
+        for (int i = rbest - 1; i >= 0; --i) { zi = -se[i] * zi / qp[i]; z[i] = zi; }
+    } else if (lane == 1) {
+        double zi = 1.0;
+        for (int i = rbest + 1; i < L; ++i) { zi = -se[i - 1] * zi / qm[i]; z[i] = zi; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // normalise (scaled against overflow), then v = H_0 ... H_{L-3} z: reflector k acts on entries k + 1 ..
+    double zmax = 0;
+    for (int i = lane; i < L; i += 64) zmax = fmax(zmax, fabs(z[i]));
+    for (int off = 32; off > 0; off >>= 1) zmax = fmax(zmax, __shfl_xor(zmax, off, 64));
+    const double zs = zmax > 0.0 && zmax < 1e300 ? 1.0 / zmax : 1.0;
+    double nrm = 0;
+    for (int i = lane; i < L; i += 64) { const double v = z[i] * zs; z[i] = v; nrm += v * v; }
+    for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off, 64);
+    const double rn = nrm > 0.0 ? 1.0 / sqrt(nrm) : 0.0;
+    for (int i = lane; i < L; i += 64) z[i] *= rn;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int k = L - 3; k >= 0; --k) {
+        const double tk = tau[k];
+        if (tk == 0.0) continue;
+        const double* hv = HV + (size_t)k * L;
+        double dot = 0;
+        for (int i = k + 1 + lane; i < L; i += 64) dot += hv[i] * z[i];
+        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+        const double f = tk * dot;
+        for (int i = k + 1 + lane; i < L; i += 64) z[i] -= f * hv[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    for (int i = lane; i < L; i += 64) V[(int64_t)i * ldv + j] = z[i];
+}
+// verdict of the two-stage route, read by the Jacobi kernels launched behind it: flag = 1 (run Jacobi) when some eigenvalue
+// is not finite or two neighbours are closer than 1e-10 of the largest magnitude (their vectors need not be orthogonal)
+__global__ void k_trieig_verdict(const double* __restrict__ w, int L, double gap_tol, int* __restrict__ flag) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    const double scale = fmax(fabs(w[0]), fabs(w[L - 1]));
+    for (int j = threadIdx.x; j < L; j += blockDim.x) {
+        const double a = w[j];
+        bool b = !(fabs(a) < 1e300);
+        if (j + 1 < L) b = b || !(a - w[j + 1] > gap_tol * scale);
+        if (b) bad = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = (bad || !(scale > 0.0)) ? 1 : 0;
+}
+
+// ---- register-resident variants for L <= 141 (the l = k + 10 of the randomized fits, the nc x nc problems of FastICA) ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, the same bits in every lane: four DPP butterfly steps inside each row of 16 lanes, then the four
+// row sums through v_readlane
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+__device__ __forceinline__ double rcp_nr(double x) {     // 1 / x to fp64 rounding error: v_rcp_f64 and two Newton steps
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double rsqrt_nr(double x) {   // 1 / sqrt(x) for normal x > 0
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+__device__ __forceinline__ double oct_sum_f64(double v) {  // sum over each group of 8 consecutive lanes
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    return v;
+}
+
+// Householder tridiagonalisation with two barriers per step and no global-memory traffic inside the loop.  The kernel is
+// bound by instruction issue and by fp64 latency on ONE compute unit, so it runs one wave per SIMD and keeps the per-wave
+// instruction count down.  Thread (g, sub) = (tid / 8, tid % 8): the eight lanes of a group share a row, lane sub owns the
+// columns j = sub (mod 8) of the trailing block and keeps v_j (and later w_j) of ITS columns in registers, read from row k
+// of the symmetric working copy -- every group computes sigma, beta, tau and p^T v redundantly (bit-identically) from
+// those, so nothing but p has to cross a barrier before the rank-2 update.  The step is a template on the number T of
+// column slots per lane (trailing order m <= 8 T) and the kernel walks down a ladder of T as the block shrinks; the working
+// copy carries PAD zero columns on the right, at least the ladder's overshoot 8 T - m, so no column needs a bound check
+// (v and w are exactly zero there and the update leaves the zeros alone).  Reflector k is parked in column k of the working
+// copy (dead by then), beta and tau in row k; one pass at the end writes d, e, tau and the reflector rows out.
+constexpr int TRR_THREADS = 256;
+template <int T>
+__device__ __forceinline__ void tri_step(double* __restrict__ W, int ld, int L, int k, double* __restrict__ sv,
+                                         double* __restrict__ sp, long long& _t0) {
+    constexpr int NG = TRR_THREADS / 8;                          // row groups
+    constexpr int RB = (8 * T + NG - 1) / NG;                    // rows per group: the whole trailing block in one unrolled pass
+    const int tid = threadIdx.x, g = tid >> 3, sub = tid & 7;
+    const int m = L - k - 1;
+    double* rowk = W + k * ld + k + 1;                           // x_j = W[k][k + 1 + j] (= W[k + 1 + j][k]); zeros from j = m on
+    double xv[T], wj[T];
+    double sq0 = 0, sq1 = 0;
+    const double alpha = rowk[0];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        xv[t] = rowk[sub + 8 * t];
+        if (t == 0) sq0 = sub > 0 ? xv[0] * xv[0] : 0.0;
+        else if (t & 1) sq1 = fma(xv[t], xv[t], sq1);
+        else sq0 = fma(xv[t], xv[t], sq0);
+    }
+    const double sigma = oct_sum_f64(sq0 + sq1);
+    double beta = alpha, tk = 0.0, scale = 0.0;
+    if (sigma > 0.0) {                                            // v_rsq / v_rcp + Newton, the reciprocal seeded from the raw rsq
+        const double n2 = fma(alpha, alpha, sigma);
+        double rs = __builtin_amdgcn_rsq(n2);
+        double rc = __builtin_amdgcn_rcp(fma(n2, rs, fabs(alpha)));   // ~ 1 / (|alpha| + ||x||), refined below
+        rs = rs * fma(-0.5 * n2 * rs, rs, 1.5);
+        rs = rs * fma(-0.5 * n2 * rs, rs, 1.5);
+        const double nrm = n2 * rs;
+        beta = -copysign(nrm, alpha);
+        const double den = fabs(alpha) + nrm;                     // |alpha - beta|
+        rc = fma(fma(-den, rc, 1.0), rc, rc);
+        rc = fma(fma(-den, rc, 1.0), rc, rc);
+        scale = copysign(rc, alpha);
+        tk = den * rs;                                            // (beta - alpha) / beta
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) xv[t] *= scale;                   // v_j (exactly 0 from j = m on)
+    if (sub == 0) xv[0] = 1.0;
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = sub + 8 * t;
+            sv[j] = xv[t];
+            if (j < m) W[(k + 1 + j) * ld + k] = xv[t];
+        }
+    }
+    DBG_T(0);
+    if (tk != 0.0) {                                              // (uniform: every thread holds the same bits)
+        double acc[RB][2];                                        // p = tau A22 v: the rows of a group side by side (ILP)
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int i = g + NG * r;
+            const double* row = W + (k + 1 + min(i, m - 1)) * ld + k + 1 + sub;
+            acc[r][0] = 0; acc[r][1] = 0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[r][t & 1] = fma(row[8 * t], xv[t], acc[r][t & 1]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int i = g + NG * r;
+            const double a = oct_sum_f64(acc[r][0] + acc[r][1]);
+            if (sub == 0) sp[i] = i < m ? tk * a : 0.0;            // (p is exactly 0 from i = m on, like v)
+        }
+    }
+    DBG_T(1);
+    __syncthreads();                                              // every read of row k is done: it now keeps beta and tau
+    DBG_T(2);
+    if (tid == 0) { rowk[0] = beta; rowk[1] = tk; }
+    if (tk != 0.0) {
+        double pv0 = 0, pv1 = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            wj[t] = sp[sub + 8 * t];
+            if (t & 1) pv1 = fma(wj[t], xv[t], pv1);
+            else pv0 = fma(wj[t], xv[t], pv0);
+        }
+        const double K = -0.5 * tk * oct_sum_f64(pv0 + pv1);
+#pragma unroll
+        for (int t = 0; t < T; ++t) wj[t] = fma(K, xv[t], wj[t]);  // w = p + K v
+        DBG_T(3);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {                            // A22 -= v w^T + w v^T
+            const int i = g + NG * r;
+            if (i < m) {
+                const double vi = sv[i], wi = fma(K, vi, sp[i]);
+                double* row = W + (k + 1 + i) * ld + k + 1 + sub;
+#pragma unroll
+                for (int t = 0; t < T; ++t) row[8 * t] = fma(-vi, wj[t], fma(-wi, xv[t], row[8 * t]));
+            }
+        }
+    }
+    DBG_T(4);
+    __syncthreads();
+    DBG_T(5);
+}
+// the steps whose trailing order m = L - k - 1 needs T slots (m > 8 (T - STEP)), then down the ladder
+template <int T, int STEP>
+__device__ __forceinline__ void tri_ladder(double* __restrict__ W, int ld, int L, int& k, double* __restrict__ sv,
+                                           double* __restrict__ sp, long long& _t0) {
+    for (const int kend = min(L - 2, L - 1 - 8 * (T - STEP)); k < kend; ++k) tri_step<T>(W, ld, L, k, sv, sp, _t0);
+    if constexpr (T - STEP > 0) tri_ladder<T - STEP, STEP>(W, ld, L, k, sv, sp, _t0);
+}
+__host__ __device__ constexpr int tri_ld(int L, int step) { return step == 1 ? L + 8 : ((L + 8 * step) | 1); }
+__host__ __device__ constexpr int tri_sp_len(int tmax) { return (TRR_THREADS / 8) * ((8 * tmax + TRR_THREADS / 8 - 1) / (TRR_THREADS / 8)); }
+template <int TMAX, int STEP>  // L <= 8 TMAX; PAD = 8 STEP zero columns
+__global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restrict__ A, int L, int64_t lda, double* __restrict__ dd,
+                                                           double* __restrict__ ee, double* __restrict__ HV,
+                                                           double* __restrict__ tau, int* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double sm_tri[];
+    const int tid = threadIdx.x;
+    const int ld = tri_ld(L, STEP);
+    double* W = sm_tri;
+    double* sv = W + (size_t)L * ld;                              // 8 TMAX entries
+    double* sp = sv + 8 * TMAX;                                   // tri_sp_len(TMAX) entries
+    for (int e = tid; e < L * ld; e += TRR_THREADS) {
+        const int r = e / ld, c = e - r * ld;
+        W[e] = c < L ? A[(int64_t)r * lda + c] : 0.0;
+    }
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    long long _t0 = 0;
+#ifdef PETAL_DEBUG_COUNTERS
+    _t0 = clock64();
+    const long long _w0 = wall_clock64();
+#endif
+    int k = 0;
+    tri_ladder<TMAX, STEP>(W, ld, L, k, sv, sp, _t0);
+#ifdef PETAL_DEBUG_COUNTERS
+    if (tid == 0) g_cyc[25] += wall_clock64() - _w0;
+#endif
+    for (int e = tid; e < (L - 2) * L; e += TRR_THREADS) {       // reflector k: row k of HV, entries k + 1 .. L - 1
+        const int kk = e / L, c = e - kk * L;
+        HV[e] = c > kk ? W[c * ld + kk] : 0.0;
+    }
+    for (int kk = tid; kk < L; kk += TRR_THREADS) {
+        dd[kk] = W[kk * ld + kk];
+        ee[kk] = kk + 2 < L ? W[kk * ld + kk + 1] : (kk + 2 == L ? W[(L - 1) * ld + L - 2] : 0.0);
+        tau[kk] = kk + 2 < L ? W[kk * ld + kk + 2] : 0.0;
+    }
+}
+
+// one wave per eigenpair.  The Sturm count runs on the three-term recurrence of the leading minors, renormalised by their
+// exponent every step (v_frexp_mant / v_ldexp: no division on the chain); d and e^2 are fetched eight at a time so the LDS
+// latency is paid once per eight steps.  The twisted factorisation keeps both recurrences in one instruction stream
+// (lanes 0 and 1) and stores the multipliers, so the two sweeps of z are products only; z then lives in registers and the
+// reflector rows come from an LDS stage filled while the eigenvalue search runs.  An eigenvalue with a neighbour inside
+// gap_tol ||T|| (its vector is then only eps / gap_tol accurate) or a non-finite result raises *flag for the Jacobi solver
+// launched behind this kernel.
+template <int WPB, int QMAX>  // L <= 64 QMAX
+__global__ __launch_bounds__(64 * WPB) void k_trieig_r(const double* __restrict__ dd, const double* __restrict__ ee,
+                                                       const double* __restrict__ HV, const double* __restrict__ tau, int L,
+                                                       double gap_tol, int hv_rows, double* __restrict__ w, double* __restrict__ V,
+                                                       int64_t ldv, int* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double sm_te[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef PETAL_DEBUG_COUNTERS
+    long long _t0 = clock64();
+    const long long _w0 = wall_clock64();
+#define DBG_E(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { long long _t = clock64(); g_cyc[i] += _t - _t0; _t0 = _t; } } while (0)
+#else
+#define DBG_E(i) do {} while (0)
+#endif
+    const int LP = ((L + 7) & ~7) + 8;          // d, e, e^2 padded: whole batches of eight may run past L without a bound check
+    double* sd = sm_te;
+    double* se = sd + LP;
+    double* s2 = se + LP;
+    double* st = s2 + LP;                       // tau
+    double* sdr = st + LP;                      // d and e^2 in reversed order (the recurrence from the bottom)
+    double* s2r = sdr + LP;
+    double* qp = s2r + LP + (size_t)wv * 4 * LP; // per wave: minors from the top / bottom and their predecessors; later l+, u-, z
+    double* qm = qp + LP;
+    double* lp = qm + LP;
+    double* lm = lp + LP;
+    double* shv = s2r + LP + (size_t)WPB * 4 * LP;   // hv_rows reflector rows, staged for the back-transformation
+    // the last hv_rows reflectors (the first ones applied) start their way into LDS now
+    int kbase = max(L - 2 - hv_rows, 0);
+    auto stage = [&](int k0, int nrows) {                          // eight loads per thread in flight: the rows come from HBM / MALL
+        const int ne = nrows * L;
+        const double* src = HV + (size_t)k0 * L;
+        for (int e0 = tid; e0 < ne; e0 += 64 * WPB * 8) {
+            double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + u * 64 * WPB; t8[u] = e < ne ? src[e] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + u * 64 * WPB; if (e < ne) shv[e] = t8[u]; }
+        }
+    };
+    stage(kbase, L - 2 - kbase);
+    // Gershgorin interval and the scale of T (every wave, from global memory: L values)
+    double glo = 1e300, ghi = -1e300;
+    for (int i = lane; i < L; i += 64) {
+        const double r = (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i + 1 < L ? fabs(ee[i]) : 0.0);
+        glo = fmin(glo, dd[i] - r); ghi = fmax(ghi, dd[i] + r);
+    }
+    for (int off = 32; off > 0; off >>= 1) { glo = fmin(glo, __shfl_xor(glo, off, 64)); ghi = fmax(ghi, __shfl_xor(ghi, off, 64)); }
+    const double tnorm = fmax(fabs(glo), fabs(ghi));
+    const bool sane = tnorm > 1e-140 && tnorm < 1e140;
+    const double inv = sane ? 1.0 / tnorm : 0.0;
+    for (int i = tid; i < LP; i += 64 * WPB) {
+        const double ev = i < L ? ee[i] * inv : 0.0;
+        sd[i] = i < L ? dd[i] * inv : 4.0;                        // padding: d - x > 0 and e = 0 there, no sign change is added
+        se[i] = ev;
+        s2[i] = fmax(ev * ev, 1e-280);                            // never an exact split: the minors cannot stick at zero
+        st[i] = i < L ? tau[i] : 0.0;
+        const int ir = L - 1 - i;                                 // reversed: sdr[t] = d_{L-1-t}, s2r[u] = e^2_{L-2-u}
+        sdr[i] = ir >= 0 ? dd[ir] * inv : 4.0;
+        const double evr = ir >= 1 ? ee[ir - 1] * inv : 0.0;
+        s2r[i] = fmax(evr * evr, 1e-280);
+    }
+    __syncthreads();
+    DBG_E(16);
+    const int j = min(blockIdx.x * WPB + wv, L - 1);             // descending index (a surplus wave repeats the last one)
+    const int kth = L - 1 - j;
+    // (p0, p1) = two consecutive leading minors of T - x on a common power-of-two scale.  The scale follows the exponent of
+    // the OLDER of the two (integer instructions on the exponent field, off the dependent chain), so the chain per step is
+    // one fma and one multiply; the magnitudes stay within a few decades of 1 because a step grows a minor at most 3 x.
+    auto step_scale = [](double p1) {
+        const int ef = max((__double2hiint(p1) >> 20) & 0x7ff, 423);
+        return __hiloint2double((2045 - ef) << 20, 0);            // 2^(1022 - ef), at most 2^599 (exact zero, denormals)
+    };
+    auto sturm = [&](double x) {                                  // number of eigenvalues of T / ||T|| below x
+        double p0 = 1.0, p1 = sd[0] - x;
+        unsigned sprev = (unsigned)__double2hiint(p1) >> 31, cnt = sprev;
+        for (int i0 = 1; i0 < L; i0 += 8) {
+            double dv[8], e2v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { dv[u] = sd[i0 + u]; e2v[u] = s2[i0 + u - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                         // (runs into the padding: no bound check per step)
+                const double sc = step_scale(p1);
+                const double raw = fma(dv[u] - x, p1, -e2v[u] * p0);
+                const unsigned sg = (unsigned)__double2hiint(raw) >> 31;
+                cnt += sg ^ sprev;                                // sign change (a zero minor: either sign)
+                sprev = sg;
+                p0 = p1 * sc;
+                p1 = raw * sc;
+            }
+        }
+        return (int)cnt;
+    };
+    double lo = glo * inv - 1e-12, hi = ghi * inv + 1e-12;
+    for (int pass = 0; pass < 10; ++pass) {                       // 65-way split per pass: 65^10 > 2^60
+        const double h = (hi - lo) * (1.0 / 65.0);
+        const int c = sturm(lo + h * (lane + 1));
+        const unsigned long long mask = __ballot(c > kth);
+        if (mask) {
+            const int first = __ffsll((long long)mask) - 1;
+            const double nhi = lo + h * (first + 1), nlo = lo + h * first;
+            hi = nhi; lo = nlo;
+        } else {
+            lo = lo + h * 64;
+        }
+    }
+    const double lam = 0.5 * (lo + hi);
+    DBG_E(17);
+    if (lane == 0) w[j] = lam * tnorm;
+    // neighbours inside gap_tol? (counts at lam -+ gap_tol: exactly this one eigenvalue should lie between)
+    {
+        const int c = sturm((lane & 1) ? lam + gap_tol : lam - gap_tol);
+        const int c0 = __builtin_amdgcn_readlane(c, 0), c1 = __builtin_amdgcn_readlane(c, 1);
+        if (lane == 0 && (c1 - c0 != 1 || !sane)) atomicOr(flag, 1);
+    }
+    DBG_E(18);
+    // twisted factorisation.  The pivots are ratios of consecutive minors: q+_i = p_{i+1} / p_i from the top (lane 0), q-_i
+    // likewise from the bottom (lane 1), both on the division-free recurrence of the Sturm count in ONE instruction stream:
+    // lane 1 walks the REVERSED copies of d and e^2 and leaves its results in reversed order, so both lanes address
+    // base + step.  The divisions, gamma and the multipliers are then lane-parallel.
+    const bool fw = lane == 0;
+    if (lane < 2) {
+        const double* bd = fw ? sd : sdr;
+        const double* be = fw ? s2 : s2r;
+        double* narr = fw ? qp : qm;
+        double* darr = fw ? lp : lm;
+        double p0 = 1.0, p1 = bd[0] - lam;
+        narr[0] = p1;
+        darr[0] = 1.0;
+        for (int t0 = 1; t0 < L; t0 += 8) {                       // (steps past L - 1 read and write the padding)
+            double dv[8], e2v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { dv[u] = bd[t0 + u]; e2v[u] = be[t0 + u - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double sc = step_scale(p1);
+                const double raw = fma(dv[u] - lam, p1, -e2v[u] * p0);
+                narr[t0 + u] = raw;
+                darr[t0 + u] = p1;
+                p0 = p1 * sc;
+                p1 = raw * sc;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    DBG_E(19);
+    double gbest = 1e300;
+    int rbest = 0;
+    {
+        double qpv[QMAX], qmv[QMAX];
+        auto pivot = [](double num, double den) {                 // a vanishing or non-finite pivot is replaced, as dstein does
+            double q = num / den;
+            if (!(fabs(q) >= 1e-30)) q = 1e-30;
+            if (!(fabs(q) <= 1e300)) q = copysign(1e300, num) * (den < 0.0 ? -1.0 : 1.0);
+            return q;
+        };
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            const int i = lane + 64 * q;
+            if (i < L) {
+                qpv[q] = pivot(qp[i], lp[i]);
+                qmv[q] = pivot(qm[L - 1 - i], lm[L - 1 - i]);
+                const double gm = fabs(qpv[q] + qmv[q] - (sd[i] - lam));
+                if (gm < gbest) { gbest = gm; rbest = i; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // multipliers, laid out for the two sweeps away from r: lp[L - 2 - i] = l+_i = e_i / q+_i (lane 0 walks i downwards,
+        // the array upwards), lm[i] = u-_{i-1} = e_{i-1} / q-_i
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            const int i = lane + 64 * q;
+            if (i < L) {
+                if (i + 1 < L) lp[L - 2 - i] = se[i] * rcp_nr(qpv[q]);
+                if (i > 0) lm[i] = se[i - 1] * rcp_nr(qmv[q]);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double og = __shfl_xor(gbest, off, 64);
+        const int orr = __shfl_xor(rbest, off, 64);
+        if (og < gbest || (og == gbest && orr < rbest)) { gbest = og; rbest = orr; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    DBG_E(20);
+    // z_r = 1, z_i = -l+_i z_{i+1} below r (lane 0: kept reversed in qm), z_i = -u-_{i-1} z_{i-1} above (lane 1: in qp)
+    if (lane < 2) {
+        const double* bm = fw ? lp + (L - 2 - rbest) : lm + rbest;   // the multiplier of step t sits at bm[t]
+        double* bz = fw ? qm + (L - 1 - rbest) : qp + rbest;         // z of step t goes to bz[t]
+        const int tcap = (fw ? rbest : L - 1 - rbest) + 8;           // steps past a lane's own end land in the padding
+        const int nmax = max(rbest, L - 1 - rbest);
+        double zi = 1.0;
+        bz[0] = 1.0;
+        for (int t0 = 1; t0 <= nmax; t0 += 8) {
+            double mv[8];
+            int tt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { tt[u] = min(t0 + u, tcap); mv[u] = bm[tt[u]]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { zi = -mv[u] * zi; bz[tt[u]] = zi; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    DBG_E(21);
+    double zq[QMAX];
+    double zmax = 0;
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        const int i = lane + 64 * q;
+        zq[q] = i < L ? (i < rbest ? qm[L - 1 - i] : qp[i]) : 0.0;
+        zmax = fmax(zmax, fabs(zq[q]));
+    }
+    for (int off = 32; off > 0; off >>= 1) zmax = fmax(zmax, __shfl_xor(zmax, off, 64));
+    const double zs = zmax > 0.0 && zmax < 1e300 ? 1.0 / zmax : 1.0;
+    double nrm = 0;
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) { zq[q] *= zs; nrm += zq[q] * zq[q]; }
+    nrm = wave_sum_f64(nrm);
+    const double rn = nrm > 0.0 ? 1.0 / sqrt(nrm) : 0.0;
+    if (lane == 0 && !(nrm > 0.0 && nrm < 1e300)) atomicOr(flag, 1);
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) zq[q] *= rn;
+    DBG_E(22);
+    // v = H_0 ... H_{L-3} z from the staged rows, hv_rows at a time (one stage when they all fit)
+    for (int ktop = L - 3; ktop >= 0;) {
+        for (int k = ktop; k >= kbase; k -= 4) {
+            double hv[4][QMAX], tk[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int kk = max(k - b, kbase);
+                tk[b] = k - b >= kbase ? st[kk] : 0.0;
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q) {
+                    const int i = lane + 64 * q;
+                    hv[b][q] = i < L ? shv[(kk - kbase) * L + i] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                double dot = 0;
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q) dot += hv[b][q] * zq[q];
+                const double f = tk[b] * wave_sum_f64(dot);
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q) zq[q] -= f * hv[b][q];
+            }
+        }
+        ktop = kbase - 1;
+        if (ktop < 0) break;
+        __syncthreads();                                          // (uniform: every wave of the block walks the same stages)
+        kbase = max(ktop + 1 - hv_rows, 0);
+        stage(kbase, ktop + 1 - kbase);
+        __syncthreads();
+    }
+    DBG_E(23);
+#ifdef PETAL_DEBUG_COUNTERS
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_cyc[24] += wall_clock64() - _w0;
+#endif
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        const int i = lane + 64 * q;
+        if (i < L) V[(int64_t)i * ldv + j] = zq[q];
+    }
+}
+
 // replay of the rotation log on V = I: wave <-> row r of V (kept in LDS), lanes <-> the disjoint pairs of a round.
 // The angles of JR_BATCH rounds are fetched ahead (independent loads) so the global-memory latency is paid once per batch.
 constexpr int JR_WAVES = 4, JR_BATCH = 8;
 template <int HP>  // pairs per lane: half <= 64 HP
 __global__ __launch_bounds__(64 * JR_WAVES) void k_apply_rot(const jf64x2* __restrict__ log_cs, const int* __restrict__ nrounds,
-                                                             const int* __restrict__ rank, int L, double* __restrict__ V, int64_t ldv) {
+                                                             const int* __restrict__ rank, int L, double* __restrict__ V, int64_t ldv,
+                                                             const int* __restrict__ flag) {
+    if (flag && *flag == 0) return;
     extern __shared__ __attribute__((aligned(16))) double sm_jr[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int Le = (L + 1) & ~1, half = Le / 2, rounds = Le - 1;
@@ -4117,6 +4819,69 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
 void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel) {
     if (L == 0) return;
     if (L > EIG_MAXL) throw std::runtime_error("eigh: matrix too large for the one-workgroup Jacobi solver");
+    // Two-stage solver first (tridiagonalisation on one workgroup, then one wave per eigenpair over the chip); the Jacobi
+    // launches below run behind it and return at once unless its verdict flags eigenvalues too close for its vectors.
+    static const bool jacobi_only = getenv("PETAL_EIGH_JACOBI") != nullptr;
+    int* flag = nullptr;
+    char* ts = nullptr;
+    if (!jacobi_only && L >= 3 && L <= 2048) {
+        // eigenvectors of eigenvalues closer than gap_tol ||A|| come out only eps / gap_tol accurate: fp32 results carry
+        // 2e-8, fp64 results 2e-11; anything closer goes to Jacobi
+        const double gap_tol = tol_rel >= 1e-9 ? 1e-8 : 1e-5;
+        const int64_t ldw = L | 1;
+        const size_t lds_in = sizeof(double) * ((size_t)L * ldw + 2 * L + 32);
+        const bool inlds = lds_in <= 160 * 1024 - 256;
+        const bool regs = L <= 138;                               // (the padded working copy of k_tridiag_r fits the LDS)
+        const size_t bytes = sizeof(double) * (3 * L + L * L + (inlds ? 0 : L * ldw)) + 64;
+        ts = (char*)dev_alloc(d, bytes);
+        double* dd = reinterpret_cast<double*>(ts);
+        double* ee = dd + L;
+        double* tau = ee + L;
+        double* HV = tau + L;
+        double* Wg = inlds ? nullptr : HV + L * L;
+        flag = reinterpret_cast<int*>(ts + bytes - 64);
+        if (regs) {
+#define PETAL_TRI_LAUNCH(TM, ST)                                                                                                   \
+    do {                                                                                                                           \
+        const size_t lds_r = sizeof(double) * ((size_t)L * tri_ld((int)L, ST) + 8 * TM + tri_sp_len(TM));                          \
+        set_max_lds(d, reinterpret_cast<const void*>(k_tridiag_r<TM, ST>));                                                        \
+        hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, flag); \
+    } while (0)
+            if (L <= 80) PETAL_TRI_LAUNCH(10, 2);
+            else if (L <= 132) PETAL_TRI_LAUNCH(18, 2);
+            else PETAL_TRI_LAUNCH(18, 1);
+#undef PETAL_TRI_LAUNCH
+            launch_check();
+            const int hv_rows = (int)std::min<int64_t>(L - 2, (96 * 1024) / (8 * L));
+            const size_t lds_e = sizeof(double) * (22 * (((L + 7) & ~7) + 8) + (size_t)hv_rows * L);
+            if (L <= 128) {
+                set_max_lds(d, reinterpret_cast<const void*>(k_trieig_r<4, 2>));
+                hipLaunchKernelGGL((k_trieig_r<4, 2>), dim3(cdiv(L, 4)), dim3(256), lds_e, d->stream, dd, ee, HV, tau, (int)L, gap_tol, hv_rows, w, V, ldv, flag);
+            } else {
+                set_max_lds(d, reinterpret_cast<const void*>(k_trieig_r<4, 3>));
+                hipLaunchKernelGGL((k_trieig_r<4, 3>), dim3(cdiv(L, 4)), dim3(256), lds_e, d->stream, dd, ee, HV, tau, (int)L, gap_tol, hv_rows, w, V, ldv, flag);
+            }
+            launch_check();
+        } else {
+            if (inlds) {
+                set_max_lds(d, reinterpret_cast<const void*>(k_tridiag<true>));
+                hipLaunchKernelGGL(k_tridiag<true>, dim3(1), dim3(TRI_THREADS), lds_in, d->stream, A, (int)L, lda, Wg, dd, ee, HV, tau);
+            } else {
+                hipLaunchKernelGGL(k_tridiag<false>, dim3(1), dim3(TRI_THREADS), sizeof(double) * (2 * L + 32), d->stream, A, (int)L, lda, Wg, dd, ee, HV, tau);
+            }
+            launch_check();
+            if (L <= 512) {
+                hipLaunchKernelGGL(k_trieig<4>, dim3(cdiv(L, 4)), dim3(256), sizeof(double) * 15 * L, d->stream, dd, ee, HV, tau, (int)L, w, V, ldv);
+            } else {
+                set_max_lds(d, reinterpret_cast<const void*>(k_trieig<1>));
+                hipLaunchKernelGGL(k_trieig<1>, dim3((unsigned)L), dim3(64), sizeof(double) * 6 * L, d->stream, dd, ee, HV, tau, (int)L, w, V, ldv);
+            }
+            launch_check();
+            hipLaunchKernelGGL(k_trieig_verdict, dim3(1), dim3(256), 0, d->stream, w, (int)L, gap_tol, flag);
+            launch_check();
+        }
+    }
+    struct Cleanup { Dev* d; char* p; ~Cleanup() { if (p) dev_free(d, p); } } cleanup{d, ts};
     if (jaca_lds_bytes((int)L) <= 160 * 1024 - 256) {
         // split solver: A in LDS + rotation log, eigenvectors replayed on L waves
         const int Le = (int)((L + 1) & ~1), half = Le / 2, rounds = Le - 1;
@@ -4136,7 +4901,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
 #define JACA_CASE(M, G)                                                                                                  \
     case 10 * M + (G == 32 ? 1 : 0): {                                                                                   \
         set_max_lds(d, reinterpret_cast<const void*>(k_jacobi_a<M, G>));                        \
-        hipLaunchKernelGGL((k_jacobi_a<M, G>), dim3(1), dim3(threads), lds, d->stream, A, (int)L, lda, log_cs, nrounds, w, rank, pw, tol_rel); \
+        hipLaunchKernelGGL((k_jacobi_a<M, G>), dim3(1), dim3(threads), lds, d->stream, A, (int)L, lda, log_cs, nrounds, w, rank, pw, tol_rel, (const int*)flag); \
     } break;
         switch (10 * std::min(mb2, 5) + (gw == 32 ? 1 : 0)) {
             JACA_CASE(1, 16) JACA_CASE(2, 16) JACA_CASE(3, 16) JACA_CASE(4, 16) JACA_CASE(5, 16)
@@ -4148,8 +4913,8 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         const int hp = (half + 63) / 64;
         const dim3 grid((unsigned)cdiv(L, JR_WAVES));
         const size_t lds2 = sizeof(double) * JR_WAVES * Le;
-        if (hp <= 1) hipLaunchKernelGGL(k_apply_rot<1>, grid, dim3(64 * JR_WAVES), lds2, d->stream, log_cs, nrounds, rank, (int)L, V, ldv);
-        else hipLaunchKernelGGL(k_apply_rot<2>, grid, dim3(64 * JR_WAVES), lds2, d->stream, log_cs, nrounds, rank, (int)L, V, ldv);
+        if (hp <= 1) hipLaunchKernelGGL(k_apply_rot<1>, grid, dim3(64 * JR_WAVES), lds2, d->stream, log_cs, nrounds, rank, (int)L, V, ldv, (const int*)flag);
+        else hipLaunchKernelGGL(k_apply_rot<2>, grid, dim3(64 * JR_WAVES), lds2, d->stream, log_cs, nrounds, rank, (int)L, V, ldv, (const int*)flag);
         launch_check();
         dev_free(d, buf);
         return;
@@ -4158,7 +4923,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     const size_t lds = sizeof(double) * jac_ws_doubles((int)L, 1024);
     {
         set_max_lds(d, reinterpret_cast<const void*>(k_eigh<0>));
-        hipLaunchKernelGGL(k_eigh<0>, dim3(1), dim3(1024), lds, d->stream, A, (int)L, lda, Vtmp, V, ldv, w, tol_rel);
+        hipLaunchKernelGGL(k_eigh<0>, dim3(1), dim3(1024), lds, d->stream, A, (int)L, lda, Vtmp, V, ldv, w, tol_rel, (const int*)flag);
     }
     launch_check();
     dev_free(d, Vtmp);
