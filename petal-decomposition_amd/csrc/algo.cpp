@@ -580,7 +580,9 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     dev_memset(c.dev, lam.p, 0, lam.bytes);
     // only the top-k pairs reach the outputs (components, singular values, the k columns of U that svd_flip signs)
     const bool partial = topk_eigh(c, C.f64(), d, dp, k, V.f64(), lam.f64());
-    if (!partial) op_eigh(c.dev, C.f64(), dp, dp, V.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
+    // (order d, not the padded dp: the zero padding would only add dp - d exact zero eigenvalues, a cluster that sends the
+    // two-stage solver to its Jacobi fallback; V and lam beyond d stay at the zeros set above)
+    if (!partial) op_eigh(c.dev, C.f64(), d, dp, V.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
     op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
     op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, dt == F32 ? 1e-6 : 1e-10);
 
@@ -765,7 +767,7 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
     dev_memset(c.dev, U.p, 0, U.bytes);
     dev_memset(c.dev, lam.p, 0, lam.bytes);
     if (!topk_eigh(c, C.f64(), d, dp, nc, U.f64(), lam.f64()))  // only the first nc pairs are used below
-        op_eigh(c.dev, C.f64(), dp, dp, U.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
+        op_eigh(c.dev, C.f64(), d, dp, U.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
     op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
     op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, 0.0);
     op_dscale_cols(c.dev, U.f64(), dp, dp, dp, inv.f64());  // U[:, i] / sigma_i  == K^T (ica.rs:190-203)

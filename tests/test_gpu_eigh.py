@@ -1,0 +1,120 @@
+"""The symmetric eigen-solver behind every fit (op_eigh: Householder tridiagonalisation + one wave per eigenpair, with the
+Jacobi solver as the fallback for eigenvalues it flags as too close), driven through the product API on a real MI355X:
+Pca with k = d eigen-decomposes the d x d covariance, so d walks the solver's kernel boundaries
+
+    d <= 80 / <= 132 / <= 138   the three register-resident tridiagonalisation kernels (k_tridiag_r<10,2>, <18,2>, <18,1>)
+    d  = 139 .. 141             working copy in LDS (k_tridiag<true>),  d >= 142: in global memory (k_tridiag<false>)
+    d <= 128 / > 128            two / three 64-lane slices of an eigenvector per wave (k_trieig_r<4,2>, <4,3>)
+
+and the spectra cover both outcomes of the verdict: well separated eigenvalues (the two-stage result is used; fp32 inputs
+accept gaps down to 1e-8 of the largest eigenvalue) and clusters / rank deficiency (the flag goes up and Jacobi runs).
+Checked against numpy's LAPACK on the same centred data: singular values, orthonormality of the components and the
+eigen-residual of every component, i.e. properties that do not depend on how a degenerate subspace is rotated."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [3, 4, 5, 15, 16, 17, 33, 64, 74, 80, 81, 100, 128, 129, 132, 133, 138, 139, 141, 142, 160]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import petal_decomposition_amd as petal
+    c = petal.Context(0)
+    yield c
+    c.close()
+
+
+def _data(d, kind, dtype, seed):
+    """n x d data whose covariance has a prescribed spectrum (orthogonal mixing, so the spectrum is known up to sampling)"""
+    rng = np.random.default_rng(seed)
+    n = max(4 * d, 256)
+    if kind == "geometric":          # sigma_i = 0.97^i: eigenvalue neighbours 6 % apart, lambda_min / lambda_max = 6e-5 at d = 160
+        s = 0.97 ** np.arange(d)
+    elif kind == "clustered":        # groups of four equal singular values: exact multiplicities in expectation
+        s = np.repeat(0.8 ** np.arange((d + 3) // 4), 4)[:d]
+    elif kind == "rank_deficient":   # rank d // 2: half of the spectrum is exactly zero after centring
+        s = np.where(np.arange(d) < max(d // 2, 1), 0.9 ** np.arange(d), 0.0)
+    else:
+        raise ValueError(kind)
+    u, _ = np.linalg.qr(rng.standard_normal((n, d)))
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    x = (u * s) @ q.T * np.sqrt(n)
+    if kind == "clustered":
+        # make the multiplicities EXACT in the sample covariance: u has orthonormal, but not centred, columns
+        u -= u.mean(axis=0)
+        u, _ = np.linalg.qr(u)
+        x = (u * s) @ q.T * np.sqrt(n)
+    return np.ascontiguousarray(x.astype(dtype))
+
+
+def _check(ctx, x, tol_sigma, tol_orth, tol_res):
+    import petal_decomposition_amd as petal
+    d = x.shape[1]
+    m = petal.Pca(d, ctx=ctx)
+    m.fit(x)
+    c = np.asarray(m.components()).astype(np.float64)
+    sg = np.asarray(m.singular_values()).astype(np.float64)
+    xc = x.astype(np.float64) - x.astype(np.float64).mean(axis=0)
+    ref = np.linalg.svd(xc, compute_uv=False)
+    r = min(len(ref), d)
+    assert np.all(np.isfinite(c)) and np.all(np.isfinite(sg))
+    assert np.all(np.diff(sg) <= 1e-12 * sg[0]), "singular values must come out in descending order"
+    # (the fit eigen-decomposes the Gram matrix: it is the EIGENVALUES sigma^2 that carry eps sigma_1^2, a zero singular value
+    # comes back as sqrt(eps) sigma_1 -- the documented floor of the Gram route, tests/test_gpu_parity.py::test_gram_route_...)
+    assert np.abs(sg[:r] ** 2 - ref[:r] ** 2).max() <= tol_sigma * ref[0] ** 2, np.abs(sg[:r] ** 2 - ref[:r] ** 2).max() / ref[0] ** 2
+    # components of non-zero singular values are orthonormal ...
+    live = sg > 1e-6 * sg[0] if x.dtype == np.float32 else sg > 1e-10 * sg[0]
+    cl = c[live]
+    assert np.abs(cl @ cl.T - np.eye(cl.shape[0])).max() <= tol_orth, np.abs(cl @ cl.T - np.eye(cl.shape[0])).max()
+    # ... and eigenvectors of the covariance: || C v - sigma^2 v || <= tol sigma_1^2, whatever basis a cluster came out in
+    cov = xc.T @ xc
+    res = np.linalg.norm(cl @ cov - (sg[live] ** 2)[:, None] * cl, axis=1)
+    assert res.max() <= tol_res * ref[0] ** 2, res.max() / ref[0] ** 2
+
+
+@pytest.mark.parametrize("d", SIZES)
+def test_eigh_across_kernel_boundaries_fp32(ctx, d):
+    _check(ctx, _data(d, "geometric", np.float32, 100 + d), tol_sigma=4e-6, tol_orth=2e-5, tol_res=2e-6)
+
+
+@pytest.mark.parametrize("d", [5, 16, 74, 81, 133, 139, 142])
+def test_eigh_across_kernel_boundaries_fp64(ctx, d):
+    _check(ctx, _data(d, "geometric", np.float64, 200 + d), tol_sigma=1e-12, tol_orth=1e-10, tol_res=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["clustered", "rank_deficient"])
+@pytest.mark.parametrize("d", [8, 74, 100, 138, 141])
+def test_eigh_clusters_take_the_jacobi_fallback(ctx, d, kind):
+    """exact multiplicities and zero eigenvalues: the two-stage verdict flags them and the Jacobi result is delivered"""
+    _check(ctx, _data(d, kind, np.float32, 300 + d), tol_sigma=4e-6, tol_orth=2e-5, tol_res=3e-6)
+    _check(ctx, _data(d, kind, np.float64, 400 + d), tol_sigma=1e-12, tol_orth=1e-11, tol_res=1e-12)
+
+
+def test_eigh_two_stage_and_jacobi_agree(ctx):
+    """the same fit with the two-stage route disabled in a child process (PETAL_EIGH_JACOBI is read once per process)"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    import petal_decomposition_amd as petal
+    x = _data(74, "geometric", np.float32, 7)
+    m = petal.Pca(74, ctx=ctx)
+    m.fit(x)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "x.npy"), x)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); import petal_decomposition_amd as petal; "
+                "x = np.load(%r); m = petal.Pca(74, ctx=petal.Context(0)); m.fit(x); "
+                "np.savez(%r, c=np.asarray(m.components()), s=np.asarray(m.singular_values()))"
+                % (root, os.path.join(tmp, "x.npy"), os.path.join(tmp, "out.npz")))
+        env = dict(os.environ, PETAL_EIGH_JACOBI="1")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+        ref = np.load(os.path.join(tmp, "out.npz"))
+    s2, sj = np.asarray(m.singular_values()), ref["s"]
+    assert np.abs(s2 - sj).max() <= 1e-6 * sj[0]
+    c2, cj = np.asarray(m.components()).astype(np.float64), ref["c"].astype(np.float64)
+    sign = np.sign(np.sum(c2 * cj, axis=1))
+    # neighbours are 6 % apart: both routes resolve every vector; fp32 outputs
+    assert np.abs(c2 - sign[:, None] * cj).max() <= 5e-5
