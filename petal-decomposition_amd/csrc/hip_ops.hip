@@ -3133,6 +3133,16 @@ __device__ __forceinline__ double rsqrt_nr(double x) {   // 1 / sqrt(x) for norm
     r = r * fma(-0.5 * x * r, r, 1.5);
     return r;
 }
+__device__ __forceinline__ void wave_sum2_f64(double& a, double& b) {  // two sums at once: the two chains interleave
+    a += dpp_f64<0xB1>(a);  b += dpp_f64<0xB1>(b);
+    a += dpp_f64<0x4E>(a);  b += dpp_f64<0x4E>(b);
+    a += dpp_f64<0x141>(a); b += dpp_f64<0x141>(b);
+    a += dpp_f64<0x140>(a); b += dpp_f64<0x140>(b);
+    const double a0 = readlane_d(a, 0) + readlane_d(a, 16), b0 = readlane_d(b, 0) + readlane_d(b, 16);
+    const double a1 = readlane_d(a, 32) + readlane_d(a, 48), b1 = readlane_d(b, 32) + readlane_d(b, 48);
+    a = a0 + a1;
+    b = b0 + b1;
+}
 __device__ __forceinline__ double oct_sum_f64(double v) {  // sum over each group of 8 consecutive lanes
     v += dpp_f64<0xB1>(v);
     v += dpp_f64<0x4E>(v);
@@ -3150,7 +3160,10 @@ __device__ __forceinline__ double oct_sum_f64(double v) {  // sum over each grou
 // copy carries PAD zero columns on the right, at least the ladder's overshoot 8 T - m, so no column needs a bound check
 // (v and w are exactly zero there and the update leaves the zeros alone).  Reflector k is parked in column k of the working
 // copy (dead by then), beta and tau in row k; one pass at the end writes d, e, tau and the reflector rows out.
-constexpr int TRR_THREADS = 256;
+#ifndef PETAL_TRR_THREADS
+#define PETAL_TRR_THREADS 512   // two waves per SIMD: 256 and 1024 threads measured 6 % and 12 % slower at L = 74
+#endif
+constexpr int TRR_THREADS = PETAL_TRR_THREADS;
 template <int T>
 __device__ __forceinline__ void tri_step(double* __restrict__ W, int ld, int L, int k, double* __restrict__ sv,
                                          double* __restrict__ sp, long long& _t0) {
@@ -3211,7 +3224,7 @@ __device__ __forceinline__ void tri_step(double* __restrict__ W, int ld, int L, 
         for (int r = 0; r < RB; ++r) {
             const int i = g + NG * r;
             const double a = oct_sum_f64(acc[r][0] + acc[r][1]);
-            if (sub == 0) sp[i] = i < m ? tk * a : 0.0;            // (p is exactly 0 from i = m on, like v)
+            if (sub == 0 && i < 8 * T) sp[i] = i < m ? tk * a : 0.0;  // (p is exactly 0 from i = m on, like v)
         }
     }
     DBG_T(1);
@@ -3253,11 +3266,12 @@ __device__ __forceinline__ void tri_ladder(double* __restrict__ W, int ld, int L
     if constexpr (T - STEP > 0) tri_ladder<T - STEP, STEP>(W, ld, L, k, sv, sp, _t0);
 }
 __host__ __device__ constexpr int tri_ld(int L, int step) { return step == 1 ? L + 8 : ((L + 8 * step) | 1); }
-__host__ __device__ constexpr int tri_sp_len(int tmax) { return (TRR_THREADS / 8) * ((8 * tmax + TRR_THREADS / 8 - 1) / (TRR_THREADS / 8)); }
+__host__ __device__ constexpr int tri_sp_len(int tmax) { return 8 * tmax; }
 template <int TMAX, int STEP>  // L <= 8 TMAX; PAD = 8 STEP zero columns
 __global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restrict__ A, int L, int64_t lda, double* __restrict__ dd,
                                                            double* __restrict__ ee, double* __restrict__ HV,
-                                                           double* __restrict__ tau, int* __restrict__ flag) {
+                                                           double* __restrict__ tau, double* __restrict__ gg,
+                                                           int* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) double sm_tri[];
     const int tid = threadIdx.x;
     const int ld = tri_ld(L, STEP);
@@ -3289,6 +3303,14 @@ __global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restr
         ee[kk] = kk + 2 < L ? W[kk * ld + kk + 1] : (kk + 2 == L ? W[(L - 1) * ld + L - 2] : 0.0);
         tau[kk] = kk + 2 < L ? W[kk * ld + kk + 2] : 0.0;
     }
+    // gg[k] = v_k . v_{k-1} (lets the back-transformation apply two reflectors per reduction round), eight lanes per k
+    for (int kk = tid >> 3; kk < L; kk += TRR_THREADS / 8) {
+        double acc = 0;
+        if (kk >= 1 && kk + 2 < L)
+            for (int c = kk + 1 + (tid & 7); c < L; c += 8) acc += W[c * ld + kk] * W[c * ld + kk - 1];
+        acc = oct_sum_f64(acc);
+        if ((tid & 7) == 0) gg[kk] = acc;
+    }
 }
 
 // one wave per eigenpair.  The Sturm count runs on the three-term recurrence of the leading minors, renormalised by their
@@ -3300,9 +3322,10 @@ __global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restr
 // launched behind this kernel.
 template <int WPB, int QMAX>  // L <= 64 QMAX
 __global__ __launch_bounds__(64 * WPB) void k_trieig_r(const double* __restrict__ dd, const double* __restrict__ ee,
-                                                       const double* __restrict__ HV, const double* __restrict__ tau, int L,
-                                                       double gap_tol, int hv_rows, double* __restrict__ w, double* __restrict__ V,
-                                                       int64_t ldv, int* __restrict__ flag) {
+                                                       const double* __restrict__ HV, const double* __restrict__ tau,
+                                                       const double* __restrict__ gg, int L, double gap_tol, int hv_rows,
+                                                       double* __restrict__ w, double* __restrict__ V, int64_t ldv,
+                                                       int* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) double sm_te[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef PETAL_DEBUG_COUNTERS
@@ -3319,11 +3342,12 @@ __global__ __launch_bounds__(64 * WPB) void k_trieig_r(const double* __restrict_
     double* st = s2 + LP;                       // tau
     double* sdr = st + LP;                      // d and e^2 in reversed order (the recurrence from the bottom)
     double* s2r = sdr + LP;
-    double* qp = s2r + LP + (size_t)wv * 4 * LP; // per wave: minors from the top / bottom and their predecessors; later l+, u-, z
+    double* sg = s2r + LP;                      // v_k . v_{k-1}
+    double* qp = sg + LP + (size_t)wv * 4 * LP; // per wave: minors from the top / bottom and their predecessors; later l+, u-, z
     double* qm = qp + LP;
     double* lp = qm + LP;
     double* lm = lp + LP;
-    double* shv = s2r + LP + (size_t)WPB * 4 * LP;   // hv_rows reflector rows, staged for the back-transformation
+    double* shv = sg + LP + (size_t)WPB * 4 * LP;   // hv_rows reflector rows, staged for the back-transformation
     // the last hv_rows reflectors (the first ones applied) start their way into LDS now
     int kbase = max(L - 2 - hv_rows, 0);
     auto stage = [&](int k0, int nrows) {                          // eight loads per thread in flight: the rows come from HBM / MALL
@@ -3354,6 +3378,7 @@ __global__ __launch_bounds__(64 * WPB) void k_trieig_r(const double* __restrict_
         se[i] = ev;
         s2[i] = fmax(ev * ev, 1e-280);                            // never an exact split: the minors cannot stick at zero
         st[i] = i < L ? tau[i] : 0.0;
+        sg[i] = i < L ? gg[i] : 0.0;
         const int ir = L - 1 - i;                                 // reversed: sdr[t] = d_{L-1-t}, s2r[u] = e^2_{L-2-u}
         sdr[i] = ir >= 0 ? dd[ir] * inv : 4.0;
         const double evr = ir >= 1 ? ee[ir - 1] * inv : 0.0;
@@ -3379,19 +3404,24 @@ __global__ __launch_bounds__(64 * WPB) void k_trieig_r(const double* __restrict_
             for (int u = 0; u < 8; ++u) { dv[u] = sd[i0 + u]; e2v[u] = s2[i0 + u - 1]; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {                         // (runs into the padding: no bound check per step)
-                const double sc = step_scale(p1);
                 const double raw = fma(dv[u] - x, p1, -e2v[u] * p0);
                 const unsigned sg = (unsigned)__double2hiint(raw) >> 31;
                 cnt += sg ^ sprev;                                // sign change (a zero minor: either sign)
                 sprev = sg;
-                p0 = p1 * sc;
-                p1 = raw * sc;
+                if (u & 1) {                                      // renormalise every second step: two steps move a minor by
+                    const double sc = step_scale(p1);             // at most 1e32 either way
+                    p0 = p1 * sc;
+                    p1 = raw * sc;
+                } else {
+                    p0 = p1;
+                    p1 = raw;
+                }
             }
         }
         return (int)cnt;
     };
     double lo = glo * inv - 1e-12, hi = ghi * inv + 1e-12;
-    for (int pass = 0; pass < 10; ++pass) {                       // 65-way split per pass: 65^10 > 2^60
+    for (int pass = 0; pass < 9; ++pass) {                        // 65-way split per pass: (2 + 2e-12) / 65^9 < 1e-16 of ||T||
         const double h = (hi - lo) * (1.0 / 65.0);
         const int c = sturm(lo + h * (lane + 1));
         const unsigned long long mask = __ballot(c > kth);
@@ -3432,12 +3462,17 @@ __global__ __launch_bounds__(64 * WPB) void k_trieig_r(const double* __restrict_
             for (int u = 0; u < 8; ++u) { dv[u] = bd[t0 + u]; e2v[u] = be[t0 + u - 1]; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const double sc = step_scale(p1);
                 const double raw = fma(dv[u] - lam, p1, -e2v[u] * p0);
                 narr[t0 + u] = raw;
                 darr[t0 + u] = p1;
-                p0 = p1 * sc;
-                p1 = raw * sc;
+                if (u & 1) {
+                    const double sc = step_scale(p1);
+                    p0 = p1 * sc;
+                    p1 = raw * sc;
+                } else {
+                    p0 = p1;
+                    p1 = raw;
+                }
             }
         }
     }
@@ -3542,13 +3577,15 @@ __global__ __launch_bounds__(64 * WPB) void k_trieig_r(const double* __restrict_
                 }
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                double dot = 0;
+            for (int b = 0; b < 4; b += 2) {                      // reflectors k - b, then k - b - 1: one reduction round for both
+                double da = 0, db = 0;
 #pragma unroll
-                for (int q = 0; q < QMAX; ++q) dot += hv[b][q] * zq[q];
-                const double f = tk[b] * wave_sum_f64(dot);
+                for (int q = 0; q < QMAX; ++q) { da += hv[b][q] * zq[q]; db += hv[b + 1][q] * zq[q]; }
+                wave_sum2_f64(da, db);
+                const double fa = tk[b] * da;
+                const double fb = tk[b + 1] * (db - fa * sg[max(k - b, 0)]);   // v_b . (z - fa v_a) = db - fa (v_a . v_b)
 #pragma unroll
-                for (int q = 0; q < QMAX; ++q) zq[q] -= f * hv[b][q];
+                for (int q = 0; q < QMAX; ++q) zq[q] -= fa * hv[b][q] + fb * hv[b + 1][q];
             }
         }
         ktop = kbase - 1;
@@ -4832,12 +4869,13 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         const size_t lds_in = sizeof(double) * ((size_t)L * ldw + 2 * L + 32);
         const bool inlds = lds_in <= 160 * 1024 - 256;
         const bool regs = L <= 138;                               // (the padded working copy of k_tridiag_r fits the LDS)
-        const size_t bytes = sizeof(double) * (3 * L + L * L + (inlds ? 0 : L * ldw)) + 64;
+        const size_t bytes = sizeof(double) * (4 * L + L * L + (inlds ? 0 : L * ldw)) + 64;
         ts = (char*)dev_alloc(d, bytes);
         double* dd = reinterpret_cast<double*>(ts);
         double* ee = dd + L;
         double* tau = ee + L;
-        double* HV = tau + L;
+        double* gg = tau + L;
+        double* HV = gg + L;
         double* Wg = inlds ? nullptr : HV + L * L;
         flag = reinterpret_cast<int*>(ts + bytes - 64);
         if (regs) {
@@ -4845,7 +4883,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     do {                                                                                                                           \
         const size_t lds_r = sizeof(double) * ((size_t)L * tri_ld((int)L, ST) + 8 * TM + tri_sp_len(TM));                          \
         set_max_lds(d, reinterpret_cast<const void*>(k_tridiag_r<TM, ST>));                                                        \
-        hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, flag); \
+        hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag); \
     } while (0)
             if (L <= 80) PETAL_TRI_LAUNCH(10, 2);
             else if (L <= 132) PETAL_TRI_LAUNCH(18, 2);
@@ -4853,13 +4891,13 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
 #undef PETAL_TRI_LAUNCH
             launch_check();
             const int hv_rows = (int)std::min<int64_t>(L - 2, (96 * 1024) / (8 * L));
-            const size_t lds_e = sizeof(double) * (22 * (((L + 7) & ~7) + 8) + (size_t)hv_rows * L);
+            const size_t lds_e = sizeof(double) * (23 * (((L + 7) & ~7) + 8) + (size_t)hv_rows * L);
             if (L <= 128) {
                 set_max_lds(d, reinterpret_cast<const void*>(k_trieig_r<4, 2>));
-                hipLaunchKernelGGL((k_trieig_r<4, 2>), dim3(cdiv(L, 4)), dim3(256), lds_e, d->stream, dd, ee, HV, tau, (int)L, gap_tol, hv_rows, w, V, ldv, flag);
+                hipLaunchKernelGGL((k_trieig_r<4, 2>), dim3(cdiv(L, 4)), dim3(256), lds_e, d->stream, dd, ee, HV, tau, gg, (int)L, gap_tol, hv_rows, w, V, ldv, flag);
             } else {
                 set_max_lds(d, reinterpret_cast<const void*>(k_trieig_r<4, 3>));
-                hipLaunchKernelGGL((k_trieig_r<4, 3>), dim3(cdiv(L, 4)), dim3(256), lds_e, d->stream, dd, ee, HV, tau, (int)L, gap_tol, hv_rows, w, V, ldv, flag);
+                hipLaunchKernelGGL((k_trieig_r<4, 3>), dim3(cdiv(L, 4)), dim3(256), lds_e, d->stream, dd, ee, HV, tau, gg, (int)L, gap_tol, hv_rows, w, V, ldv, flag);
             }
             launch_check();
         } else {
