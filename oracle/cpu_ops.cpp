@@ -202,7 +202,7 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
         }
     }
 }
-void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel) {
+void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool /*clustered*/) {
     for (int64_t i = 0; i < L; ++i)
         for (int64_t j = 0; j < L; ++j) V[i * ldv + j] = (i == j);
     for (int sweep = 0; sweep < 60; ++sweep) {

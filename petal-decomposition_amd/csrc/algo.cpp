@@ -215,7 +215,7 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
         op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, Q.f64(), p, 0.0, Y.f64(), p);  // Y = C Q
         if (it % 2 == 1) {  // Rayleigh-Ritz + residual check every second product (never converged after the first)
             op_dgemm(dv, true, false, p, p, dp, 1.0, Q.f64(), p, Y.f64(), p, 0.0, H.f64(), p);  // Rayleigh quotient
-            op_eigh(dv, H.f64(), p, p, S.f64(), p, th.f64());
+            op_eigh(dv, H.f64(), p, p, S.f64(), p, th.f64(), 1e-15, true);  // Ritz values: the unconverged tail is a cluster
             op_dgemm(dv, false, false, dp, p, p, 1.0, Q.f64(), p, S.f64(), p, 0.0, QS.f64(), p);  // Ritz vectors
             op_dgemm(dv, false, false, dp, p, p, 1.0, Y.f64(), p, S.f64(), p, 0.0, R.f64(), p);   // C (Q S)
             DBuf QST(dv, QS.bytes);                                                               // (Q S) diag(theta)

@@ -4853,7 +4853,7 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_mode, ndead, (int)Lz);
     launch_check();
 }
-void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel) {
+void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool clustered) {
     if (L == 0) return;
     if (L > EIG_MAXL) throw std::runtime_error("eigh: matrix too large for the one-workgroup Jacobi solver");
     // Two-stage solver first (tridiagonalisation on one workgroup, then one wave per eigenpair over the chip); the Jacobi
@@ -4861,7 +4861,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     static const bool jacobi_only = getenv("PETAL_EIGH_JACOBI") != nullptr;
     int* flag = nullptr;
     char* ts = nullptr;
-    if (!jacobi_only && L >= 3 && L <= 2048) {
+    if (!jacobi_only && !clustered && L >= 3 && L <= 2048) {
         // eigenvectors of eigenvalues closer than gap_tol ||A|| come out only eps / gap_tol accurate: fp32 results carry
         // 2e-8, fp64 results 2e-11; anything closer goes to Jacobi
         const double gap_tol = tol_rel >= 1e-9 ? 1e-8 : 1e-5;

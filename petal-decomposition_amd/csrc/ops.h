@@ -130,7 +130,10 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
 // tol_rel: off-diagonal elements are annihilated down to |a_pq| <= tol_rel sqrt(a_pp a_qq) (graded matrices keep the
 // relative accuracy of their small eigenvalues) or to the 1e-16 ||diag|| rounding floor; 1e-15 for fp64 data, 1e-8 is
 // ample when the matrix was formed from fp32 data.
-void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel = 1e-15);
+// clustered = true: the caller expects eigenvalues closer than the two-stage solver's gap tolerance (the Ritz values of a
+// subspace iteration: a block of noise-level eigenvalues) -- go to the Jacobi solver directly instead of paying for both
+void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel = 1e-15,
+             bool clustered = false);
 // x[i] *= alpha
 void op_dscal(Dev*, double* x, int64_t count, double alpha);
 // y[i] += alpha * x[i]
