@@ -2,6 +2,7 @@
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPETAL_DEBUG_COUNTERS -o micro_small dev/micro_small.hip
 #include "../petal-decomposition_amd/csrc/hip_ops.hip"
 #include <random>
+#include <cstring>
 using namespace petal;
 int main(int argc, char** argv) {
     int L = argc > 1 ? atoi(argv[1]) : 80;
@@ -16,6 +17,15 @@ int main(int argc, char** argv) {
     // graded columns (sigma ratio 1e3)
     for (int i = 0; i < M; ++i) for (int j = 0; j < L; ++j) B[i * L + j] *= pow(10.0, -3.0 * j / L);
     for (int i = 0; i < L; ++i) for (int j = 0; j < L; ++j) { double s = 0; for (int k = 0; k < M; ++k) s += B[k * L + i] * B[k * L + j]; S[i * L + j] = s; }
+    if (const char* mk = getenv("MATRIX")) {   // special matrices for the eigen-solver: diag, ident, blocks (two decoupled halves), arrow
+        for (auto& v : S) v = 0;
+        for (int i = 0; i < L; ++i) {
+            if (!strcmp(mk, "diag")) S[i * L + i] = 1.0 + i;
+            else if (!strcmp(mk, "ident")) S[i * L + i] = 1.0;
+            else if (!strcmp(mk, "blocks")) { S[i * L + i] = 2.0 + 0.37 * i; int j = i + 1; if (j < L && j != L / 2) S[i * L + j] = S[j * L + i] = 0.5; }
+            else if (!strcmp(mk, "arrow")) { S[i * L + i] = 1.0 + i; S[i] = S[i * L] = i ? 0.3 : 1.0; }
+        }
+    }
     double *dS = (double*)dev_alloc(d, 8 * L * L), *dA = (double*)dev_alloc(d, 8 * L * L), *dV = (double*)dev_alloc(d, 8 * L * L), *dw = (double*)dev_alloc(d, 8 * L), *dT = (double*)dev_alloc(d, 8 * L * L);
     dev_h2d(d, dS, S.data(), 8 * L * L);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -37,7 +47,10 @@ int main(int argc, char** argv) {
     dev_d2h(d, w.data(), dw, 8 * L); dev_d2h(d, V.data(), dV, 8 * L * L); dev_sync(d);
     double maxres = 0;
     for (int j = 0; j < L; ++j) for (int i = 0; i < L; ++i) { double s = 0; for (int k = 0; k < L; ++k) s += S[i * L + k] * V[k * L + j]; maxres = fmax(maxres, fabs(s - w[j] * V[i * L + j])); }
-    printf("eig residual max |S v - w v| = %.3e (w0 = %.3e, wlast = %.3e)\n", maxres, w[0], w[L - 1]);
+    if (L <= 8) { for (int j = 0; j < L; ++j) { printf("w[%d] = %.6f  v =", j, w[j]); for (int i = 0; i < L; ++i) printf(" %9.2e", V[i * L + j]); printf("\n"); } }
+    double maxorth = 0;
+    for (int a = 0; a < L; ++a) for (int b = a; b < L; ++b) { double s = 0; for (int k = 0; k < L; ++k) s += V[k * L + a] * V[k * L + b]; maxorth = fmax(maxorth, fabs(s - (a == b))); }
+    printf("eig residual max |S v - w v| = %.3e, max |V^T V - I| = %.3e (w0 = %.3e, wlast = %.3e)\n", maxres, maxorth, w[0], w[L - 1]);
     op_chol_inv(d, dS, L, L, dT, L, 1e-13); dev_d2h(d, T.data(), dT, 8 * L * L); dev_sync(d);
     double maxo = 0;  // T^T S T = I
     for (int i = 0; i < L; ++i) for (int j = 0; j < L; ++j) { double s = 0; for (int a = 0; a < L; ++a) for (int b = 0; b < L; ++b) s += T[a * L + i] * S[a * L + b] * T[b * L + j]; maxo = fmax(maxo, fabs(s - (i == j))); }

@@ -3090,7 +3090,7 @@ __global__ __launch_bounds__(64 * WPB) void k_trieig(const double* __restrict__ 
 }
 // verdict of the two-stage route, read by the Jacobi kernels launched behind it: flag = 1 (run Jacobi) when some eigenvalue
 // is not finite or two neighbours are closer than 1e-10 of the largest magnitude (their vectors need not be orthogonal)
-__global__ void k_trieig_verdict(const double* __restrict__ w, int L, double gap_tol, int* __restrict__ flag) {
+__global__ void k_trieig_verdict(const double* __restrict__ w, const double* __restrict__ ee, int L, double gap_tol, int* __restrict__ flag) {
     __shared__ int bad;
     if (threadIdx.x == 0) bad = 0;
     __syncthreads();
@@ -3098,7 +3098,7 @@ __global__ void k_trieig_verdict(const double* __restrict__ w, int L, double gap
     for (int j = threadIdx.x; j < L; j += blockDim.x) {
         const double a = w[j];
         bool b = !(fabs(a) < 1e300);
-        if (j + 1 < L) b = b || !(a - w[j + 1] > gap_tol * scale);
+        if (j + 1 < L) b = b || !(a - w[j + 1] > gap_tol * scale) || !(fabs(ee[j]) > 1e-14 * scale);   // (or the matrix decouples)
         if (b) bad = 1;
     }
     __syncthreads();
@@ -3377,6 +3377,9 @@ __global__ __launch_bounds__(64 * WPB) void k_trieig_r(const double* __restrict_
         sd[i] = i < L ? dd[i] * inv : 4.0;                        // padding: d - x > 0 and e = 0 there, no sign change is added
         se[i] = ev;
         s2[i] = fmax(ev * ev, 1e-280);                            // never an exact split: the minors cannot stick at zero
+        // a (numerically) decoupled matrix: the twisted factorisation's choice of r compares pivots that the 1e-30 clamp has
+        // flattened (an exactly diagonal A with lambda hit to the last bit picked a neighbour's unit vector) -- Jacobi's case
+        if (i + 1 < L && !(fabs(ev) > 1e-14)) atomicOr(flag, 1);
         st[i] = i < L ? tau[i] : 0.0;
         sg[i] = i < L ? gg[i] : 0.0;
         const int ir = L - 1 - i;                                 // reversed: sdr[t] = d_{L-1-t}, s2r[u] = e^2_{L-2-u}
@@ -4915,7 +4918,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
                 hipLaunchKernelGGL(k_trieig<1>, dim3((unsigned)L), dim3(64), sizeof(double) * 6 * L, d->stream, dd, ee, HV, tau, (int)L, w, V, ldv);
             }
             launch_check();
-            hipLaunchKernelGGL(k_trieig_verdict, dim3(1), dim3(256), 0, d->stream, w, (int)L, gap_tol, flag);
+            hipLaunchKernelGGL(k_trieig_verdict, dim3(1), dim3(256), 0, d->stream, w, ee, (int)L, gap_tol, flag);
             launch_check();
         }
     }

@@ -118,3 +118,21 @@ def test_eigh_two_stage_and_jacobi_agree(ctx):
     sign = np.sign(np.sum(c2 * cj, axis=1))
     # neighbours are 6 % apart: both routes resolve every vector; fp32 outputs
     assert np.abs(c2 - sign[:, None] * cj).max() <= 5e-5
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("d", [5, 74, 138, 150])
+def test_eigh_exactly_diagonal_covariance(ctx, d, dtype):
+    """X = [D; -D] has mean zero and the exactly diagonal covariance 2 D^2 with integer eigenvalues: the tridiagonal form
+    decouples completely and the multisection can hit an eigenvalue to the last bit -- the twisted factorisation then
+    compares pivots it has clamped (it once returned a neighbour's unit vector); the solver must notice and hand over."""
+    import petal_decomposition_amd as petal
+    dg = np.diag(np.arange(1, d + 1, dtype=np.float64))
+    x = np.ascontiguousarray(np.vstack([dg, -dg]).astype(dtype))
+    m = petal.Pca(d, ctx=ctx)
+    m.fit(x)
+    c = np.abs(np.asarray(m.components()).astype(np.float64))
+    sg = np.asarray(m.singular_values()).astype(np.float64)
+    assert np.allclose(sg, np.sqrt(2.0) * np.arange(d, 0, -1), rtol=1e-6 if dtype == np.float32 else 1e-13)
+    assert np.array_equal(c.argmax(axis=1), np.arange(d - 1, -1, -1))      # component j is the unit vector of feature d - 1 - j
+    assert np.abs(c - np.eye(d)[::-1]).max() <= (1e-6 if dtype == np.float32 else 1e-12)
