@@ -1196,8 +1196,13 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
     __shared__ bf16x8 sB[2][NT * 192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int m0 = (blockIdx.x * WV + wave) * 64;
-    const int64_t rbeg = (int64_t)blockIdx.y * chunk, rend = min(n, rbeg + chunk);
+    // XCD-aware launch: grid = (8 hx, ceil(nsplit / 8)) with hx = column groups.  Workgroups are dealt to the 8 XCDs round-robin
+    // by linear id, so the hx groups of ONE row chunk (blockIdx.x = s, s + 8, ...) share an XCD and its L2: the chunk's Z stage
+    // is fetched once, not once per column group.
+    const int bx = blockIdx.x >> 3, by = blockIdx.y * 8 + (blockIdx.x & 7);
+    if ((int64_t)by * chunk >= n) return;   // (the last group of eight may be short; uniform per workgroup)
+    const int m0 = (bx * WV + wave) * 64;
+    const int64_t rbeg = (int64_t)by * chunk, rend = min(n, rbeg + chunk);
     const int nstage = (int)((rend - rbeg) >> 5);
     // uniform row bases (advance 32 rows per stage) + ONE 32-bit per-lane offset each: no per-load address arithmetic
     const float* abase = A + rbeg * lda;
@@ -1292,7 +1297,7 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
         }
     }
     // D[row = 4 q + r][col = i] of tile (t, u):  m = m0 + 4 (4 q + r) + t,  col = n0col + 16 u + i
-    float* out = part + (int64_t)blockIdx.y * M * Npart;
+    float* out = part + (int64_t)by * M * Npart;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -4472,7 +4477,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         if (split3_mode) {
             // 8-wave workgroups (one B stage per 512 columns of A) where the row split already puts two waves on every SIMD
             const bool wv8 = M >= 512 && nsplit * mslices >= (int64_t)num_cu2 * 8;
-            const dim3 grid(cdiv(M, wv8 ? 512 : 256), (unsigned)nsplit), block(wv8 ? 512 : 256);
+            const dim3 grid(8 * cdiv(M, wv8 ? 512 : 256), (unsigned)cdiv(nsplit, 8)), block(wv8 ? 512 : 256);
 #define ATB3_LAUNCH(NTv)                                                                                                              \
             do {                                                                                                                      \
                 if (ma && wv8) hipLaunchKernelGGL((k_atb3<NTv, true, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
