@@ -1040,9 +1040,12 @@ __global__ __launch_bounds__(256, 2) void k_atb_mfma(const float* __restrict__ A
     constexpr int UN = 4;  // k-steps (of 4 rows) per pipeline stage: 16 rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int m0 = (blockIdx.x * 4 + wave) * 64;
+    // XCD-aware launch (see k_atb3): grid = (8 hx, ceil(nsplit / 8)); the column groups of one row chunk share an XCD
+    const int bx = blockIdx.x >> 3, by = blockIdx.y * 8 + (blockIdx.x & 7);
+    if ((int64_t)by * chunk >= n) return;
+    const int m0 = (bx * 4 + wave) * 64;
     if (m0 >= M) return;
-    const int64_t rbeg = (int64_t)blockIdx.y * chunk, rend = min(n, rbeg + chunk);
+    const int64_t rbeg = (int64_t)by * chunk, rend = min(n, rbeg + chunk);
     // Columns beyond M / N are never stored, so their loads are simply clamped into the row (any finite value
     // will do); rows beyond rend must contribute nothing: only the ragged tail stage masks them (B := 0).
     const float* ap = A + min(m0 + 4 * i, M - 4);
@@ -1154,7 +1157,7 @@ __global__ __launch_bounds__(256, 2) void k_atb_mfma(const float* __restrict__ A
         }
     }
     // D[row = 4 q + r][col = i] of tile (t, u):  m = m0 + 4 (4 q + r) + t;  col from the B grouping
-    float* out = part + (int64_t)blockIdx.y * M * Npart;
+    float* out = part + (int64_t)by * M * Npart;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -4366,7 +4369,7 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
 template <int NT>
 static void launch_atb(Dev* d, const float* A, int64_t lda, int M, const float* muA, const float* B, int64_t ldb, int N,
                        int n0col, const float* muB, int64_t n, int64_t chunk, float* part, int nsplit) {
-    const dim3 grid(cdiv(M, 256), nsplit), block(256);
+    const dim3 grid(8 * cdiv(M, 256), cdiv(nsplit, 8)), block(256);
 #define ATB_ARGS A, lda, M, muA, B, ldb, N, n0col, muB, n, chunk, part, N
     if (muA && muB) hipLaunchKernelGGL((k_atb_mfma<NT, true, true>), grid, block, 0, d->stream, ATB_ARGS);
     else if (muA) hipLaunchKernelGGL((k_atb_mfma<NT, true, false>), grid, block, 0, d->stream, ATB_ARGS);
