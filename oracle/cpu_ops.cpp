@@ -202,7 +202,10 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
         }
     }
 }
-void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool /*clustered*/) {
+void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool /*clustered*/, int64_t Lz) {
+    for (int64_t r = 0; r < Lz; ++r)
+        for (int64_t c = 0; c < Lz; ++c)
+            if (r >= L || c >= L) V[r * ldv + c] = 0.0;
     for (int64_t i = 0; i < L; ++i)
         for (int64_t j = 0; j < L; ++j) V[i * ldv + j] = (i == j);
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -271,7 +274,9 @@ void op_dscale_cols(Dev*, double* A, int64_t M, int64_t N, int64_t lda, const do
 void op_cvt_from_f64(Dev*, int dt, void* dst, const double* src, int64_t count) {
     for (int64_t i = 0; i < count; ++i) st(dst, dt, i, src[i]);
 }
-void op_pad_to_f64(Dev*, int dt, double* dst, int64_t rows_p, int64_t cols_p, const void* src, int64_t rows, int64_t cols, int64_t lds) {
+void op_pad_to_f64(Dev*, int dt, double* dst, int64_t rows_p, int64_t cols_p, const void* src, int64_t rows, int64_t cols, int64_t lds,
+                   double* zero_ptr, int64_t zero_count) {
+    for (int64_t i = 0; i < zero_count; ++i) zero_ptr[i] = 0.0;
     for (int64_t r = 0; r < rows_p; ++r)
         for (int64_t c = 0; c < cols_p; ++c) dst[r * cols_p + c] = (r < rows && c < cols) ? ld(src, dt, r * lds + c) : 0.0;
 }

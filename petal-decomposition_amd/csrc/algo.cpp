@@ -388,7 +388,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     {
         DBuf raw(c.dev, esz * size_t(d) * l_req);
         dev_h2d_async(c.dev, raw.p, omega, raw.bytes);
-        op_pad_to_f64(c.dev, dt, P.f64(), dp, LP, raw.p, d, L, l_req);
+        op_pad_to_f64(c.dev, dt, P.f64(), dp, LP, raw.p, d, L, l_req, tvp, 2 + LP);  // (also clears tv, ndead, lam for the first pipeline run)
     }
     replicate_from_rank0(c, P.f64(), dp * LP);
     DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
@@ -405,7 +405,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // the single-Cholesky fast path and no host round trip; the kernels record the worst pivot breakdown in `ndead`,
     // which is read together with the results.  Only if a breakdown happened is the fit redone with robust = true.
     auto pipeline = [&](bool robust) {
-    dev_memset(c.dev, tvp, 0, sizeof(double) * (2 + LP));  // tv, ndead, lam (only lam[0 .. L) is written below)
+    if (robust) dev_memset(c.dev, tvp, 0, sizeof(double) * (2 + LP));  // tv, ndead, lam (only lam[0 .. L) is written below); the first run's were cleared with Omega
     // Z = Xc . Omega (pca.rs:707); total_variance = sum Xc^2 (pca.rs:533) is fused into this product unless tv_from_sq
     dev_set_tag(c.dev, TAG_XP);
     op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv_from_sq ? nullptr : tvp);
@@ -483,8 +483,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // economy SVD of B (l x d) (svddc, pca.rs:682): eigen-decomposition of B B^T in fp64
     op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Bt.f64(), LP, Bt.f64(), LP, 0.0, S.f64(), LP);
     // only the leading L x L block of S is non-zero (columns L..LP-1 of every iterate are exact zero padding)
-    dev_memset(c.dev, Uh.p, 0, Uh.bytes);
-    op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15);
+    op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, false, LP);  // (zero padding of Uh included)
     op_sigma_inv(c.dev, lam, sig, inv.f64(), LP, dt == F32 ? 1e-7 : 1e-12);
     // V[:, j] = B^T u_j / sigma_j
     op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Bt.f64(), LP, Uh.f64(), LP, 0.0, V, LP, inv.f64());

@@ -3279,10 +3279,14 @@ template <int TMAX, int STEP>  // L <= 8 TMAX; PAD = 8 STEP zero columns
 __global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restrict__ A, int L, int64_t lda, double* __restrict__ dd,
                                                            double* __restrict__ ee, double* __restrict__ HV,
                                                            double* __restrict__ tau, double* __restrict__ gg,
-                                                           int* __restrict__ flag) {
+                                                           int* __restrict__ flag, double* __restrict__ V, int64_t ldv, int Lz) {
     extern __shared__ __attribute__((aligned(16))) double sm_tri[];
     const int tid = threadIdx.x;
     const int ld = tri_ld(L, STEP);
+    for (int e = tid; e < Lz * Lz; e += TRR_THREADS) {           // the caller's zero padding of V (rows / columns L .. Lz - 1)
+        const int r = e / Lz, c = e - r * Lz;
+        if (r >= L || c >= L) V[(int64_t)r * ldv + c] = 0.0;
+    }
     double* W = sm_tri;
     double* sv = W + (size_t)L * ld;                              // 8 TMAX entries
     double* sp = sv + 8 * TMAX;                                   // tri_sp_len(TMAX) entries
@@ -4022,8 +4026,9 @@ __global__ void k_cvt_from_f64(T* dst, const double* src, int64_t count) {
 // dst (rows_p x cols_p fp64, zero padded) <- the leading rows x cols block of src (row-major, leading dimension lds)
 template <class T>
 __global__ void k_pad_to_f64(double* __restrict__ dst, int64_t rows_p, int64_t cols_p, const T* __restrict__ src, int64_t rows,
-                             int64_t cols, int64_t lds) {
+                             int64_t cols, int64_t lds, double* __restrict__ zero_ptr, int64_t zero_count) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e < zero_count) zero_ptr[e] = 0.0;
     if (e >= rows_p * cols_p) return;
     const int64_t r = e / cols_p, c = e - r * cols_p;
     dst[e] = (r < rows && c < cols) ? (double)src[r * lds + c] : 0.0;
@@ -4864,15 +4869,19 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_mode, ndead, (int)Lz);
     launch_check();
 }
-void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool clustered) {
+void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool clustered, int64_t Lz) {
     if (L == 0) return;
+    const bool pad_done = Lz <= L;   // else: rows / columns L .. Lz - 1 of V are to be zeroed here
     if (L > EIG_MAXL) throw std::runtime_error("eigh: matrix too large for the one-workgroup Jacobi solver");
     // Two-stage solver first (tridiagonalisation on one workgroup, then one wave per eigenpair over the chip); the Jacobi
     // launches below run behind it and return at once unless its verdict flags eigenvalues too close for its vectors.
     static const bool jacobi_only = getenv("PETAL_EIGH_JACOBI") != nullptr;
     int* flag = nullptr;
     char* ts = nullptr;
-    if (!jacobi_only && !clustered && L >= 3 && L <= 2048) {
+    const bool two_stage = !jacobi_only && !clustered && L >= 3 && L <= 2048;
+    // k_tridiag_r (orders up to 138) writes the padding itself; every other route gets one 2-D clear of the Lz x Lz frame first
+    if (!pad_done && !(two_stage && L <= 138)) HIP_CHECK(hipMemset2DAsync(V, sizeof(double) * ldv, 0, sizeof(double) * Lz, Lz, d->stream));
+    if (two_stage) {
         // eigenvectors of eigenvalues closer than gap_tol ||A|| come out only eps / gap_tol accurate: fp32 results carry
         // 2e-8, fp64 results 2e-11; anything closer goes to Jacobi
         const double gap_tol = tol_rel >= 1e-9 ? 1e-8 : 1e-5;
@@ -4894,7 +4903,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     do {                                                                                                                           \
         const size_t lds_r = sizeof(double) * ((size_t)L * tri_ld((int)L, ST) + 8 * TM + tri_sp_len(TM));                          \
         set_max_lds(d, reinterpret_cast<const void*>(k_tridiag_r<TM, ST>));                                                        \
-        hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag); \
+        hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag, V, ldv, (int)(pad_done ? 0 : Lz)); \
     } while (0)
             if (L <= 80) PETAL_TRI_LAUNCH(10, 2);
             else if (L <= 132) PETAL_TRI_LAUNCH(18, 2);
@@ -5002,10 +5011,11 @@ void op_cvt_from_f64(Dev* d, int dt, void* dst, const double* src, int64_t count
     DISPATCH_T(dt, hipLaunchKernelGGL(k_cvt_from_f64<T>, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, (T*)dst, src, count));
     launch_check();
 }
-void op_pad_to_f64(Dev* d, int dt, double* dst, int64_t rows_p, int64_t cols_p, const void* src, int64_t rows, int64_t cols, int64_t lds) {
-    if (rows_p * cols_p == 0) return;
-    DISPATCH_T(dt, hipLaunchKernelGGL(k_pad_to_f64<T>, dim3(cdiv(rows_p * cols_p, 256)), dim3(256), 0, d->stream, dst, rows_p, cols_p,
-                                      (const T*)src, rows, cols, lds));
+void op_pad_to_f64(Dev* d, int dt, double* dst, int64_t rows_p, int64_t cols_p, const void* src, int64_t rows, int64_t cols, int64_t lds,
+                   double* zero_ptr, int64_t zero_count) {
+    if (rows_p * cols_p == 0 && zero_count == 0) return;
+    DISPATCH_T(dt, hipLaunchKernelGGL(k_pad_to_f64<T>, dim3(cdiv(std::max(rows_p * cols_p, zero_count), 256)), dim3(256), 0, d->stream, dst,
+                                      rows_p, cols_p, (const T*)src, rows, cols, lds, zero_ptr, zero_count));
     launch_check();
 }
 void op_cvt_to_f64(Dev* d, int dt, double* dst, const void* src, int64_t count) {

@@ -132,8 +132,10 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
 // ample when the matrix was formed from fp32 data.
 // clustered = true: the caller expects eigenvalues closer than the two-stage solver's gap tolerance (the Ritz values of a
 // subspace iteration: a block of noise-level eigenvalues) -- go to the Jacobi solver directly instead of paying for both
+// Lz > L: V is an Lz x Lz matrix (leading dimension ldv) whose rows / columns L .. Lz - 1 must come out zero (padding for the
+// GEMM kernels); the solver's first kernel writes those zeros itself, which saves the caller a memset launch.
 void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel = 1e-15,
-             bool clustered = false);
+             bool clustered = false, int64_t Lz = 0);
 // x[i] *= alpha
 void op_dscal(Dev*, double* x, int64_t count, double alpha);
 // y[i] += alpha * x[i]
@@ -145,6 +147,8 @@ void op_dscale_cols(Dev*, double* A, int64_t M, int64_t N, int64_t lda, const do
 void op_cvt_from_f64(Dev*, int dtype, void* dst, const double* src, int64_t count);
 void op_cvt_to_f64(Dev*, int dtype, double* dst, const void* src, int64_t count);
 // dst (rows_p x cols_p fp64, zero padded) <- the leading rows x cols block of the row-major device matrix src (ld lds)
-void op_pad_to_f64(Dev*, int dtype, double* dst, int64_t rows_p, int64_t cols_p, const void* src, int64_t rows, int64_t cols, int64_t lds);
+// (zero_ptr, zero_count: a small fp64 range the same launch clears -- the caller's accumulators -- instead of a memset of its own)
+void op_pad_to_f64(Dev*, int dtype, double* dst, int64_t rows_p, int64_t cols_p, const void* src, int64_t rows, int64_t cols, int64_t lds,
+                   double* zero_ptr = nullptr, int64_t zero_count = 0);
 
 }  // namespace petal
