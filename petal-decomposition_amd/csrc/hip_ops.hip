@@ -4260,24 +4260,33 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         }
         launch_check();
         constexpr int RTv = PETAL_XP3_RT, DPv = PETAL_XP3_DEPTH;
-        const int blocks = cdiv(n, 64 * RTv);
         const float* Xf = (const float*)X; const float* muf = (const float*)mu; const float* bf = (const float*)bias; float* Zf = (float*)Z;
         TagScope ts(d);
-        for (int nt0 = 0; nt0 < NTtot;) {
-            const int rem = NTtot - nt0;
-            const int w = rem >= 5 ? 5 : rem;
+        // Column panels: as few passes over X as 9-tile panels allow, the tiles spread evenly over them.  A panel of <= 5 tiles
+        // runs on 64-row wave tiles (RT = 4), one of 6 .. 9 tiles on 32-row wave tiles (RT = 2: 72 accumulator registers at 9
+        // tiles, still two waves per SIMD) -- every pass reads and splits X again, so l = 138 in one 9-tile pass instead of
+        // 5 + 4 takes 0.49 instead of 0.55 ms at 250000 x 1024 (a one-wave-per-SIMD 64-row form of it had measured slower).
+        const int npass = cdiv(NTtot, 9);
+        for (int nt0 = 0, pass = 0; nt0 < NTtot; ++pass) {
+            const int w = (NTtot - nt0 + (npass - pass) - 1) / (npass - pass);
             const size_t lds = sizeof(bf16x8) * 2 * w * 192 + sizeof(float) * 32 * nch;
-#define XP3_LAUNCH(NTv)                                                                                                                     \
+#define XP3_LAUNCH(RTw, NTv)                                                                                                               \
             do {                                                                                                                            \
-                if (muf) hipLaunchKernelGGL((k_xp3<RTv, NTv, DPv, true>), dim3(blocks), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
-                else hipLaunchKernelGGL((k_xp3<RTv, NTv, DPv, false>), dim3(blocks), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
+                const int blocksw = cdiv(n, 64 * RTw);                                                                                      \
+                if (lds > 64 * 1024) set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp3<RTw, NTv, DPv, true>) : reinterpret_cast<const void*>(k_xp3<RTw, NTv, DPv, false>)); \
+                if (muf) hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, true>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
+                else hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, false>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
             } while (0)
             switch (w) {
-                case 5: XP3_LAUNCH(5); break;
-                case 4: XP3_LAUNCH(4); break;
-                case 3: XP3_LAUNCH(3); break;
-                case 2: XP3_LAUNCH(2); break;
-                default: XP3_LAUNCH(1); break;
+                case 9: XP3_LAUNCH(2, 9); break;
+                case 8: XP3_LAUNCH(2, 8); break;
+                case 7: XP3_LAUNCH(2, 7); break;
+                case 6: XP3_LAUNCH(2, 6); break;
+                case 5: XP3_LAUNCH(RTv, 5); break;
+                case 4: XP3_LAUNCH(RTv, 4); break;
+                case 3: XP3_LAUNCH(RTv, 3); break;
+                case 2: XP3_LAUNCH(RTv, 2); break;
+                default: XP3_LAUNCH(RTv, 1); break;
             }
 #undef XP3_LAUNCH
             launch_check();
