@@ -1190,12 +1190,13 @@ __global__ __launch_bounds__(256, 2) void k_atb_mfma(const float* __restrict__ A
 // 32-row stage of B, which is read from memory and converted ONCE per workgroup: with 4-wave workgroups a 512-column A
 // makes two workgroups per row chunk read and convert the same stage (K2's PMC traffic was 1.16-1.23x algorithmic, most
 // of it this); 8-wave workgroups cover 512 columns with one.
-template <int NT, bool CA, int WV>
+template <int NT, bool CA, int WV, int MT = 4>  // MT = column tiles of A per wave (4: 64 columns, 16-B loads; 2: 32 columns, 8-B loads)
 __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
                                                      const float* __restrict__ B, int64_t ldb, int N, int n0col, int64_t n,
                                                      int64_t chunk, float* __restrict__ part, int Npart) {
     constexpr int BITEMS = NT * 64;                       // operand items of one B stage (8 elements each)
-    constexpr bool Z2 = BITEMS > 64 * WV;                 // wave 0 carries a second item when NT = 5 and there are 4 waves
+    constexpr bool Z2 = BITEMS > 64 * WV;                 // the first NT - WV waves carry a second item (tile WV + wave)
+    typedef float fvecm __attribute__((ext_vector_type(MT)));
     __shared__ bf16x8 sB[2][NT * 192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -1204,30 +1205,30 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
     // is fetched once, not once per column group.
     const int bx = blockIdx.x >> 3, by = blockIdx.y * 8 + (blockIdx.x & 7);
     if ((int64_t)by * chunk >= n) return;   // (the last group of eight may be short; uniform per workgroup)
-    const int m0 = (bx * WV + wave) * 64;
+    const int m0 = (bx * WV + wave) * (16 * MT);
     const int64_t rbeg = (int64_t)by * chunk, rend = min(n, rbeg + chunk);
     const int nstage = (int)((rend - rbeg) >> 5);
     // uniform row bases (advance 32 rows per stage) + ONE 32-bit per-lane offset each: no per-load address arithmetic
     const float* abase = A + rbeg * lda;
     const float* zbase = B + rbeg * ldb;
-    const unsigned aoff = (unsigned)((int64_t)(8 * q) * lda + min(m0 + 4 * i, M - 4));  // columns beyond M are never stored
-    const int zcol0 = n0col + 16 * (tid >> 6) + i, zcol1 = n0col + 64 + 16 * (tid >> 6) + i;  // items tid and 256 + tid
-    const bool zon0 = (tid >> 6) < NT && zcol0 < N, zon1 = Z2 && wave == 0 && (n0col + 64 + i) < N;
+    const unsigned aoff = (unsigned)((int64_t)(8 * q) * lda + min(m0 + MT * i, M - MT));  // columns beyond M are never stored
+    const int zcol0 = n0col + 16 * wave + i, zcol1 = n0col + 16 * (WV + wave) + i;  // items tid and 64 WV + tid
+    const bool z2w = Z2 && WV + wave < NT;                // this wave converts a second item
+    const bool zon0 = wave < NT && zcol0 < N, zon1 = z2w && zcol1 < N;
     const unsigned zoff0 = (unsigned)((int64_t)(8 * q) * ldb + min(zcol0, N - 1));
-    const unsigned zoff1 = (unsigned)((int64_t)(8 * q) * ldb + min(n0col + 64 + i, N - 1));
-    (void)zcol1;
-    f32x4 ma = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (CA) ma = *reinterpret_cast<const f32x4*>(muA + min(m0 + 4 * i, M - 4));
-    f32x4 acc[4][NT];
+    const unsigned zoff1 = (unsigned)((int64_t)(8 * q) * ldb + min(zcol1, N - 1));
+    fvecm ma = fvecm(0.f);
+    if (CA) ma = *reinterpret_cast<const fvecm*>(muA + min(m0 + MT * i, M - MT));
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     // every chunk is a whole number of 32-row stages (the host hands the < 32 ragged rows of the matrix to the fp32 kernel)
-    auto load_a = [&](int st, f32x4(&av)[8]) {
+    auto load_a = [&](int st, fvecm(&av)[8]) {
         const float* p = abase + (int64_t)st * 32 * lda;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) av[e] = ld_stream(p + (int64_t)e * lda + aoff);
+        for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const fvecm*>(p + (int64_t)e * lda + aoff);
     };
     auto load_z1 = [&](int st, f32x8& zr, bool on, unsigned zoff) {
         const float* p = zbase + (int64_t)st * 32 * ldb;
@@ -1243,32 +1244,32 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
         sB[buf][(u * 3 + 1) * 64 + lane] = m;
         sB[buf][(u * 3 + 2) * 64 + lane] = l;
     };
-    f32x4 av[8];
+    fvecm av[8];
     f32x8 zr0, zr1 = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
     if (nstage > 0) {
         if (wave < NT) load_z1(0, zr0, zon0, zoff0);
-        if (Z2 && wave == 0) load_z1(0, zr1, zon1, zoff1);
+        if (z2w) load_z1(0, zr1, zon1, zoff1);
         load_a(0, av);
         if (wave < NT) stage_z1(0, zr0, wave, zon0);
-        if (Z2 && wave == 0) stage_z1(0, zr1, 4, zon1);
+        if (z2w) stage_z1(0, zr1, WV + wave, zon1);
     }
     for (int st = 0; st < nstage; ++st) {
         const int buf = st & 1;
         __syncthreads();  // stage st of B is in sB[buf]; nobody still reads sB[buf ^ 1]
-        bf16x8 ah[4], am[4], al[4];
+        bf16x8 ah[MT], am[MT], al[MT];
         if (CA) {  // centred in place (a centred COPY would keep 32 more registers alive across the four splits)
 #pragma unroll
             for (int e = 0; e < 8; ++e) av[e] -= ma;
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < MT; ++t) {
             const f32x8 x = f32x8{av[0][t], av[1][t], av[2][t], av[3][t], av[4][t], av[5][t], av[6][t], av[7][t]};
             split3(x, ah[t], am[t], al[t]);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (st + 1 < nstage) {  // fly under this stage's MFMAs; B first (vmcnt retires in order, see k_xp3)
             if (wave < NT) load_z1(st + 1, zr0, zon0, zoff0);
-            if (Z2 && wave == 0) load_z1(st + 1, zr1, zon1, zoff1);
+            if (z2w) load_z1(st + 1, zr1, zon1, zoff1);
             load_a(st + 1, av);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1280,7 +1281,7 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
             if (u + 1 < NT) { nh = sB[buf][(u * 3 + 3) * 64 + lane]; nm = sB[buf][(u * 3 + 4) * 64 + lane]; nl = sB[buf][(u * 3 + 5) * 64 + lane]; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < MT; ++t) {
                 f32x4 c4 = acc[t][u];
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bh, c4, 0, 0, 0);   // smallest terms first
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bm, c4, 0, 0, 0);
@@ -1296,16 +1297,16 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
         __builtin_amdgcn_sched_barrier(0);
         if (st + 1 < nstage) {
             if (wave < NT) stage_z1(buf ^ 1, zr0, wave, zon0);
-            if (Z2 && wave == 0) stage_z1(buf ^ 1, zr1, 4, zon1);
+            if (z2w) stage_z1(buf ^ 1, zr1, WV + wave, zon1);
         }
     }
-    // D[row = 4 q + r][col = i] of tile (t, u):  m = m0 + 4 (4 q + r) + t,  col = n0col + 16 u + i
+    // D[row = 4 q + r][col = i] of tile (t, u):  m = m0 + MT (4 q + r) + t,  col = n0col + 16 u + i
     float* out = part + (int64_t)by * M * Npart;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 4 * (4 * q + r) + t;
+            const int m = m0 + MT * (4 * q + r) + t;
             if (m >= M) continue;
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
@@ -4486,11 +4487,47 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     float* part = (float*)dev_alloc(d, sizeof(float) * nslab * M * N);
     const int NTtot = int(N / 16);
     TagScope ts(d);
-    for (int nt0 = 0; nt0 < NTtot;) {
+    // split-product kernels: as few column panels (passes over A) as 9-tile panels allow, the tiles spread evenly; a panel of
+    // 6 .. 9 tiles runs on waves that own 32 columns of A (two m-tiles, 8-B loads: 72 accumulator registers at 9 tiles)
+    const int npass3 = cdiv(NTtot, 9);
+    for (int nt0 = 0, pass = 0; nt0 < NTtot; ++pass) {
         const int rem = NTtot - nt0;
-        const int w = rem >= 5 ? 5 : rem;
+        const int w = split3_mode ? (rem + (npass3 - pass) - 1) / std::max(npass3 - pass, 1) : (rem >= 5 ? 5 : rem);
         const float* Af = (const float*)A; const float* Bf = (const float*)B;
         const float* ma = (const float*)muA; const float* mb = (const float*)muB;
+        if (split3_mode && w >= 6) {
+            const dim3 grid(8 * cdiv(M, 256), (unsigned)cdiv(nsplit, 8)), block(512);   // 8 waves x 32 columns per workgroup
+#define ATB3W_LAUNCH(NTv)                                                                                                             \
+            do {                                                                                                                      \
+                if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, 8, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+                else hipLaunchKernelGGL((k_atb3<NTv, false, 8, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+            } while (0)
+            switch (w) {
+                case 9: ATB3W_LAUNCH(9); break;
+                case 8: ATB3W_LAUNCH(8); break;
+                case 7: ATB3W_LAUNCH(7); break;
+                default: ATB3W_LAUNCH(6); break;
+            }
+#undef ATB3W_LAUNCH
+            launch_check();
+            if (n_tail) {  // the ragged rows (< one stage): one more slab from the fp32 kernel, in two sub-panels of <= 5 tiles
+                const float* At = Af + n_main * lda; const float* Bt = Bf + n_main * ldb;
+                float* pt = part + nsplit * M * N;
+                for (int s0 = 0; s0 < w;) {
+                    const int ws = std::min(5, w - s0);
+                    switch (ws) {
+                        case 5: launch_atb<5>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * (nt0 + s0), mb, n_tail, 64, pt, 1); break;
+                        case 4: launch_atb<4>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * (nt0 + s0), mb, n_tail, 64, pt, 1); break;
+                        case 3: launch_atb<3>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * (nt0 + s0), mb, n_tail, 64, pt, 1); break;
+                        case 2: launch_atb<2>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * (nt0 + s0), mb, n_tail, 64, pt, 1); break;
+                        default: launch_atb<1>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * (nt0 + s0), mb, n_tail, 64, pt, 1); break;
+                    }
+                    s0 += ws;
+                }
+            }
+            nt0 += w;
+            continue;
+        }
         if (split3_mode) {
             // 8-wave workgroups (one B stage per 512 columns of A) where the row split already puts two waves on every SIMD
             const bool wv8 = M >= 512 && nsplit * mslices >= (int64_t)num_cu2 * 8;
