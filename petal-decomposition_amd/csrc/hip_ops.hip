@@ -4495,7 +4495,12 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         const int w = split3_mode ? (rem + (npass3 - pass) - 1) / std::max(npass3 - pass, 1) : (rem >= 5 ? 5 : rem);
         const float* Af = (const float*)A; const float* Bf = (const float*)B;
         const float* ma = (const float*)muA; const float* mb = (const float*)muB;
-        if (split3_mode && w >= 6) {
+        // 8-wave workgroups of 64-column waves (one B stage per 512 columns of A) only where the row split already puts two waves
+        // on every SIMD (long row ranges); everywhere else, and for every panel of more than 5 tiles, 8 waves of 32 columns:
+        // at 100000 x 512 that form takes 55.4 us where four 64-column waves took 57.4 (at 1e6 rows it is the slower one,
+        // 0.544 vs 0.533 ms)
+        const bool wv8 = M >= 512 && nsplit * mslices >= (int64_t)num_cu2 * 8;
+        if (split3_mode && (w >= 6 || !wv8)) {
             const dim3 grid(8 * cdiv(M, 256), (unsigned)cdiv(nsplit, 8)), block(512);   // 8 waves x 32 columns per workgroup
 #define ATB3W_LAUNCH(NTv)                                                                                                             \
             do {                                                                                                                      \
@@ -4506,7 +4511,12 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
                 case 9: ATB3W_LAUNCH(9); break;
                 case 8: ATB3W_LAUNCH(8); break;
                 case 7: ATB3W_LAUNCH(7); break;
-                default: ATB3W_LAUNCH(6); break;
+                case 6: ATB3W_LAUNCH(6); break;
+                case 5: ATB3W_LAUNCH(5); break;
+                case 4: ATB3W_LAUNCH(4); break;
+                case 3: ATB3W_LAUNCH(3); break;
+                case 2: ATB3W_LAUNCH(2); break;
+                default: ATB3W_LAUNCH(1); break;
             }
 #undef ATB3W_LAUNCH
             launch_check();
@@ -4529,15 +4539,11 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
             continue;
         }
         if (split3_mode) {
-            // 8-wave workgroups (one B stage per 512 columns of A) where the row split already puts two waves on every SIMD
-            const bool wv8 = M >= 512 && nsplit * mslices >= (int64_t)num_cu2 * 8;
-            const dim3 grid(8 * cdiv(M, wv8 ? 512 : 256), (unsigned)cdiv(nsplit, 8)), block(wv8 ? 512 : 256);
+            const dim3 grid(8 * cdiv(M, 512), (unsigned)cdiv(nsplit, 8)), block(512);
 #define ATB3_LAUNCH(NTv)                                                                                                              \
             do {                                                                                                                      \
-                if (ma && wv8) hipLaunchKernelGGL((k_atb3<NTv, true, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
-                else if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, 4>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
-                else if (wv8) hipLaunchKernelGGL((k_atb3<NTv, false, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
-                else hipLaunchKernelGGL((k_atb3<NTv, false, 4>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+                if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+                else hipLaunchKernelGGL((k_atb3<NTv, false, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
             } while (0)
             switch (w) {
                 case 5: ATB3_LAUNCH(5); break;
