@@ -902,22 +902,23 @@ __global__ __launch_bounds__(256) void k_pack_p3(const double* __restrict__ P, i
 #define PETAL_XP3_DEPTH 1   // raw X chunks in flight per wave (2 measured slower)
 #define PETAL_XP3_OCC 2     // waves per SIMD the register budget is cut for
 #endif
-template <int RT, int NT, int DEPTH, bool CENTER>
-__global__ __launch_bounds__(256, PETAL_XP3_OCC) void k_xp3(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
+template <int RT, int NT, int DEPTH, bool CENTER, int WVK = 4>  // WVK = waves (row tiles of 16 RT rows) per workgroup
+__global__ __launch_bounds__(64 * WVK, PETAL_XP3_OCC) void k_xp3(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
                                                             const float* __restrict__ mu, const bf16x8* __restrict__ Ppk3,
                                                             int NTtot, int nt0, int N, const float* __restrict__ bias,
                                                             float* __restrict__ Z, int64_t ldz) {
     constexpr int PITEMS = NT * 192;               // 16-B items of one P chunk (NT tiles x 3 planes x 64 lanes)
-    constexpr int PI = (PITEMS + 255) / 256;       // per thread
+    constexpr int NTHR = 64 * WVK;
+    constexpr int PI = (PITEMS + NTHR - 1) / NTHR;  // per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_xp3[];
     bf16x8* sP = reinterpret_cast<bf16x8*>(sm_xp3);                        // [2][PITEMS]
     float* sMu = reinterpret_cast<float*>(sm_xp3 + sizeof(bf16x8) * 2 * PITEMS);  // [32 nchunk] (zero padded)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+    const int64_t row0 = ((int64_t)blockIdx.x * WVK + wave) * (16 * RT);
     const int nchunk = (K + 31) >> 5;
     if (CENTER)
-        for (int k = tid; k < 32 * nchunk; k += 256) sMu[k] = k < K ? mu[k] : 0.f;
+        for (int k = tid; k < 32 * nchunk; k += NTHR) sMu[k] = k < K ? mu[k] : 0.f;
     f32x4 acc[RT][NT];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -942,12 +943,12 @@ __global__ __launch_bounds__(256, PETAL_XP3_OCC) void k_xp3(const float* __restr
     auto load_p = [&](int c, bf16x8(&pn)[PI]) {
 #pragma unroll
         for (int it = 0; it < PI; ++it)
-            if (tid + 256 * it < PITEMS) pn[it] = psrc[(int64_t)c * NTtot * 192 + 256 * it];
+            if (tid + NTHR * it < PITEMS) pn[it] = psrc[(int64_t)c * NTtot * 192 + NTHR * it];
     };
     auto store_p = [&](int buf, const bf16x8(&pn)[PI]) {
 #pragma unroll
         for (int it = 0; it < PI; ++it)
-            if (tid + 256 * it < PITEMS) sP[buf * PITEMS + tid + 256 * it] = pn[it];
+            if (tid + NTHR * it < PITEMS) sP[buf * PITEMS + tid + NTHR * it] = pn[it];
     };
     f32x8 a[DEPTH][RT];
     bf16x8 pn[PI];
@@ -4265,12 +4266,31 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         TagScope ts(d);
         // Column panels: as few passes over X as 9-tile panels allow, the tiles spread evenly over them.  A panel of <= 5 tiles
         // runs on 64-row wave tiles (RT = 4), one of 6 .. 9 tiles on 32-row wave tiles (RT = 2: 72 accumulator registers at 9
-        // tiles, still two waves per SIMD) -- every pass reads and splits X again, so l = 138 in one 9-tile pass instead of
-        // 5 + 4 takes 0.49 instead of 0.55 ms at 250000 x 1024 (a one-wave-per-SIMD 64-row form of it had measured slower).
+        // tiles, eight waves per workgroup) -- every pass reads and splits X again, so l = 138 in one 9-tile pass instead of
+        // 5 + 4 takes 0.41 instead of 0.55 ms at 250000 x 1024 (0.47 with four waves per workgroup, which stage the P chunk
+        // twice as often; a one-wave-per-SIMD 64-row form had measured slower; at <= 5 tiles the 32-row form loses, 64 vs 54 us).
         const int npass = cdiv(NTtot, 9);
         for (int nt0 = 0, pass = 0; nt0 < NTtot; ++pass) {
             const int w = (NTtot - nt0 + (npass - pass) - 1) / (npass - pass);
             const size_t lds = sizeof(bf16x8) * 2 * w * 192 + sizeof(float) * 32 * nch;
+#define XP3_LAUNCH8(NTv)                                                                                                                  \
+            do {                                                                                                                            \
+                const int blocksw = cdiv(n, 256);                                                                                           \
+                if (lds > 64 * 1024) set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp3<2, NTv, DPv, true, 8>) : reinterpret_cast<const void*>(k_xp3<2, NTv, DPv, false, 8>)); \
+                if (muf) hipLaunchKernelGGL((k_xp3<2, NTv, DPv, true, 8>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
+                else hipLaunchKernelGGL((k_xp3<2, NTv, DPv, false, 8>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
+            } while (0)
+            if (w >= 6) {   // eight 32-row waves per workgroup: the P chunk is staged once per 256 rows, as in the 64-row form
+                switch (w) {
+                    case 9: XP3_LAUNCH8(9); break;
+                    case 8: XP3_LAUNCH8(8); break;
+                    case 7: XP3_LAUNCH8(7); break;
+                    default: XP3_LAUNCH8(6); break;
+                }
+                launch_check();
+                nt0 += w;
+                continue;
+            }
 #define XP3_LAUNCH(RTw, NTv)                                                                                                               \
             do {                                                                                                                            \
                 const int blocksw = cdiv(n, 64 * RTw);                                                                                      \
@@ -4279,10 +4299,6 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
                 else hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, false>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
             } while (0)
             switch (w) {
-                case 9: XP3_LAUNCH(2, 9); break;
-                case 8: XP3_LAUNCH(2, 8); break;
-                case 7: XP3_LAUNCH(2, 7); break;
-                case 6: XP3_LAUNCH(2, 6); break;
                 case 5: XP3_LAUNCH(RTv, 5); break;
                 case 4: XP3_LAUNCH(RTv, 4); break;
                 case 3: XP3_LAUNCH(RTv, 3); break;
@@ -4290,6 +4306,7 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
                 default: XP3_LAUNCH(RTv, 1); break;
             }
 #undef XP3_LAUNCH
+#undef XP3_LAUNCH8
             launch_check();
             nt0 += w;
         }
