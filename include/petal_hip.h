@@ -67,6 +67,9 @@ typedef struct petal_stats {
     double  ica_step_flops;    /* per launch: 4 nc^2 n                                                 */
     double  ica_step_bytes;    /* per launch: 4 nc n                                                   */
     int64_t n_iter;            /* FastICA iterations of the last fit                                  */
+    /* sample-sharded fits: what went through the collective during the last fit (separates comm from compute) */
+    int64_t allreduce_calls;   /* all-reduce calls issued (RandomizedPca: n_iter + 3)                  */
+    double  allreduce_bytes;   /* payload bytes summed over those calls                                */
 } petal_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */

@@ -63,7 +63,8 @@ class petal_stats(C.Structure):
                 ("pass_flops", C.c_double), ("pass_bytes", C.c_double),
                 ("ica_step_ms", C.c_double), ("ica_step_launches", C.c_int64),
                 ("ica_step_flops", C.c_double), ("ica_step_bytes", C.c_double),
-                ("n_iter", C.c_int64)]
+                ("n_iter", C.c_int64),
+                ("allreduce_calls", C.c_int64), ("allreduce_bytes", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -34,33 +34,54 @@ void check_matrix(const petal_matrix& m, const char* what) {
 
 struct RankInfo { double n_total = 0; int64_t row_offset = 0; };
 
-RankInfo rank_info(petal_ctx& c, int64_t n_local) {
-    RankInfo r;
-    if (!sharded(c)) { r.n_total = double(n_local); return r; }
+// Everything a sample-sharded fit needs from the other ranks before its first product, in ONE all-reduce (round 2 issued
+// three: row counts, column sums, rank 0's random draw):
+//     buf = [ row counts (world) | column sums (w_sums: 0, dp or 2 dp with the sums of squares) | draw (ndraw) ]
+//  - counts: every rank writes its own row count into its slot, zeros elsewhere: the SUM is the table of counts;
+//  - draw: the replicated random input (Omega, pca.rs:701-705; w_init, ica.rs:210-214).  In the crate ONE model-owned
+//    generator draws it; with one process per GPU every rank has its own generator, so rank 0's draw is the one every rank
+//    uses: the other ranks contribute zeros and the SUM hands them rank 0's values (x + 0 + ... + 0 = x).
+// The one host synchronisation of a sharded fit's start happens here (the counts decide shapes and error returns).
+struct ShardPrologue {
+    RankInfo ri;
+    DBuf buf;
+    double* sums = nullptr;  // device, w_sums doubles (all ranks' column sums [| sums of squares])
+    double* draw = nullptr;  // device, ndraw doubles (rank 0's draw widened to fp64)
+};
+ShardPrologue shard_prologue(petal_ctx& c, const DevMat& X, int64_t w_sums, bool with_sq, int dt_draw, const void* host_draw, int64_t ndraw) {
+    ShardPrologue p;
+    const int64_t total = int64_t(c.world) + w_sums + ndraw;
+    p.buf = DBuf(c.dev, sizeof(double) * size_t(total));
+    double* base = p.buf.f64();
+    p.sums = base + c.world;
+    p.draw = p.sums + w_sums;
     std::vector<double> h(c.world, 0.0);
-    h[c.rank] = double(n_local);
-    DBuf b(c.dev, sizeof(double) * c.world);
-    dev_h2d(c.dev, b.p, h.data(), b.bytes);
-    allreduce_f64(c, b.f64(), c.world, PETAL_SUM);
-    dev_d2h(c.dev, h.data(), b.p, b.bytes);
+    h[c.rank] = double(X.n);
+    dev_h2d_async(c.dev, base, h.data(), sizeof(double) * c.world);
+    if (w_sums) op_colsum(c.dev, X.dtype, X.p, X.n, X.dp, X.ld, p.sums, with_sq);
+    if (ndraw) {
+        if (c.rank == 0) {
+            DBuf raw(c.dev, dtype_size(dt_draw) * size_t(ndraw));
+            dev_h2d_async(c.dev, raw.p, host_draw, raw.bytes);
+            op_cvt_to_f64(c.dev, dt_draw, p.draw, raw.p, ndraw);
+        } else {
+            dev_memset(c.dev, p.draw, 0, sizeof(double) * size_t(ndraw));
+        }
+    }
+    allreduce_f64(c, base, total, PETAL_SUM);
+    dev_d2h(c.dev, h.data(), base, sizeof(double) * c.world);
     dev_sync(c.dev);
-    for (int i = 0; i < c.world; ++i) { r.n_total += h[i]; if (i < c.rank) r.row_offset += int64_t(h[i]); }
-    return r;
-}
-
-// Replicated random inputs (Omega, pca.rs:701-705; w_init, ica.rs:210-214): in the crate ONE model-owned generator draws
-// them; with one process per GPU every rank has its own generator, so rank 0's draw is the one every rank uses (the other
-// ranks' buffers are zeroed and the SUM all-reduce hands them rank 0's values bit for bit: x + 0 + ... + 0 = x).
-void replicate_from_rank0(petal_ctx& c, double* dev_buf, int64_t count) {
-    if (!sharded(c) || count == 0) return;
-    if (c.rank != 0) dev_memset(c.dev, dev_buf, 0, sizeof(double) * size_t(count));
-    allreduce_f64(c, dev_buf, count, PETAL_SUM);
+    for (int i = 0; i < c.world; ++i) { p.ri.n_total += h[i]; if (i < c.rank) p.ri.row_offset += int64_t(h[i]); }
+    return p;
 }
 
 // column means (pca.rs:520-528 / ica.rs:174): mu64 (device f64[dp]) and muT (device dtype[dp]); zeros if !centering
 // with_sq (centering only): mu64 has 2 dp entries, the second half holds the column sums of squares over all ranks,
 // from the same pass over X (total variance = sum_j (sq_j - n mu_j^2), formed in fp64 by the caller).
-void column_means_into(petal_ctx& c, const DevMat& X, double n_total, bool centering, double* mu64, DBuf& muT, bool with_sq) {
+// reduced_sums (sharded fits): the all-reduced [column sums | sums of squares] of shard_prologue(); single-rank fits make
+// their own pass over X here.
+void column_means_into(petal_ctx& c, const DevMat& X, double n_total, bool centering, double* mu64, DBuf& muT, bool with_sq,
+                       const double* reduced_sums = nullptr) {
     const int64_t w = (with_sq && centering) ? 2 * X.dp : X.dp;
     muT = DBuf(c.dev, dtype_size(X.dtype) * X.dp);
     if (!centering) {
@@ -68,18 +89,18 @@ void column_means_into(petal_ctx& c, const DevMat& X, double n_total, bool cente
         dev_memset(c.dev, muT.p, 0, muT.bytes);
         return;
     }
-    if (!sharded(c)) {  // one pass + one finishing launch (sum of the block partials, 1 / n, the dtype copy)
+    if (!reduced_sums) {  // one pass + one finishing launch (sum of the block partials, 1 / n, the dtype copy)
         op_colmean(c.dev, X.dtype, X.p, X.n, X.dp, X.ld, n_total, mu64, muT.p, w > X.dp);
         return;
     }
-    op_colsum(c.dev, X.dtype, X.p, X.n, X.dp, X.ld, mu64, w > X.dp);
-    allreduce_f64(c, mu64, w, PETAL_SUM);
+    dev_d2d(c.dev, mu64, reduced_sums, sizeof(double) * w);
     op_dscal(c.dev, mu64, X.dp, 1.0 / n_total);
     op_cvt_from_f64(c.dev, X.dtype, muT.p, mu64, X.dp);
 }
-void column_means(petal_ctx& c, const DevMat& X, double n_total, bool centering, DBuf& mu64, DBuf& muT, bool with_sq = false) {
+void column_means(petal_ctx& c, const DevMat& X, double n_total, bool centering, DBuf& mu64, DBuf& muT, bool with_sq = false,
+                  const double* reduced_sums = nullptr) {
     mu64 = DBuf(c.dev, sizeof(double) * ((with_sq && centering) ? 2 * X.dp : X.dp));
-    column_means_into(c, X, n_total, centering, mu64.f64(), muT, with_sq);
+    column_means_into(c, X, n_total, centering, mu64.f64(), muT, with_sq, reduced_sums);
 }
 
 // svd_flip's decision (pca.rs:826-839) for the columns of a row-sharded U: sign of the first
@@ -262,6 +283,8 @@ void allreduce_f64(petal_ctx& c, double* dev_buf, int64_t count, int op) {
     if (!c.allreduce) device_error("world_size > 1 but no collective hook installed (petal_ctx_set_collective)");
     int rc = c.allreduce(c.allreduce_user, dev_buf, count, PETAL_F64, op, dev_stream(c.dev));
     if (rc != 0) device_error("collective all-reduce failed with code " + std::to_string(rc));
+    c.stats.allreduce_calls += 1;
+    c.stats.allreduce_bytes += double(sizeof(double)) * double(count);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,15 +361,30 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     check_matrix(x, "input");
     if (k < 0 || n_oversample < 0 || n_iter < 0) invalid_input("negative parameter");
     const int dt = x.dtype;
-    RankInfo ri = rank_info(c, x.rows);
-    const int64_t n_total = int64_t(ri.n_total), d = x.cols;
+    const int64_t d = x.cols, l_req = k + n_oversample;
+    // fp32 input: the total variance comes from column sums of squares gathered in the means pass (exact products, fp64
+    // sums: the cancellation in sum x^2 - n mu^2 costs (mu / sigma)^2 ulps of fp64, far below fp32 resolution); fp64 input
+    // keeps the centred sum fused into the first product
+    const bool tv_from_sq = centering && dt == F32;
+    DevMat X;
+    ShardPrologue pro;
+    RankInfo ri;
+    if (sharded(c)) {
+        // (argument errors that every rank sees alike are raised BEFORE the collective, so no rank is left waiting in it)
+        if (d > 0 && l_req > 0 && omega == nullptr) invalid_input("omega is required");
+        X = ingest(c, x);
+        pro = shard_prologue(c, X, centering ? (tv_from_sq ? 2 * X.dp : X.dp) : 0, tv_from_sq, dt, omega, d * l_req);
+        ri = pro.ri;
+    } else {
+        ri.n_total = double(x.rows);
+    }
+    const int64_t n_total = int64_t(ri.n_total);
     if (n_total < k || d < k)  // pca.rs:513-518
         invalid_input("every dimension should be at least " + std::to_string(k));
     if (centering && n_total == 0) {  // mean_axis -> None (pca.rs:521-525): Ok, model untouched
         if (y_out && (y_out->rows != 0)) invalid_input("output has the wrong shape");
         return;
     }
-    const int64_t l_req = k + n_oversample;
     const int64_t L = std::min(l_req, std::min(n_total, d));  // the reference's min(nrows, ncols) slices, pca.rs:710/713
     if (L > 0 && omega == nullptr) invalid_input("omega is required");
     if (d == 0 || L == 0) {  // nothing to decompose: k == 0 here
@@ -355,7 +393,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         return;
     }
     const int64_t LP = round_up(L, 16);
-    DevMat X = ingest(c, x);
+    if (!sharded(c)) X = ingest(c, x);
     const int64_t n = X.n, dp = X.dp;
     const size_t esz = dtype_size(dt);
     const double tol_drop = (dt == F32 ? 1e-6 : 1e-13);
@@ -375,22 +413,20 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     double* const mu64 = res.f64() + o_mu;
     double* const flip = res.f64() + o_flip;
     DBuf muT;
-    // fp32 input: the total variance comes from column sums of squares gathered in the means pass (exact products, fp64
-    // sums: the cancellation in sum x^2 - n mu^2 costs (mu / sigma)^2 ulps of fp64, far below fp32 resolution); fp64 input
-    // keeps the centred sum fused into the first product
-    const bool tv_from_sq = centering && dt == F32;
     if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
-    column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq);
+    column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq, sharded(c) && centering ? pro.sums : nullptr);
 
-    // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64.  The raw draw goes
-    // up through the pinned ring without a host wait (it overlaps the column-means pass) and is widened on the device.
+    // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64.  Single rank: the raw
+    // draw goes up through the pinned ring without a host wait (it overlaps the column-means pass) and is widened on the
+    // device; sharded: rank 0's draw came back from the prologue's all-reduce, already fp64.
     DBuf P(c.dev, sizeof(double) * dp * LP);
-    {
+    if (sharded(c)) {
+        op_pad_to_f64(c.dev, F64, P.f64(), dp, LP, pro.draw, d, L, l_req, tvp, 2 + LP);
+    } else {
         DBuf raw(c.dev, esz * size_t(d) * l_req);
         dev_h2d_async(c.dev, raw.p, omega, raw.bytes);
         op_pad_to_f64(c.dev, dt, P.f64(), dp, LP, raw.p, d, L, l_req, tvp, 2 + LP);  // (also clears tv, ndead, lam for the first pipeline run)
     }
-    replicate_from_rank0(c, P.f64(), dp * LP);
     DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
     c.stats.pass_flops = 2.0 * double(n) * double(d) * double(l_req);
     c.stats.pass_bytes = double(esz) * (double(n) * d + double(n) * l_req + double(d) * l_req);
@@ -461,7 +497,11 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         dev_set_tag(c.dev, TAG_NONE);
         allreduce_f64(c, Yp, dp * LP + 1, PETAL_SUM);  // [ Xc^T Z | sum Xc^2 ]
         op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Pcur, LP, Yp, LP, 0.0, G, LP);
-        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);
+        // (a pivot lost here -- H is only symmetric / positive up to the fp32 rounding of Pcur and Z -- is recorded like the
+        // breakdowns of the power iterations: the fit is then redone on the robust Cholesky-QR2 path instead of silently
+        // dropping a component.  On the planted spectra the pivot ratios r_jj^2 / H_jj stay above 0.9: Pcur's columns come out
+        // of a Cholesky-QR ordered like the singular vectors, so Z's columns are nearly orthogonal.)
+        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, ndead, LP);
         Usrc = Z.p; Ubuf = Z1.p;
     } else {
         // Cholesky-QR2: Z1 = Z T1, Q = Z1 T2 with T2 folded into the small side
@@ -550,8 +590,18 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     check_matrix(x, "input");
     if (k < 0) invalid_input("negative parameter");
     const int dt = x.dtype;
-    RankInfo ri = rank_info(c, x.rows);
-    const int64_t n_total = int64_t(ri.n_total), d = x.cols;
+    const int64_t d = x.cols;
+    DevMat X;
+    ShardPrologue pro;
+    RankInfo ri;
+    if (sharded(c)) {
+        X = ingest(c, x);
+        pro = shard_prologue(c, X, centering ? X.dp : 0, false, dt, nullptr, 0);
+        ri = pro.ri;
+    } else {
+        ri.n_total = double(x.rows);
+    }
+    const int64_t n_total = int64_t(ri.n_total);
     if (n_total < k || d < k) invalid_input("every dimension should be at least " + std::to_string(k));  // pca.rs:199-204
     if (centering && n_total == 0) return;  // pca.rs:207-211
     if (d == 0 || n_total == 0) {
@@ -559,11 +609,11 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
         if (y_out) emit(c, dt, nullptr, x.rows, 0, 0, *y_out);
         return;
     }
-    DevMat X = ingest(c, x);
+    if (!sharded(c)) X = ingest(c, x);
     const int64_t n = X.n, dp = X.dp;
     const size_t esz = dtype_size(dt);
     DBuf mu64, muT;
-    column_means(c, X, ri.n_total, centering, mu64, muT);
+    column_means(c, X, ri.n_total, centering, mu64, muT, false, sharded(c) && centering ? pro.sums : nullptr);
 
     DBuf C(c.dev, sizeof(double) * dp * dp), V(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp);
     DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp);
@@ -698,12 +748,16 @@ int64_t ica_loop(petal_ctx& c, int dt, const void* X1T, int64_t n, int64_t nc, i
         constexpr int64_t RUN_AHEAD = 2;
         volatile int* hp = dev_host_progress(c.dev);
         hp[0] = 0; hp[1] = 0;
-        const auto t0 = std::chrono::steady_clock::now();
+        auto t_progress = std::chrono::steady_clock::now();  // when the device last reported a finished iteration
+        int last_seen = 0;
         for (int64_t it = 0; it < max_iter && !hp[0]; ++it) {
             int spins = 0;
             while (!hp[0] && it - int64_t(hp[1]) >= RUN_AHEAD) {
-                if ((++spins & 0xFFFF) == 0 &&   // a device that stopped reporting: fall back to a blocking wait
-                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) { dev_sync(c.dev); break; }
+                if ((++spins & 0xFFFF) != 0) continue;
+                const auto now = std::chrono::steady_clock::now();
+                if (hp[1] != last_seen) { last_seen = hp[1]; t_progress = now; }
+                // a device that stopped reporting for 30 s (not: a fit that has been running for 30 s): blocking wait
+                if (std::chrono::duration<double>(now - t_progress).count() > 30.0) { dev_sync(c.dev); t_progress = now; break; }
             }
             if (hp[0]) break;
             enqueue(it, const_cast<int*>(hp));
@@ -744,19 +798,33 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
     c.stats = petal_stats{};
     check_matrix(x, "input");
     const int dt = x.dtype;
-    RankInfo ri = rank_info(c, x.rows);
-    const int64_t n_total = int64_t(ri.n_total), d = x.cols;
+    const int64_t d = x.cols;
     if (n_iter) *n_iter = 0;
+    DevMat X;
+    ShardPrologue pro;
+    RankInfo ri;
+    // sharded: the caller sizes w_init before the row counts are known -- n_components, or the number of features
+    const int64_t nc_draw = n_components > 0 ? n_components : d;
+    if (sharded(c)) {
+        if (d > 0 && w_init == nullptr) invalid_input("w_init is required");  // (before the collective: every rank alike)
+        X = ingest(c, x);
+        pro = shard_prologue(c, X, X.dp, false, dt, w_init, nc_draw * nc_draw);
+        ri = pro.ri;
+    } else {
+        ri.n_total = double(x.rows);
+    }
+    const int64_t n_total = int64_t(ri.n_total);
     if (n_total == 0) return;  // ica.rs:174-176
     int64_t nc = n_components > 0 ? n_components : std::min(n_total, d);  // ica.rs:173
     if (nc > std::min(n_total, d)) invalid_input("n_components should be at most min(n_samples, n_features)");
     if (nc == 0 || d == 0) return;
     if (w_init == nullptr) invalid_input("w_init is required");
-    DevMat X = ingest(c, x);
+    if (sharded(c) && nc != nc_draw) invalid_input("a sharded fit with fewer samples than features needs n_components");
+    if (!sharded(c)) X = ingest(c, x);
     const int64_t n = X.n, dp = X.dp, ncp = round_up(nc, 16);
     const size_t esz = dtype_size(dt);
     DBuf mu64, muT;
-    column_means(c, X, ri.n_total, true, mu64, muT);
+    column_means(c, X, ri.n_total, true, mu64, muT, false, sharded(c) ? pro.sums : nullptr);
 
     // whitening (ica.rs:189-208): left singular vectors / values of Xc^T == eigenpairs of Xc^T Xc
     DBuf C(c.dev, sizeof(double) * dp * dp), U(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp);
@@ -780,12 +848,13 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
     op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, KTs.f64(), ncp, ncp, nullptr, X1T.p, ncp, nullptr);
 
     DBuf W(c.dev, sizeof(double) * nc * nc);
-    {
+    if (sharded(c)) {  // rank 0's draw, from the prologue's all-reduce
+        dev_d2d(c.dev, W.p, pro.draw, W.bytes);
+    } else {
         std::vector<double> h(size_t(nc) * nc);
         for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
         dev_h2d(c.dev, W.p, h.data(), W.bytes);
     }
-    replicate_from_rank0(c, W.f64(), nc * nc);
     const int64_t iters = ica_loop(c, dt, X1T.p, n, nc, ncp, ri.n_total, W, tol, max_iter, mode);  // ica.rs:216
     if (n_iter) *n_iter = iters;
 
@@ -824,16 +893,23 @@ void ica_par(petal_ctx& c, const petal_matrix& x1, double tol, int64_t max_iter,
     if (nc == 0) { if (n_iter) *n_iter = 0; return; }
     petal_matrix xt = x1;  // view the transpose: sample-major n x nc
     xt.rows = n; xt.cols = nc; xt.row_stride = x1.col_stride; xt.col_stride = x1.row_stride;
-    RankInfo ri = rank_info(c, n);
     DevMat X1T = ingest(c, xt);
     DBuf keep;
     const void* xp = X1T.p;
     if (n == 0) { keep = DBuf(c.dev, 64); xp = keep.p; }
     DBuf W(c.dev, sizeof(double) * nc * nc);
     std::vector<double> h(size_t(nc) * nc);
-    for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
-    dev_h2d(c.dev, W.p, h.data(), W.bytes);
-    replicate_from_rank0(c, W.f64(), nc * nc);
+    RankInfo ri;
+    if (sharded(c)) {
+        ShardPrologue pro = shard_prologue(c, X1T, 0, false, dt, w_init, nc * nc);
+        ri = pro.ri;
+        dev_d2d(c.dev, W.p, pro.draw, W.bytes);
+        dev_sync(c.dev);  // (pro's buffer returns to the allocator; stream order keeps the copy ahead of any reuse anyway)
+    } else {
+        ri.n_total = double(n);
+        for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
+        dev_h2d(c.dev, W.p, h.data(), W.bytes);
+    }
     const int64_t iters = ica_loop(c, dt, xp, n, nc, X1T.ld, ri.n_total, W, tol, max_iter, mode);
     dev_d2h(c.dev, h.data(), W.p, W.bytes);
     dev_sync(c.dev);

@@ -147,7 +147,9 @@ void dev_destroy(Dev* d) {
 void* dev_stream(Dev* d) { return d->stream; }
 volatile int* dev_host_progress(Dev* d) {
     if (!d->progress) {
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->progress), 64, hipHostMallocMapped));
+        // coherent (uncached on the device side) + mapped: the kernel's system-scope stores must become visible to the polling
+        // host while the stream is still running, whatever HIP_HOST_COHERENT / the platform default says
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->progress), 64, hipHostMallocCoherent | hipHostMallocMapped));
         std::memset(d->progress, 0, 64);
     }
     return d->progress;
@@ -2925,8 +2927,9 @@ __global__ __launch_bounds__(TRI_THREADS) void k_tridiag(const double* __restric
     for (int k = 0; k + 2 < L; ++k) {
         const int m = L - k - 1;                               // order of the trailing block, rows / columns k + 1 ..
         const double* colk = W + (size_t)(k + 1) * ld + k;     // x_i = W[k + 1 + i][k]
-        double xi = 0, sq = 0;
-        if (tid < m) { xi = colk[(size_t)tid * ld]; sq = tid > 0 ? xi * xi : 0.0; }
+        // (strided over the column: the trailing block may be longer than the workgroup, orders up to 2048 come here)
+        double sq = 0;
+        for (int i = tid; i < m; i += nt) { const double xi = colk[(size_t)i * ld]; sq += i > 0 ? xi * xi : 0.0; }
         double sigma, dummy;
         block_sum2(sq, 0.0, sigma, dummy);
         const double alpha = colk[0];
@@ -2936,10 +2939,10 @@ __global__ __launch_bounds__(TRI_THREADS) void k_tridiag(const double* __restric
             tk = (beta - alpha) / beta;
             scale = 1.0 / (alpha - beta);
         }
-        if (tid < m) {
-            const double vi = tid == 0 ? 1.0 : xi * scale;
-            sv[tid] = vi;
-            HV[(size_t)k * L + k + 1 + tid] = vi;              // reflector k: row k of HV, entries k + 1 .. L - 1
+        for (int i = tid; i < m; i += nt) {
+            const double vi = i == 0 ? 1.0 : colk[(size_t)i * ld] * scale;
+            sv[i] = vi;
+            HV[(size_t)k * L + k + 1 + i] = vi;                // reflector k: row k of HV, entries k + 1 .. L - 1
         }
         if (tid == 0) { dd[k] = W[(size_t)k * ld + k]; ee[k] = beta; tau[k] = tk; }
         __syncthreads();
@@ -3100,8 +3103,10 @@ __global__ __launch_bounds__(64 * WPB) void k_trieig(const double* __restrict__ 
 }
 // verdict of the two-stage route, read by the Jacobi kernels launched behind it: flag = 1 (run Jacobi) when some eigenvalue
 // is not finite or two neighbours are closer than 1e-10 of the largest magnitude (their vectors need not be orthogonal)
-__global__ void k_trieig_verdict(const double* __restrict__ w, const double* __restrict__ ee, int L, double gap_tol, int* __restrict__ flag) {
+__global__ __launch_bounds__(1024) void k_trieig_verdict(const double* __restrict__ w, const double* __restrict__ ee, int L, double gap_tol,
+                                                         const double* __restrict__ A, int64_t lda, int* __restrict__ flag) {
     __shared__ int bad;
+    __shared__ double red[3][16];
     if (threadIdx.x == 0) bad = 0;
     __syncthreads();
     const double scale = fmax(fabs(w[0]), fabs(w[L - 1]));
@@ -3111,8 +3116,28 @@ __global__ void k_trieig_verdict(const double* __restrict__ w, const double* __r
         if (j + 1 < L) b = b || !(a - w[j + 1] > gap_tol * scale) || !(fabs(ee[j]) > 1e-14 * scale);   // (or the matrix decouples)
         if (b) bad = 1;
     }
+    // two invariants of the similarity transform, checked against the INPUT matrix (k_tridiag works on a copy): the trace and
+    // the squared Frobenius norm.  A defect anywhere in the reduction or the eigenvalue search shows up here instead of in
+    // the caller's results (orders above the workgroup size once went through a truncated Householder step unnoticed).
+    double tr = 0, fr = 0, sw = 0, sw2 = 0;
+    for (int64_t e = threadIdx.x; e < (int64_t)L * L; e += blockDim.x) {
+        const int64_t r = e / L, c = e - r * L;
+        const double v = A[r * lda + c];
+        fr += v * v;
+        if (r == c) tr += v;
+    }
+    for (int j = threadIdx.x; j < L; j += blockDim.x) { const double a = w[j]; sw += a; sw2 += a * a; }
+    double d0 = tr - sw, d1 = fr - sw2, d2 = fr;
+    for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); d1 += __shfl_down(d1, off, 64); d2 += __shfl_down(d2, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d0; red[1][threadIdx.x >> 6] = d1; red[2][threadIdx.x >> 6] = d2; }
     __syncthreads();
-    if (threadIdx.x == 0) *flag = (bad || !(scale > 0.0)) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int x = 0; x < (int)(blockDim.x >> 6); ++x) { t0 += red[0][x]; t1 += red[1][x]; t2 += red[2][x]; }
+        const double fn = sqrt(fmax(t2, 0.0));
+        const bool off_inv = !(fabs(t0) <= 1e-9 * fmax(fn, 1e-300) * sqrt((double)L)) || !(fabs(t1) <= 1e-9 * fmax(t2, 1e-300));
+        *flag = (bad || off_inv || !(scale > 0.0)) ? 1 : 0;
+    }
 }
 
 // ---- register-resident variants for L <= 141 (the l = k + 10 of the randomized fits, the nc x nc problems of FastICA) ----
@@ -5004,7 +5029,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
                 hipLaunchKernelGGL(k_trieig<1>, dim3((unsigned)L), dim3(64), sizeof(double) * 6 * L, d->stream, dd, ee, HV, tau, (int)L, w, V, ldv);
             }
             launch_check();
-            hipLaunchKernelGGL(k_trieig_verdict, dim3(1), dim3(256), 0, d->stream, w, ee, (int)L, gap_tol, flag);
+            hipLaunchKernelGGL(k_trieig_verdict, dim3(1), dim3(1024), 0, d->stream, w, ee, (int)L, gap_tol, A, lda, flag);
             launch_check();
         }
     }
