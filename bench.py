@@ -257,7 +257,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"RandomizedPca.fit k={k} n_iter={n_iter} oversample=10 on {n}x{d} fp32 per GPU "
-                                   f"({cfg['label']}), X resident in HBM",
+                                   f"({cfg['label']}), X resident in HBM"
+                                   + (" and small enough (%.0f MB) to stay in the 256 MiB Infinity Cache between passes" % (4e-6 * n * d)
+                                      if 4 * n * d + 8 * n * l <= INFINITY_CACHE_BYTES else ""),
+                       "x_fits_infinity_cache": bool(4 * n * d + 8 * n * l <= INFINITY_CACHE_BYTES),
                        "rows_per_gpu": n, "features": d, "n_components": k, "n_iter": n_iter,
                        "gemm_mode": ("bf16x3: fp32 operands split exactly into 3 bf16 pieces, 6 piece products on the bf16 "
                                      "matrix cores, fp32 accumulation (fp32-equivalent)") if args.gemm == "bf16x3"
@@ -265,6 +268,7 @@ def main():
                        "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU",
                        "collective": collective},
             "roofline": roofline,
+            "fit_roofline": fit_roofline(n, d, l, n_iter, 4, args.gemm, elapsed / args.steps * 1e3),
         }
 
         if world == 1:
@@ -311,33 +315,74 @@ def pmc_traffic(n, d, l, mode, kind, with_commit=False):
     return (None, None) if with_commit else None
 
 
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: Peak BF16 MFMA, dense (never the 2:1-sparsity figure)
+INFINITY_CACHE_BYTES = 256 * 1024 * 1024
+
+
+def pass_bound(pass_flops, pass_bytes, mode):
+    """Which roofline binds ONE power-iteration GEMM launch of this shape -- computed, not assumed: the largest of
+      hbm        algorithmic bytes / 8 TB/s
+      mfma-bf16  (bf16x3 mode) six bf16 piece products per fp32 product: 6 x algorithmic flops / 2.5 PFLOP/s dense
+      mfma-fp32  (fp32 mode) algorithmic flops / 157.3 TFLOP/s
+    Returns {"bound": "hbm" | "mfma", "pipe": ..., "floor_s": the binding time, "times_s": every candidate}."""
+    times = {"hbm": pass_bytes / (HBM_PEAK_GBS * 1e9)}
+    if mode == "bf16x3":
+        times["mfma-bf16"] = 6.0 * pass_flops / (BF16_MFMA_PEAK_TF * 1e12)
+    else:
+        times["mfma-fp32"] = pass_flops / (FP32_MFMA_PEAK_TF * 1e12)
+    pipe = max(times, key=times.get)
+    return {"bound": "hbm" if pipe == "hbm" else "mfma", "pipe": pipe, "floor_s": times[pipe], "times_s": times}
+
+
 def roofline_entry(dom, per, pass_flops, pass_bytes, mode, traffic_override, n, d, l):
-    """The `roofline` object of the bench line for the dominant kernel `dom`.
-    fp32 mode: the kernels issue v_mfma_f32_16x16x4_f32 -> bound "mfma", achieved = algorithmic flops / duration vs the
-    157.3 TFLOP/s fp32-MFMA peak.  bf16x3 (split-product) mode: the same products take 2.7x less matrix-pipe time on the
-    bf16 cores and the kernels are paced by the X stream -> bound "hbm", achieved = algorithmic bytes / duration vs
-    8 TB/s; the fp32-equivalent flop rate is kept alongside for comparison with the fp32 mode."""
+    """The `roofline` object of the bench line for the dominant kernel `dom`, against the roofline that BINDS its shape
+    (pass_bound): "hbm" -> achieved = algorithmic bytes / duration vs 8 TB/s; "mfma" on the bf16 pipe -> achieved = the six
+    bf16 piece products' flops / duration vs 2.5 PFLOP/s dense (l = 138: the matrix pipe binds, not the X stream); "mfma" on
+    the fp32 pipe (--gemm fp32) -> algorithmic flops / duration vs 157.3 TFLOP/s.  frac = floor time / measured duration."""
     avg_ms = per[dom]
     tf = pass_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     gbs = pass_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    b = pass_bound(pass_flops, pass_bytes, mode)
     traffic, measured_at = (traffic_override, "--pmc-traffic") if traffic_override is not None else \
         pmc_traffic(n, d, l, mode, dom.split(" ")[0], with_commit=True)
     other = {kname: {"avg_launch_ms": round(v, 5), "GB/s_algorithmic": round(pass_bytes / (v * 1e-3) / 1e9, 1) if v > 0 else 0.0,
-                     "fp32_equivalent_TFLOP/s": round(pass_flops / (v * 1e-3) / 1e12, 3) if v > 0 else 0.0}
+                     "fp32_equivalent_TFLOP/s": round(pass_flops / (v * 1e-3) / 1e12, 3) if v > 0 else 0.0,
+                     "frac_of_binding_roofline": round(b["floor_s"] / (v * 1e-3), 4) if v > 0 else 0.0}
              for kname, v in per.items() if kname != dom}
-    common = {"kernel": dom + (" k_xp3 / k_atb3 (bf16x3 split-product, fp32 accumulate)" if mode == "bf16x3"
+    common = {"pipe": b["pipe"],
+              "candidate_floors_us": {k2: round(v * 1e6, 2) for k2, v in b["times_s"].items()},
+              "kernel": dom + (" k_xp3 / k_atb3 (bf16x3 split-product, fp32 accumulate)" if mode == "bf16x3"
                                else " k_xp_* / k_atb_mfma (fp32 MFMA)"),
               "traffic": traffic, "traffic_measured_at": measured_at,
               "traffic_note": "FETCH_SIZE x 2 + WRITE_SIZE (the gfx950 guide's correction); the x 2 is exact for 128-B requests but "
                               "over-counts reads issued as 64-B segments such as K2's Z stage (factor 1.5 measured, profiles/r02_fetch_size_calibration.txt)",
               "avg_launch_ms": round(avg_ms, 5), "flops_per_launch": pass_flops,
-              "bytes_per_launch": pass_bytes, "other_kernel": other}
-    if mode == "bf16x3":
-        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                **common, "fp32_equivalent_TFLOP/s": round(tf, 3),
-                "fp32_equivalent_frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TF, 4)}
+              "bytes_per_launch": pass_bytes, "other_kernel": other,
+              "hbm_GBps_algorithmic": round(gbs, 1), "fp32_equivalent_TFLOP/s": round(tf, 3)}
+    if b["pipe"] == "hbm":
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **common}
+    if b["pipe"] == "mfma-bf16":
+        tf6 = 6.0 * tf
+        return {"bound": "mfma", "achieved": round(tf6, 2), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(tf6 / BF16_MFMA_PEAK_TF, 4), **common,
+                "achieved_note": "bf16 flops issued for the algorithmic product: 6 piece products x 2 n d l"}
     return {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": round(tf / FP32_MFMA_PEAK_TF, 4), **common, "hbm_GBps_algorithmic": round(gbs, 1)}
+            "frac": round(tf / FP32_MFMA_PEAK_TF, 4), **common}
+
+
+def fit_roofline(n, d, l, n_iter, esz, mode, ms_per_step):
+    """Whole-fit fraction: the algorithmic floor of one RandomizedPca.fit -- (2 n_iter + 2) GEMM passes at their binding
+    roofline, one means pass (n d bytes) and U = Q.Uh (2 n l^2 flop, 2 n l bytes) -- over the measured time per fit."""
+    flops, nbytes = 2.0 * n * d * l, float(esz) * (n * d + n * l + d * l)
+    b = pass_bound(flops, nbytes, mode)
+    passes = 2 * n_iter + 2
+    means_s = esz * n * d / (HBM_PEAK_GBS * 1e9)
+    u_s = pass_bound(2.0 * n * l * l, float(esz) * 2 * n * l, mode)["floor_s"]
+    floor_ms = (passes * b["floor_s"] + means_s + u_s) * 1e3
+    return {"floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ms_per_step, 4) if ms_per_step > 0 else 0.0,
+            "passes": passes, "pass_floor_us": round(b["floor_s"] * 1e6, 2), "pass_pipe": b["pipe"],
+            "note": "floor = (2 n_iter + 2) GEMM passes at their binding roofline + the means pass + U = Q.Uh; the serial "
+                    "small-matrix steps between the passes have no floor of their own here"}
 
 
 def fp32_mode_extra(petal, ctx, model, x, omega, steps=10):

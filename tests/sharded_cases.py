@@ -105,11 +105,13 @@ def run_cfg5(petal, ctx, xs, rank):
 
 CASES = {
     "rpca32": {"x": x_rpca32, "run": run_rpca(np.float32, True), "both_modes": True},
+    "rpca32_rerun": {"x": x_rpca32, "run": run_rpca(np.float32, True), "both_modes": True},   # run-to-run determinism
     "rpca32_own_omega": {"x": x_rpca32, "run": run_rpca(np.float32, False)},
     "rpca64": {"x": lambda: x_rpca32().astype(np.float64), "run": run_rpca(np.float64, True)},
     "pca64": {"x": x_pca, "run": run_pca},
     "pca32": {"x": lambda: x_pca().astype(np.float32), "run": run_pca},
     "ica32": {"x": x_ica, "run": run_ica(True), "both_modes": True},
+    "ica32_rerun": {"x": x_ica, "run": run_ica(True), "both_modes": True},
     "ica32_own_w": {"x": x_ica, "run": run_ica(False)},
     "cfg4_share": {"x": x_cfg4, "run": run_cfg4},
     "cfg5_share": {"x": x_cfg5, "run": run_cfg5},

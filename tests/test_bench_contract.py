@@ -36,6 +36,30 @@ def _run(*extra, launcher_env=True, n_gpus=1):
     return rec
 
 
+def test_roofline_bound_is_computed_from_the_shape():
+    """bench.py picks the binding roofline per shape: at l = 74 (configs[1]) the X stream binds the split-product kernels
+    ("hbm"); at l = 138 (configs[3]) the six bf16 piece products take longer than the bytes ("mfma" on the bf16 pipe:
+    0.17 ms vs 0.145 ms per pass at 250000 x 1024); the fp32-MFMA mode is bound by the fp32 pipe at both."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for (n, d, l, mode, bound, pipe) in [(100000, 512, 74, "bf16x3", "hbm", "hbm"), (250000, 1024, 138, "bf16x3", "mfma", "mfma-bf16"),
+                                         (1000000, 512, 74, "bf16x3", "hbm", "hbm"),
+                                         (100000, 512, 74, "fp32", "mfma", "mfma-fp32"), (250000, 1024, 138, "fp32", "mfma", "mfma-fp32")]:
+        flops, nbytes = 2.0 * n * d * l, 4.0 * (n * d + n * l + d * l)
+        b = bench.pass_bound(flops, nbytes, mode)
+        assert (b["bound"], b["pipe"]) == (bound, pipe), (n, d, l, mode, b)
+        assert b["floor_s"] == max(b["times_s"].values())
+    # the entry itself: cfg4's K1 at 0.42 ms is 0.40 of the bf16 pipe, not 0.35 "of HBM"
+    flops, nbytes = 2.0 * 250000 * 1024 * 138, 4.0 * (250000 * 1024 + 250000 * 138 + 1024 * 138)
+    e = bench.roofline_entry("K1 (Z = Xc.P)", {"K1 (Z = Xc.P)": 0.42, "K2 (Y = Xc^T.Z)": 0.41}, flops, nbytes, "bf16x3", 0.0, 250000, 1024, 138)
+    assert e["bound"] == "mfma" and e["pipe"] == "mfma-bf16" and abs(e["frac"] - 0.404) < 0.002, e
+    assert abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-3
+    e = bench.roofline_entry("K2 (Y = Xc^T.Z)", {"K1 (Z = Xc.P)": 0.055, "K2 (Y = Xc^T.Z)": 0.0565}, 7577600000.0, 234551552.0, "bf16x3", 0.0, 100000, 512, 74)
+    assert e["bound"] == "hbm" and abs(e["frac"] - 0.519) < 0.002 and "fp32_equivalent_frac_of_fp32_mfma_peak" not in e
+    f = bench.fit_roofline(100000, 512, 74, 5, 4, "bf16x3", 1.39)
+    assert f["passes"] == 12 and 0.2 < f["frac"] < 0.35, f
+
+
 def test_help_runs_without_a_gpu():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and "--gpus" in res.stdout and "--steps" in res.stdout and "--warmup" in res.stdout

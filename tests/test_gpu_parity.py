@@ -130,7 +130,11 @@ def test_sizes_beyond_the_one_workgroup_kernels(ctx):
     pc.pca_parity(ctx, 6000, 2048, 8, seed=42, dtype=np.float64, tol=1e-8, thin_oracle=True)              # d = 2048, fp64
     pc.pca_parity(ctx, 6000, 2048, 8, seed=43, dtype=np.float32, tol=2e-5, thin_oracle=True)
     pc.ica_parity(ctx, 20000, 2048, 8, seed=44, dtype=np.float32, n_components=8)       # whitening at d = 2048
-    pc.ica_parity(ctx, 20000, 96, 96, seed=45, dtype=np.float32, tol_src=2e-2)          # nc = min(n, d) = 96 > 64 (crate default)
+    # nc = min(n, d) = 96 > 64 (crate default).  Why 2e-2 and not the 5e-3 of the other cases: with nc = d every direction is kept, so
+    # the whitening divides by the SMALLEST singular values (the 0.01-noise-floor ones when d > planted sources; here the mixing
+    # matrix is 96 x 96 Gaussian, cond ~ 1e3) -- the recovered sources carry the fp32 data error amplified by that factor, and
+    # the two runs stop at different points of the 1e-4 criterion; the loop itself at nc = 80 is held to 1e-7 on fp64 data below
+    pc.ica_parity(ctx, 20000, 96, 96, seed=45, dtype=np.float32, tol_src=2e-2)
     pc.ica_par_parity(ctx, 20000, 80, seed=46, dtype=np.float64, tol=1e-7)              # the loop itself at nc = 80, fp64
 
 
@@ -399,6 +403,61 @@ def test_cfg4_shard_shape_properties():
         c.close()
     assert np.allclose(comps["bf16x3"][1], comps["fp32"][1], rtol=1e-5)
     assert pc.rowwise_rel(comps["bf16x3"][0][:k // 2], comps["fp32"][0][:k // 2]).max() < 1e-4
+
+
+def test_run_to_run_bitwise_determinism(ctx):
+    """The same fit twice on one ctx, both GEMM modes (the ctx fixture): every output bit for bit.  Split-K partial slabs are
+    combined in a fixed order, nothing uses atomics, and the FastICA host loop's run-ahead only ever adds no-op launches."""
+    import torch
+    import petal_decomposition_amd as petal
+    x = torch.from_numpy(pc.po.synth_pca(50000, 512, 64, seed=3, dtype=np.float32)).cuda()
+    om = np.random.default_rng(4).standard_normal((512, 74)).astype(np.float32)
+    runs = []
+    for _ in range(2):
+        m = petal.RandomizedPca(64, ctx=ctx, n_iter=5)
+        y = m.fit_transform(x, omega=om)
+        runs.append((m.components().copy(), m.singular_values().copy(), m.explained_variance_ratio().copy(), y.cpu().numpy()))
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+    xi = torch.from_numpy(pc.po.synth_ica(100000, 64, 32, seed=5, dtype=np.float32)).cuda()
+    w0 = np.random.default_rng(6).standard_normal((32, 32)).astype(np.float32)
+    runs = []
+    for _ in range(2):
+        ica = petal.FastIca(ctx=ctx, n_components=32)
+        y = ica.fit_transform(xi, w_init=w0)
+        runs.append((ica.components.copy(), np.array([ica.n_iter]), y.cpu().numpy()))
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+    p = petal.Pca(8, ctx=ctx).fit(x)
+    q = petal.Pca(8, ctx=ctx).fit(x)
+    assert np.array_equal(p.components(), q.components()) and np.array_equal(p.singular_values(), q.singular_values())
+
+
+def test_cfg4_share_against_the_oracle():
+    """ONE rank's share of BASELINE configs[3] -- 250000 x 1024 fp32, k = 128 (l = 138), n_iter = 7 (src/pca.rs:680) -- against the
+    fp64 LAPACK oracle run from the same Omega (about a minute of host time on the GPU box), both GEMM modes: singular values to
+    1e-5, the leading k/2 components to 1e-5.  (The trailing half has 2.7 % spectral gaps next to the noise floor: in fp32
+    those vectors are determined to ~1e-7 sigma_1 / gap only; they are held to 5e-3 here and to 1e-8 by the fp64-data case of
+    test_sizes_beyond_the_one_workgroup_kernels.)"""
+    import torch
+    import petal_decomposition_amd as petal
+    from oracle import petal_oracle as po
+    n, d, k, n_iter = 250000, 1024, 128, 7
+    x = po.synth_pca(n, d, k, seed=4, dtype=np.float32)
+    om = np.random.default_rng(3).standard_normal((d, k + 10))
+    o = po.RandomizedPcaOracle(k, n_iter=n_iter).fit(x.astype(np.float64), omega=om)
+    xd = torch.from_numpy(x).cuda()
+    for mode in ("bf16x3", "fp32"):
+        c = petal.Context(0)
+        c.set_gemm_mode(mode)
+        m = petal.RandomizedPca(k, ctx=c, n_iter=n_iter).fit(xd, omega=om.astype(np.float32))
+        rel = pc.rowwise_rel(m.components().astype(np.float64), o.components)
+        assert rel[: k // 2].max() <= 1e-5, (mode, rel[: k // 2].max())
+        assert rel.max() <= 5e-3, (mode, rel.max())
+        assert np.allclose(m.singular_values(), o.singular, rtol=1e-5, atol=0), (mode, np.abs(m.singular_values() / o.singular - 1).max())
+        assert np.allclose(m.explained_variance_ratio(), o.explained_variance_ratio(), rtol=4e-5, atol=0)
+        assert np.abs(m.mean() - o.means).max() <= 1e-6 * max(1.0, np.abs(o.means).max())
+        c.close()
 
 
 def test_cfg5_shard_shape_source_recovery(ctx):

@@ -72,6 +72,18 @@ def test_replicated_outputs_are_bit_identical_on_every_rank(ranks):
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+def test_sharded_fits_are_bitwise_reproducible_run_to_run(ranks, mode):
+    """the same sharded fit twice in one process: every output -- replicated ones and each rank's rows of fit_transform -- bit
+    for bit (deterministic two-stage reductions, no atomics)"""
+    for r in ranks:
+        for case in ("rpca32", "ica32"):
+            keys = [k for k in r.files if k.startswith(f"{case}.{mode}.")]
+            assert keys
+            for k in keys:
+                assert np.array_equal(r[k], r[k.replace(f"{case}.", f"{case}_rerun.")]), k
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
 def test_sharded_rpca_fp32_matches_single_and_oracle(ranks, mode):
     import petal_decomposition_amd as petal
     from oracle import petal_oracle as po
