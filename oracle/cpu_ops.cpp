@@ -202,7 +202,36 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
         }
     }
 }
-void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool /*clustered*/, int64_t Lz) {
+void op_ritz_residual(Dev*, const double* CV, const double* Vr, int64_t rows, int64_t ld, int64_t nc, const double* theta, double* out3) {
+    double worst = 0, bad = 0;
+    for (int64_t j = 0; j < nc; ++j) {
+        double s2 = 0;
+        for (int64_t i = 0; i < rows; ++i) { const double r = CV[i * ld + j] - theta[j] * Vr[i * ld + j]; s2 += r * r; }
+        if (!std::isfinite(s2)) bad = 1;
+        else worst = std::max(worst, s2);
+    }
+    out3[0] = worst; out3[1] = theta[0]; out3[2] = bad;
+}
+void op_whiten_k(Dev*, const double* U, int64_t ldu, const double* lam, int64_t rows, int64_t nc, int64_t ncp, double scale,
+                 double* KT, double* KTs) {
+    for (int64_t j = 0; j < ncp; ++j) {
+        double f = 0;
+        if (j < nc) {  // sign normalisation: first component of largest magnitude positive (see hip_ops.hip)
+            double best = -1.0, sgn = 1.0;
+            for (int64_t i = 0; i < rows; ++i)
+                if (std::fabs(U[i * ldu + j]) > best) { best = std::fabs(U[i * ldu + j]); sgn = U[i * ldu + j] < 0 ? -1.0 : 1.0; }
+            const double sg = std::sqrt(std::max(lam[j], 0.0));
+            f = sg > 0 ? sgn / sg : 0.0;
+        }
+        for (int64_t i = 0; i < rows; ++i) {
+            const double v = j < nc ? U[i * ldu + j] * f : 0.0;
+            KT[i * ncp + j] = v;
+            KTs[i * ncp + j] = v * scale;
+        }
+    }
+}
+void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool /*clustered*/, int64_t Lz,
+             int64_t /*ncheck*/) {
     for (int64_t r = 0; r < Lz; ++r)
         for (int64_t c = 0; c < Lz; ++c)
             if (r >= L || c >= L) V[r * ldv + c] = 0.0;

@@ -200,15 +200,32 @@ void orthonormalize_small(petal_ctx& c, DBuf& Y, int64_t M, int64_t L, int64_t L
 // Top-nc eigenpairs of the symmetric PSD matrix C (dp x dp fp64, device) by block subspace iteration with
 // Rayleigh-Ritz, all in fp64 on the small-matrix kernels.  The one-workgroup Jacobi solver needs ~150 ms at d = 256
 // (its matrices do not fit LDS); when only nc << d pairs are wanted (FastICA with n_components, Pca with k < d) a
-// block of p = nc + 16 vectors converges in a few products.  On success V[:, :nc] (ld = dp) and w[:nc] are filled and
-// true is returned; otherwise the caller runs the full solver.  Convergence: ||C v - w v|| <= 1e-12 w_0 for every pair.
-bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc, double* V, double* w) {
+// block of p = nc + 16 vectors converges in a few products.  Convergence: ||C v - w v|| <= 1e-12 w_0 for every wanted pair.
+//
+// Two ways to run it:
+//  * resid3 == nullptr (synchronous): products and Rayleigh-Ritz steps until the residuals pass, a host round trip per
+//    Rayleigh-Ritz step; returns false when the shape does not qualify or 40 products did not converge (the caller then
+//    runs the full solver).
+//  * resid3 != nullptr (optimistic): exactly two products and ONE Rayleigh-Ritz step are enqueued -- what the synchronous
+//    loop needs on every spectrum with a gap behind the wanted pairs -- V / w are written and the residual verdict goes to
+//    resid3 (device, 3 doubles: op_ritz_residual) for the caller to read with its own results: no host synchronisation
+//    here.  topk_verdict_ok() decodes it; a caller that finds it failed redoes its fit with the synchronous form.
+// The Ritz problem (order p) goes to the two-stage eigen-solver with the closeness verdict restricted to the nc wanted
+// pairs: the unconverged tail of the block is a cluster of noise-level Ritz values whose vectors only have to span it.
+bool topk_applies(int64_t d, int64_t dp, int64_t nc) {
     const int64_t p = std::min<int64_t>(round_up(nc + 16, 16), dp);
-    if (nc <= 0 || p >= d || d <= 88 || p > 512) return false;  // (beyond that the Rayleigh-Ritz solves cost more than they save)
+    return !(nc <= 0 || p >= d || d <= 88 || p > 512);  // (beyond that the Rayleigh-Ritz solves cost more than they save)
+}
+bool topk_verdict_ok(const double* r3) {
+    return r3[2] == 0.0 && std::isfinite(r3[0]) && r3[1] > 0 && std::sqrt(std::max(r3[0], 0.0)) <= 1e-12 * r3[1];
+}
+bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc, double* V, double* w, double* resid3 = nullptr) {
+    if (!topk_applies(d, dp, nc)) return false;
+    const int64_t p = std::min<int64_t>(round_up(nc + 16, 16), dp);
     Dev* dv = c.dev;
     DBuf Q(dv, sizeof(double) * dp * p), Y(dv, sizeof(double) * dp * p), G(dv, sizeof(double) * p * p), T(dv, sizeof(double) * p * p);
     DBuf H(dv, sizeof(double) * p * p), S(dv, sizeof(double) * p * p), th(dv, sizeof(double) * p), R(dv, sizeof(double) * dp * p);
-    DBuf QS(dv, sizeof(double) * dp * p);
+    DBuf QS(dv, sizeof(double) * dp * p), r3(dv, sizeof(double) * 3);
     {
         std::vector<double> h(size_t(dp) * p, 0.0);
         uint64_t st = 0x9E3779B97F4A7C15ull;
@@ -217,7 +234,7 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
                 st = st * 6364136223846793005ull + 1442695040888963407ull;
                 h[size_t(i) * p + j] = double(int64_t(st >> 11)) / double(1ll << 52) - 1.0;
             }
-        dev_h2d(dv, Y.p, h.data(), Y.bytes);
+        dev_h2d_async(dv, Y.p, h.data(), Y.bytes);   // (through the pinned ring: no host wait)
     }
     auto orth = [&](DBuf& src, DBuf& dst) {  // dst = orthonormal basis of range(src), two Cholesky-QR rounds
         const double* in = src.f64();
@@ -229,31 +246,32 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
             in = out;
         }
     };
-    std::vector<double> hG(size_t(p) * p), hth(p);
+    auto rayleigh_ritz = [&](double* out3) {  // Ritz pairs (QS, th), their images R = C (Q S) and the residual verdict
+        op_dgemm(dv, true, false, p, p, dp, 1.0, Q.f64(), p, Y.f64(), p, 0.0, H.f64(), p);    // Rayleigh quotient
+        op_eigh(dv, H.f64(), p, p, S.f64(), p, th.f64(), 1e-15, false, 0, nc);
+        op_dgemm(dv, false, false, dp, p, p, 1.0, Q.f64(), p, S.f64(), p, 0.0, QS.f64(), p);  // Ritz vectors
+        op_dgemm(dv, false, false, dp, p, p, 1.0, Y.f64(), p, S.f64(), p, 0.0, R.f64(), p);   // C (Q S)
+        op_ritz_residual(dv, R.f64(), QS.f64(), dp, p, nc, th.f64(), out3);
+    };
+    auto deliver = [&] {
+        dev_copy2d(dv, V, dp * sizeof(double), QS.p, p * sizeof(double), size_t(nc) * sizeof(double), size_t(dp), 2);
+        dev_d2d(dv, w, th.p, sizeof(double) * nc);
+    };
+    double h3[3];
     for (int it = 0; it < 40; ++it) {
         if (it == 0) op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, Y.f64(), p, 0.0, R.f64(), p), std::swap(Y, R);
         orth(Y, Q);
         op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, Q.f64(), p, 0.0, Y.f64(), p);  // Y = C Q
         if (it % 2 == 1) {  // Rayleigh-Ritz + residual check every second product (never converged after the first)
-            op_dgemm(dv, true, false, p, p, dp, 1.0, Q.f64(), p, Y.f64(), p, 0.0, H.f64(), p);  // Rayleigh quotient
-            op_eigh(dv, H.f64(), p, p, S.f64(), p, th.f64(), 1e-15, true);  // Ritz values: the unconverged tail is a cluster
-            op_dgemm(dv, false, false, dp, p, p, 1.0, Q.f64(), p, S.f64(), p, 0.0, QS.f64(), p);  // Ritz vectors
-            op_dgemm(dv, false, false, dp, p, p, 1.0, Y.f64(), p, S.f64(), p, 0.0, R.f64(), p);   // C (Q S)
-            DBuf QST(dv, QS.bytes);                                                               // (Q S) diag(theta)
-            dev_d2d(dv, QST.p, QS.p, QS.bytes);
-            op_dscale_cols(dv, QST.f64(), dp, p, p, th.f64());
-            op_daxpy(dv, dp * p, -1.0, QST.f64(), R.f64());                                       // residuals
-            op_dgemm(dv, true, false, p, p, dp, 1.0, R.f64(), p, R.f64(), p, 0.0, G.f64(), p);
-            dev_d2h(dv, hG.data(), G.p, G.bytes);
-            dev_d2h(dv, hth.data(), th.p, th.bytes);
-            dev_sync(dv);
-            double worst = 0;
-            for (int64_t j = 0; j < nc; ++j) worst = std::max(worst, std::sqrt(std::max(hG[size_t(j) * p + j], 0.0)));
-            if (std::isfinite(worst) && hth[0] > 0 && worst <= 1e-12 * hth[0]) {
-                dev_copy2d(dv, V, dp * sizeof(double), QS.p, p * sizeof(double), size_t(nc) * sizeof(double), size_t(dp), 2);
-                dev_d2d(dv, w, th.p, sizeof(double) * nc);
+            if (resid3) {
+                rayleigh_ritz(resid3);
+                deliver();
                 return true;
             }
+            rayleigh_ritz(r3.f64());
+            dev_d2h(dv, h3, r3.p, sizeof(h3));
+            dev_sync(dv);
+            if (topk_verdict_ok(h3)) { deliver(); return true; }
         }
     }
     return false;
@@ -739,28 +757,40 @@ int64_t ica_loop(petal_ctx& c, int dt, const void* X1T, int64_t n, int64_t nc, i
         allreduce_f64(c, GX.f64(), nc * nc + nc, PETAL_SUM);
         op_ica_tail(c.dev, nc, n_total, W.f64(), GX.f64(), mode, tol, state.as<int>(), int(it), progress);  // ica.rs:334-358
     };
+    int64_t n_iter = -1;
     if (!sharded(c)) {
         // Converged iterations are no-ops on the device.  The host follows the loop WITHOUT synchronising: the tail kernel
         // stores {converged at, iterations done} to pinned host memory, the host enqueues iteration `it` once the device has
         // finished iteration it - RUN_AHEAD (so the queue never runs dry and never runs far ahead) and stops at the flag: at
         // most RUN_AHEAD no-op iterations are launched after convergence (the round-1 schedule synchronised after 4, 12, 28,
         // ... iterations: two round trips and up to three wasted iterations for a fit that converges at iteration 9).
+        // The iteration count itself comes from those words too: the loop ends without a synchronisation of its own.
         constexpr int64_t RUN_AHEAD = 2;
         volatile int* hp = dev_host_progress(c.dev);
         hp[0] = 0; hp[1] = 0;
         auto t_progress = std::chrono::steady_clock::now();  // when the device last reported a finished iteration
         int last_seen = 0;
-        for (int64_t it = 0; it < max_iter && !hp[0]; ++it) {
+        bool synced = false;
+        int64_t it = 0;
+        for (; it < max_iter && !hp[0]; ++it) {
             int spins = 0;
             while (!hp[0] && it - int64_t(hp[1]) >= RUN_AHEAD) {
                 if ((++spins & 0xFFFF) != 0) continue;
                 const auto now = std::chrono::steady_clock::now();
                 if (hp[1] != last_seen) { last_seen = hp[1]; t_progress = now; }
                 // a device that stopped reporting for 30 s (not: a fit that has been running for 30 s): blocking wait
-                if (std::chrono::duration<double>(now - t_progress).count() > 30.0) { dev_sync(c.dev); t_progress = now; break; }
+                if (std::chrono::duration<double>(now - t_progress).count() > 30.0) { dev_sync(c.dev); t_progress = now; synced = true; break; }
             }
             if (hp[0]) break;
             enqueue(it, const_cast<int*>(hp));
+        }
+        if (hp[0]) {
+            n_iter = hp[0];                       // converged: the tail kernel published the iteration it stopped at
+        } else {                                  // ran to max_iter (or the progress words failed): the device state decides
+            (void)synced;
+            dev_d2h(c.dev, hstate, state.p, sizeof(hstate));
+            dev_sync(c.dev);
+            n_iter = hstate[0] ? hstate[1] : max_iter;
         }
     } else {
         // several ranks: every rank must enqueue the SAME number of iterations (each carries an all-reduce), so the flag --
@@ -773,10 +803,8 @@ int64_t ica_loop(petal_ctx& c, int dt, const void* X1T, int64_t n, int64_t nc, i
             dev_sync(c.dev);
             if (hstate[0]) break;
         }
+        n_iter = hstate[0] ? hstate[1] : max_iter;
     }
-    dev_d2h(c.dev, hstate, state.p, sizeof(hstate));
-    dev_sync(c.dev);
-    const int64_t n_iter = hstate[0] ? hstate[1] : max_iter;
     c.stats.n_iter = n_iter;
     c.stats.ica_step_flops = 4.0 * double(nc) * nc * double(n);
     c.stats.ica_step_bytes = double(dtype_size(dt)) * nc * double(n);
@@ -826,45 +854,50 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
     DBuf mu64, muT;
     column_means(c, X, ri.n_total, true, mu64, muT, false, sharded(c) ? pro.sums : nullptr);
 
-    // whitening (ica.rs:189-208): left singular vectors / values of Xc^T == eigenpairs of Xc^T Xc
-    DBuf C(c.dev, sizeof(double) * dp * dp), U(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp);
-    DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp);
-    op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
-    allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
-    dev_memset(c.dev, U.p, 0, U.bytes);
-    dev_memset(c.dev, lam.p, 0, lam.bytes);
-    if (!topk_eigh(c, C.f64(), d, dp, nc, U.f64(), lam.f64()))  // only the first nc pairs are used below
-        op_eigh(c.dev, C.f64(), d, dp, U.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
-    op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
-    op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, 0.0);
-    op_dscale_cols(c.dev, U.f64(), dp, dp, dp, inv.f64());  // U[:, i] / sigma_i  == K^T (ica.rs:190-203)
-    DBuf KT(c.dev, sizeof(double) * dp * ncp);              // K^T, first nc columns, zero padded
-    dev_memset(c.dev, KT.p, 0, KT.bytes);
-    dev_copy2d(c.dev, KT.p, ncp * sizeof(double), U.p, dp * sizeof(double), size_t(nc) * sizeof(double), size_t(dp), 2);
-    DBuf KTs(c.dev, KT.bytes);                              // K^T sqrt(n) (ica.rs:204-208)
-    dev_d2d(c.dev, KTs.p, KT.p, KT.bytes);
-    op_dscal(c.dev, KTs.f64(), dp * ncp, std::sqrt(ri.n_total));
-    DBuf X1T(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * ncp);
-    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, KTs.f64(), ncp, ncp, nullptr, X1T.p, ncp, nullptr);
-
-    DBuf W(c.dev, sizeof(double) * nc * nc);
-    if (sharded(c)) {  // rank 0's draw, from the prologue's all-reduce
-        dev_d2d(c.dev, W.p, pro.draw, W.bytes);
-    } else {
-        std::vector<double> h(size_t(nc) * nc);
-        for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
-        dev_h2d(c.dev, W.p, h.data(), W.bytes);
-    }
-    const int64_t iters = ica_loop(c, dt, X1T.p, n, nc, ncp, ri.n_total, W, tol, max_iter, mode);  // ica.rs:216
-    if (n_iter) *n_iter = iters;
-
-    // components = W K (ica.rs:217)
-    DBuf Cm(c.dev, sizeof(double) * nc * dp);
-    op_dgemm(c.dev, false, true, nc, dp, nc, 1.0, W.f64(), nc, KT.f64(), ncp, 0.0, Cm.f64(), dp);
+    // The whole device pipeline.  It runs OPTIMISTICALLY first: the whitening's eigenpairs come from two products and one
+    // Rayleigh-Ritz step of the subspace iteration with no host round trip, whose residual verdict is read together with the
+    // results; only if that verdict fails is the fit redone with the synchronous, residual-controlled iteration.
     std::vector<double> hC(size_t(nc) * dp), hmu(dp);
-    dev_d2h(c.dev, hC.data(), Cm.p, Cm.bytes);
-    dev_d2h(c.dev, hmu.data(), mu64.p, mu64.bytes);
-    dev_sync(c.dev);
+    DBuf X1T(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * ncp);
+    int64_t iters = 0;
+    auto pipeline = [&](bool optimistic) -> bool {
+        // whitening (ica.rs:189-208): left singular vectors / values of Xc^T == eigenpairs of Xc^T Xc
+        DBuf C(c.dev, sizeof(double) * dp * dp), U(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp), r3(c.dev, sizeof(double) * 3);
+        op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
+        allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
+        const bool topk = topk_eigh(c, C.f64(), d, dp, nc, U.f64(), lam.f64(), optimistic ? r3.f64() : nullptr);  // only the first nc pairs are used below
+        if (!topk) {
+            dev_memset(c.dev, U.p, 0, U.bytes);
+            dev_memset(c.dev, lam.p, 0, lam.bytes);
+            op_eigh(c.dev, C.f64(), d, dp, U.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
+        }
+        // K^T = U[:, :nc] / sigma (ica.rs:190-203), zero padded, and K^T sqrt(n) (ica.rs:204-208), one launch
+        DBuf KT(c.dev, sizeof(double) * dp * ncp), KTs(c.dev, sizeof(double) * dp * ncp);
+        op_whiten_k(c.dev, U.f64(), dp, lam.f64(), dp, nc, ncp, std::sqrt(ri.n_total), KT.f64(), KTs.f64());
+        op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, KTs.f64(), ncp, ncp, nullptr, X1T.p, ncp, nullptr);
+
+        DBuf W(c.dev, sizeof(double) * nc * nc);
+        if (sharded(c)) {  // rank 0's draw, from the prologue's all-reduce
+            dev_d2d(c.dev, W.p, pro.draw, W.bytes);
+        } else {
+            std::vector<double> h(size_t(nc) * nc);
+            for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
+            dev_h2d_async(c.dev, W.p, h.data(), W.bytes);  // (staged through the pinned ring: no host wait)
+        }
+        iters = ica_loop(c, dt, X1T.p, n, nc, ncp, ri.n_total, W, tol, max_iter, mode);  // ica.rs:216
+
+        // components = W K (ica.rs:217); everything the host reads comes back behind ONE synchronisation
+        DBuf Cm(c.dev, sizeof(double) * nc * dp);
+        op_dgemm(c.dev, false, true, nc, dp, nc, 1.0, W.f64(), nc, KT.f64(), ncp, 0.0, Cm.f64(), dp);
+        double h3[3] = {0, 1, 0};
+        dev_d2h(c.dev, hC.data(), Cm.p, Cm.bytes);
+        dev_d2h(c.dev, hmu.data(), mu64.p, sizeof(double) * dp);
+        if (topk && optimistic) dev_d2h(c.dev, h3, r3.p, sizeof(h3));
+        dev_sync(c.dev);
+        return !(topk && optimistic) || topk_verdict_ok(h3);
+    };
+    if (!pipeline(true)) pipeline(false);
+    if (n_iter) *n_iter = iters;
     check_finite_w(hC);
     for (int64_t i = 0; i < nc; ++i)
         for (int64_t j = 0; j < d; ++j) put_elem(components, dt, i * d + j, hC[size_t(i) * dp + j]);

@@ -134,8 +134,23 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
 // subspace iteration: a block of noise-level eigenvalues) -- go to the Jacobi solver directly instead of paying for both
 // Lz > L: V is an Lz x Lz matrix (leading dimension ldv) whose rows / columns L .. Lz - 1 must come out zero (padding for the
 // GEMM kernels); the solver's first kernel writes those zeros itself, which saves the caller a memset launch.
+// ncheck > 0: only the leading ncheck eigenpairs are delivered to full accuracy -- the two-stage solver's closeness verdict
+// looks at those alone (a cluster further down, e.g. the noise-level Ritz values of a subspace iteration, gets vectors that
+// are accurate to eps ||A|| / gap only and need not be mutually orthogonal; it no longer sends the whole problem to Jacobi).
 void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel = 1e-15,
-             bool clustered = false, int64_t Lz = 0);
+             bool clustered = false, int64_t Lz = 0, int64_t ncheck = 0);
+// Residual verdict of a Rayleigh-Ritz step without a host round trip: with the Ritz vectors Vr (rows x >= nc, ld), their
+// images CV = C Vr and the Ritz values theta,  out[0] = max_{j < nc} ||CV[:, j] - theta_j Vr[:, j]||_2^2,  out[1] = theta[0],
+// out[2] = 1 if one of those nc norms is not finite.  One launch; the caller reads `out` with its other results.
+void op_ritz_residual(Dev*, const double* CV, const double* Vr, int64_t rows, int64_t ld, int64_t nc, const double* theta, double* out3);
+// FastICA whitening matrix from the eigenpairs of the covariance (ica.rs:190-208) in one launch:
+//   KT[i][j]  = s_j U[i][j] / sigma_j,  sigma_j = sqrt(max(lam_j, 0)) (0 where sigma_j == 0),  j < nc;  0 for nc <= j < ncp
+//   s_j = +-1 normalises the eigenvector's sign: its first component of largest magnitude becomes positive (an eigen-solver's
+//   own sign is arbitrary and may flip under a last-bit perturbation; the whitening rows must not)
+//   KTs[i][j] = KT[i][j] * scale          (scale = sqrt(n): X1 = K X sqrt(n))
+// U: rows x >= nc (ldu), KT / KTs: rows x ncp.
+void op_whiten_k(Dev*, const double* U, int64_t ldu, const double* lam, int64_t rows, int64_t nc, int64_t ncp, double scale,
+                 double* KT, double* KTs);
 // x[i] *= alpha
 void op_dscal(Dev*, double* x, int64_t count, double alpha);
 // y[i] += alpha * x[i]
