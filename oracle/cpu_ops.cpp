@@ -283,6 +283,38 @@ void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, do
     for (int64_t i = 0; i < L; ++i)
         for (int64_t j = 0; j < L; ++j) V[i * ldv + j] = Vs[i * L + j];
 }
+void op_jacobi_svd_rows(Dev*, double* A, int64_t L, int64_t lda, double* U, int64_t ldu, double* s_inv) {
+    std::vector<double> G(size_t(L) * L, 0.0);
+    for (int64_t i = 0; i < L; ++i) G[i * L + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int64_t p = 0; p < L - 1; ++p)
+            for (int64_t q = p + 1; q < L; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int64_t j = 0; j < L; ++j) { al += A[p * lda + j] * A[p * lda + j]; be += A[q * lda + j] * A[q * lda + j]; ga += A[p * lda + j] * A[q * lda + j]; }
+                if (!(std::fabs(ga) > 1e-15 * std::sqrt(al * be))) continue;
+                rotated = true;
+                const double zeta = (be - al) / (2 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
+                const double cs = 1 / std::sqrt(1 + t * t), sn = cs * t;
+                for (int64_t j = 0; j < L; ++j) {
+                    const double ap = A[p * lda + j], aq = A[q * lda + j];
+                    A[p * lda + j] = cs * ap - sn * aq; A[q * lda + j] = sn * ap + cs * aq;
+                    const double gp = G[p * L + j], gq = G[q * L + j];
+                    G[p * L + j] = cs * gp - sn * gq; G[q * L + j] = sn * gp + cs * gq;
+                }
+            }
+        if (!rotated) break;
+    }
+    std::vector<double> nrm(L);
+    std::vector<int64_t> idx(L);
+    for (int64_t i = 0; i < L; ++i) { double a = 0; for (int64_t j = 0; j < L; ++j) a += A[i * lda + j] * A[i * lda + j]; nrm[i] = std::sqrt(a); idx[i] = i; }
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return nrm[a] < nrm[b]; });
+    for (int64_t j = 0; j < L; ++j) {
+        s_inv[j] = nrm[idx[j]] > 0 ? 1.0 / nrm[idx[j]] : 0.0;
+        for (int64_t i = 0; i < L; ++i) U[i * ldu + j] = G[idx[j] * L + i];
+    }
+}
 void op_dscal(Dev*, double* x, int64_t count, double alpha) {
     for (int64_t i = 0; i < count; ++i) x[i] *= alpha;
 }
@@ -293,6 +325,7 @@ void op_dvec(Dev*, int mode, const double* x, double* y, int64_t count, double t
     const double x0 = count ? x[0] : 0;
     for (int64_t i = 0; i < count; ++i) {
         if (mode == 0) y[i] = std::sqrt(std::max(x[i], 0.0));
+        else if (mode == 2) y[i] = x[i] * x[i];
         else y[i] = (x[i] > thr * x0 && x[i] > 0) ? 1.0 / x[i] : 0.0;
     }
 }

@@ -277,6 +277,36 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
     return false;
 }
 
+// fp64 data whose wanted singular values fall below the accuracy floor of the Gram routes (an eigen-decomposition of
+// Xc^T Xc keeps sigma_k to eps (sigma_1 / sigma_k)^2; the crate's gesvd, linalg.rs:70-91, to eps sigma_1 / sigma_k): thin QR of
+// Xc by Cholesky-QR2 in fp64 -- T1 = chol(Xc^T Xc)^-1, Q1 = Xc T1, T2 = chol(Q1^T Q1)^-1, R^-1 = T1 T2, two more passes
+// over X -- and a one-sided Jacobi SVD of R^-1, whose left singular vectors are the right singular vectors of Xc.
+// C: the (all-reduced) Gram matrix Xc^T Xc.  Fills V (leading d x d block, ld = dp: column j = right singular vector j) and
+// sig (d values, descending).  Returns false, nothing written, when a Cholesky pivot broke down (kappa beyond ~1e7 or
+// rank-deficient data: the caller keeps the Gram-route result) or the order is beyond the one-workgroup Jacobi kernel.
+bool accurate_small_svd(petal_ctx& c, const DevMat& X, const void* muT, const double* C, int64_t d, double* V, double* sig) {
+    const int64_t dp = X.dp, n = X.n;
+    if (X.dtype != F64 || d > 1024 || d < 1) return false;
+    Dev* dv = c.dev;
+    DBuf T1(dv, sizeof(double) * dp * dp), T2(dv, sizeof(double) * dp * dp), T(dv, sizeof(double) * dp * dp), G2(dv, sizeof(double) * dp * dp);
+    DBuf nd(dv, 64), Q1(dv, sizeof(double) * size_t(std::max<int64_t>(n, 1)) * dp);
+    dev_memset(dv, nd.p, 0, nd.bytes);
+    op_chol_inv(dv, C, d, dp, T1.f64(), dp, 1e-15, nd.as<int>(), dp);
+    op_gemm_xp(dv, F64, X.p, n, dp, X.ld, muT, T1.f64(), dp, dp, nullptr, Q1.p, dp, nullptr);
+    op_gemm_atb(dv, F64, Q1.p, dp, dp, nullptr, Q1.p, dp, dp, nullptr, n, G2.f64(), dp, true);
+    allreduce_f64(c, G2.f64(), dp * dp, PETAL_SUM);
+    op_chol_inv(dv, G2.f64(), d, dp, T2.f64(), dp, 1e-15, nd.as<int>(), dp);
+    op_dgemm(dv, false, false, dp, dp, dp, 1.0, T1.f64(), dp, T2.f64(), dp, 0.0, T.f64(), dp);
+    int hdead = 0;
+    dev_d2h(dv, &hdead, nd.p, sizeof(int));
+    dev_sync(dv);
+    if (hdead != 0) return false;
+    op_jacobi_svd_rows(dv, T.f64(), d, dp, V, dp, sig);
+    return true;
+}
+// (sigma_k / sigma_1 of the Gram route's own eigenvalues below this: its sigma_k is no longer good to 1e-9)
+constexpr double GRAM_ROUTE_FLOOR = 3.1622776601683794e-4;  // 10^-3.5
+
 struct Timer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
@@ -646,11 +676,23 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     dev_memset(c.dev, V.p, 0, V.bytes);
     dev_memset(c.dev, lam.p, 0, lam.bytes);
     // only the top-k pairs reach the outputs (components, singular values, the k columns of U that svd_flip signs)
+    DBuf Ckeep;  // (the eigen-solvers may destroy their input; the accurate route of fp64 fits factors the Gram matrix again)
+    if (dt == F64) { Ckeep = DBuf(c.dev, C.bytes); dev_d2d(c.dev, Ckeep.p, C.p, C.bytes); }
     const bool partial = topk_eigh(c, C.f64(), d, dp, k, V.f64(), lam.f64());
     // (order d, not the padded dp: the zero padding would only add dp - d exact zero eigenvalues, a cluster that sends the
     // two-stage solver to its Jacobi fallback; V and lam beyond d stay at the zeros set above)
     if (!partial) op_eigh(c.dev, C.f64(), d, dp, V.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
-    op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
+    // fp64 data with wanted singular values below 10^-3.5 sigma_1 (by the Gram route's own estimate): the QR + one-sided
+    // Jacobi route keeps them to eps sigma_1 / sigma_k like the crate's gesvd (linalg.rs:70-91); two more passes over X
+    bool accurate = false;
+    if (dt == F64 && k > 0) {
+        std::vector<double> hl(k);
+        dev_d2h(c.dev, hl.data(), lam.p, sizeof(double) * k);
+        dev_sync(c.dev);
+        const double ratio = (hl[0] > 0 && hl[k - 1] > 0) ? std::sqrt(hl[k - 1] / hl[0]) : 0.0;
+        if (ratio < GRAM_ROUTE_FLOOR) accurate = accurate_small_svd(c, X, muT.p, Ckeep.f64(), d, V.f64(), sig.f64());
+    }
+    if (!accurate) op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
     op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, dt == F32 ? 1e-6 : 1e-10);
 
     // U[:, j] = Xc v_j / sigma_j for j < r: only the columns svd_flip looks at (all min(n, d) of them in the crate;
@@ -865,11 +907,23 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         DBuf C(c.dev, sizeof(double) * dp * dp), U(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp), r3(c.dev, sizeof(double) * 3);
         op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
         allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
+        DBuf Ckeep;  // (see pca_fit)
+        if (dt == F64) { Ckeep = DBuf(c.dev, C.bytes); dev_d2d(c.dev, Ckeep.p, C.p, C.bytes); }
         const bool topk = topk_eigh(c, C.f64(), d, dp, nc, U.f64(), lam.f64(), optimistic ? r3.f64() : nullptr);  // only the first nc pairs are used below
         if (!topk) {
             dev_memset(c.dev, U.p, 0, U.bytes);
             dev_memset(c.dev, lam.p, 0, lam.bytes);
             op_eigh(c.dev, C.f64(), d, dp, U.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
+        }
+        if (dt == F64) {  // the whitening divides by sigma: below the Gram route's floor take the accurate route (see pca_fit)
+            std::vector<double> hl(nc);
+            dev_d2h(c.dev, hl.data(), lam.p, sizeof(double) * nc);
+            dev_sync(c.dev);
+            const double ratio = (hl[0] > 0 && hl[nc - 1] > 0) ? std::sqrt(hl[nc - 1] / hl[0]) : 0.0;
+            if (ratio < GRAM_ROUTE_FLOOR) {
+                DBuf sg(c.dev, sizeof(double) * dp);
+                if (accurate_small_svd(c, X, muT.p, Ckeep.f64(), d, U.f64(), sg.f64())) op_dvec(c.dev, 2, sg.f64(), lam.f64(), d, 0.0);
+            }
         }
         // K^T = U[:, :nc] / sigma (ica.rs:190-203), zero padded, and K^T sqrt(n) (ica.rs:204-208), one launch
         DBuf KT(c.dev, sizeof(double) * dp * ncp), KTs(c.dev, sizeof(double) * dp * ncp);

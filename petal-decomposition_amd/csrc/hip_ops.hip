@@ -958,6 +958,13 @@ __global__ __launch_bounds__(64 * WVK, PETAL_XP3_OCC) void k_xp3(const float* __
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) load_a(s < nchunk ? s : nchunk - 1, a[s]);
     store_p(0, pn);
+#ifdef PETAL_DEBUG_COUNTERS
+    long long ph[6] = {0, 0, 0, 0, 0, 0};
+    long long tq = __builtin_amdgcn_s_memtime();
+#define XP3_STAMP(i) do { const long long _t = __builtin_amdgcn_s_memtime(); ph[i] += _t - tq; tq = _t; } while (0)
+#else
+#define XP3_STAMP(i) do {} while (0)
+#endif
     for (int c0 = 0; c0 < nchunk; c0 += DEPTH) {
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) {
@@ -965,6 +972,11 @@ __global__ __launch_bounds__(64 * WVK, PETAL_XP3_OCC) void k_xp3(const float* __
             if (c >= nchunk) break;
             const int buf = c & 1;
             __syncthreads();  // chunk c is in sP[buf]; nobody still reads sP[buf ^ 1]
+            XP3_STAMP(0);
+#ifdef PETAL_DEBUG_COUNTERS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            XP3_STAMP(1);
+#endif
             // the raw fragments are dead once split: their registers take the loads of chunk c + DEPTH, which then fly
             // under the MFMAs of DEPTH chunks
             bf16x8 ah[RT], am[RT], al[RT];
@@ -981,11 +993,13 @@ __global__ __launch_bounds__(64 * WVK, PETAL_XP3_OCC) void k_xp3(const float* __
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            XP3_STAMP(2);
             // P first: its registers are waited for at the end of this chunk, and vmcnt retires in order -- X loads issued
             // BEFORE it would be drained by that wait, the ones issued after it stay in flight
             if (c + 1 < nchunk) load_p(c + 1, pn);
             if (c + DEPTH < nchunk) load_a(c + DEPTH, a[s]);
             __builtin_amdgcn_sched_barrier(0);
+            XP3_STAMP(3);
             // P fragments one tile ahead of the MFMAs that use them (pinned: hoisting all 15 reads costs 48 more registers)
             const bf16x8* sPb = sP + buf * PITEMS + lane;
             bf16x8 bh = sPb[0], bm = sPb[64], bl = sPb[128];
@@ -1009,9 +1023,17 @@ __global__ __launch_bounds__(64 * WVK, PETAL_XP3_OCC) void k_xp3(const float* __
                 bh = nh; bm = nm; bl = nl;
             }
             __builtin_amdgcn_sched_barrier(0);
+            XP3_STAMP(4);
             if (c + 1 < nchunk) store_p(buf ^ 1, pn);
+            XP3_STAMP(5);
         }
     }
+#ifdef PETAL_DEBUG_COUNTERS
+    if (lane == 0) {
+        for (int e = 0; e < 6; ++e) atomicAdd((unsigned long long*)&g_cyc[20 + e], (unsigned long long)ph[e]);
+        atomicAdd((unsigned long long*)&g_cyc[26], 1ull);
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         const int col = 16 * (nt0 + u) + 4 * q;
@@ -4018,6 +4040,7 @@ __global__ void k_dvec(int mode, const double* x, double* y, int64_t count, doub
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= count) return;
     if (mode == 0) y[e] = sqrt(fmax(x[e], 0.0));
+    else if (mode == 2) y[e] = x[e] * x[e];
     else y[e] = (x[e] > thr * x[0] && x[e] > 0.0) ? 1.0 / x[e] : 0.0;
 }
 __global__ void k_sigma_inv(const double* __restrict__ lam, double* __restrict__ sig, double* __restrict__ inv, int64_t count, double thr) {
@@ -5086,6 +5109,97 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     }
     launch_check();
     dev_free(d, Vtmp);
+}
+// One-sided (Hestenes) Jacobi on the ROWS of M (L x L), G accumulates the rotations from the identity: one workgroup, 32 lanes
+// per row pair, the L / 2 disjoint pairs of a round-robin round in flight together; a round ends with one barrier.  M and G live in
+// LDS when both fit (L <= 96), else in global memory (L2-resident).  Built for accuracy, not speed: it only runs for fp64
+// data whose wanted singular values fall below the Gram route's 10^-3.5 sigma_1 accuracy floor.
+constexpr int HJ_THREADS = 1024, HJ_GROUP = 32;
+template <bool INLDS>
+__global__ __launch_bounds__(HJ_THREADS) void k_jacobi_svd_rows(double* __restrict__ A, int L, int64_t lda, double* __restrict__ Gg,
+                                                                double* __restrict__ U, int64_t ldu, double* __restrict__ s_inv) {
+    extern __shared__ __attribute__((aligned(16))) double sm_hj[];   // [row norms (L) | flag | M, G when INLDS]: all dynamic
+    const int tid = threadIdx.x, gl = tid & (HJ_GROUP - 1), grp = tid / HJ_GROUP, ngrp = HJ_THREADS / HJ_GROUP;
+    const int ld = INLDS ? (L | 1) : L;
+    double* s_nrm = sm_hj;
+    volatile int* s_rotp = reinterpret_cast<volatile int*>(sm_hj + L);
+#define s_rot (*s_rotp)
+    double* M = INLDS ? sm_hj + L + 2 : A;
+    double* G = INLDS ? sm_hj + L + 2 + (size_t)L * ld : Gg;
+    const int64_t ldm = INLDS ? ld : lda;
+    for (int e = tid; e < L * L; e += HJ_THREADS) {
+        const int r = e / L, c = e - r * L;
+        if (INLDS) M[r * ld + c] = A[(int64_t)r * lda + c];
+        G[(size_t)r * ld + c] = r == c ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const int n = (L + 1) & ~1, half = n >> 1;   // round-robin over n players (a dummy when L is odd)
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        if (tid == 0) s_rot = 0;
+        __syncthreads();
+        for (int r = 0; r < n - 1; ++r) {
+            for (int slot = grp; slot < half; slot += ngrp) {
+                int p = slot == 0 ? n - 1 : (r + slot) % (n - 1);
+                int q = (n - 1 - slot + r) % (n - 1);
+                if (p > q) { const int t = p; p = q; q = t; }
+                if (q >= L) continue;                      // the dummy sits out
+                double* mp = M + (size_t)p * ldm;
+                double* mq = M + (size_t)q * ldm;
+                double al = 0, be = 0, ga = 0;
+                for (int j = gl; j < L; j += HJ_GROUP) { const double a = mp[j], b = mq[j]; al += a * a; be += b * b; ga += a * b; }
+                for (int off = HJ_GROUP / 2; off > 0; off >>= 1) {
+                    al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
+                }
+                if (!(fabs(ga) > 1e-15 * sqrt(al * be))) continue;   // (uniform over the 32 lanes of the pair)
+                if (gl == 0) s_rot = 1;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                double* gp = G + (size_t)p * ld;
+                double* gq = G + (size_t)q * ld;
+                for (int j = gl; j < L; j += HJ_GROUP) {
+                    const double a = mp[j], b = mq[j];
+                    mp[j] = cs * a - sn * b; mq[j] = sn * a + cs * b;
+                    const double u = gp[j], v = gq[j];
+                    gp[j] = cs * u - sn * v; gq[j] = sn * u + cs * v;
+                }
+            }
+            __syncthreads();
+        }
+        const int any = s_rot;
+        __syncthreads();
+        if (!any) break;
+    }
+    // singular values = row norms; ascending order (ties: lower row first), 1 / s out
+    for (int i = tid; i < L; i += HJ_THREADS) {
+        double a = 0;
+        for (int j = 0; j < L; ++j) { const double v = M[(size_t)i * ldm + j]; a += v * v; }
+        s_nrm[i] = sqrt(a);
+    }
+    __syncthreads();
+    for (int i = tid; i < L; i += HJ_THREADS) {
+        const double mine = s_nrm[i];
+        int rank = 0;
+        for (int k2 = 0; k2 < L; ++k2) { const double o = s_nrm[k2]; rank += (o < mine || (o == mine && k2 < i)) ? 1 : 0; }
+        s_inv[rank] = mine > 0.0 ? 1.0 / mine : 0.0;
+        for (int j = 0; j < L; ++j) U[(int64_t)j * ldu + rank] = G[(size_t)i * ld + j];
+    }
+#undef s_rot
+}
+void op_jacobi_svd_rows(Dev* d, double* A, int64_t L, int64_t lda, double* U, int64_t ldu, double* s_inv) {
+    if (L == 0) return;
+    if (L > 1024) throw std::runtime_error("jacobi_svd_rows: order above 1024");
+    const size_t lds = sizeof(double) * (L + 2 + 2 * (size_t)L * (L | 1));
+    if (lds <= 150 * 1024) {
+        set_max_lds(d, reinterpret_cast<const void*>(k_jacobi_svd_rows<true>));
+        hipLaunchKernelGGL(k_jacobi_svd_rows<true>, dim3(1), dim3(HJ_THREADS), lds, d->stream, A, (int)L, lda, (double*)nullptr, U, ldu, s_inv);
+        launch_check();
+        return;
+    }
+    double* G = (double*)dev_alloc(d, sizeof(double) * L * L);
+    hipLaunchKernelGGL(k_jacobi_svd_rows<false>, dim3(1), dim3(HJ_THREADS), sizeof(double) * (L + 2), d->stream, A, (int)L, lda, G, U, ldu, s_inv);
+    launch_check();
+    dev_free(d, G);
 }
 // one block, 256 threads: thread groups of 8 lanes per column, fixed order (deterministic)
 __global__ __launch_bounds__(256) void k_ritz_residual(const double* __restrict__ CV, const double* __restrict__ Vr, int64_t rows, int64_t ld,

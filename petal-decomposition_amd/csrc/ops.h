@@ -151,11 +151,20 @@ void op_ritz_residual(Dev*, const double* CV, const double* Vr, int64_t rows, in
 // U: rows x >= nc (ldu), KT / KTs: rows x ncp.
 void op_whiten_k(Dev*, const double* U, int64_t ldu, const double* lam, int64_t rows, int64_t nc, int64_t ncp, double scale,
                  double* KT, double* KTs);
+// Singular value decomposition of a small square matrix A (L x L fp64, lda) by ONE-SIDED (Hestenes) Jacobi on its rows --
+// the route that keeps the relative accuracy of small singular values (eps kappa of the row-scaled matrix, not eps kappa^2
+// like an eigen-decomposition of A A^T): rows p, q are rotated until all are mutually orthogonal, G A = W, so A = G^T W and
+// the rows of G are the LEFT singular vectors, the row norms of W the singular values.
+//   U (L x L, ldu): column j = the left singular vector of the j-th singular value in ASCENDING order,
+//   s_inv (L):      1 / (that singular value)  (descending; 0 where the singular value is 0).
+// (This is the order its one caller wants: A = R^-1 of a thin QR X = Q R, whose left singular vectors are the right
+// singular vectors of X and whose inverse singular values are X's, largest first.)  A is destroyed.
+void op_jacobi_svd_rows(Dev*, double* A, int64_t L, int64_t lda, double* U, int64_t ldu, double* s_inv);
 // x[i] *= alpha
 void op_dscal(Dev*, double* x, int64_t count, double alpha);
 // y[i] += alpha * x[i]
 void op_daxpy(Dev*, int64_t count, double alpha, const double* x, double* y);
-// elementwise helpers on f64 vectors:  mode 0: y = sqrt(max(x,0)); mode 1: y = x > thr*x[0] ? 1/x : 0
+// elementwise helpers on f64 vectors:  mode 0: y = sqrt(max(x,0)); mode 1: y = x > thr*x[0] ? 1/x : 0; mode 2: y = x^2
 void op_dvec(Dev*, int mode, const double* x, double* y, int64_t count, double thr);
 // A[i][j] *= s[j]  (f64 matrix M x N)
 void op_dscale_cols(Dev*, double* A, int64_t M, int64_t N, int64_t lda, const double* s);
