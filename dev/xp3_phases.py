@@ -20,6 +20,6 @@ for n in (100000, 1000000):
     st = ctx.stats()
     lib.petal_debug_counters(cyc, dbg)
     waves = max(cyc[26], 1); chunks = 16
-    names = ["barrier", "xwait", "split", "issue", "mfma", "pstore"]
+    names = ["vmwait", "barrier", "split(+pdma)", "xdma", "mfma", "-"] if os.environ.get("PETAL_XP4", "1") != "0" else ["barrier", "xwait", "split", "issue", "mfma", "pstore"]
     per = [cyc[20 + i] / waves / chunks for i in range(6)]
     print(f"n={n}: K1 {st['xp_ms']*1e3:.1f} us, waves {waves}; cycles per chunk per wave:", {k: round(v) for k, v in zip(names, per)}, "sum", round(sum(per)))

@@ -231,7 +231,7 @@ void op_whiten_k(Dev*, const double* U, int64_t ldu, const double* lam, int64_t 
     }
 }
 void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool /*clustered*/, int64_t Lz,
-             int64_t /*ncheck*/) {
+             int64_t /*ncheck*/, int* /*verdict*/) {
     for (int64_t r = 0; r < Lz; ++r)
         for (int64_t c = 0; c < Lz; ++c)
             if (r >= L || c >= L) V[r * ldv + c] = 0.0;

@@ -461,12 +461,10 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     double* const mu64 = res.f64() + o_mu;
     double* const flip = res.f64() + o_flip;
     DBuf muT;
-    if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
-    column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq, sharded(c) && centering ? pro.sums : nullptr);
-
     // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64.  Single rank: the raw
-    // draw goes up through the pinned ring without a host wait (it overlaps the column-means pass) and is widened on the
-    // device; sharded: rank 0's draw came back from the prologue's all-reduce, already fp64.
+    // draw goes up through the pinned ring without a host wait and is widened on the device -- queued BEFORE the column-means
+    // pass, whose 35 us then cover the host's copy into the ring and the launches that follow (queued behind it the device sat
+    // idle for 20 us waiting for the host); sharded: rank 0's draw came back from the prologue's all-reduce, already fp64.
     DBuf P(c.dev, sizeof(double) * dp * LP);
     if (sharded(c)) {
         op_pad_to_f64(c.dev, F64, P.f64(), dp, LP, pro.draw, d, L, l_req, tvp, 2 + LP);
@@ -475,6 +473,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         dev_h2d_async(c.dev, raw.p, omega, raw.bytes);
         op_pad_to_f64(c.dev, dt, P.f64(), dp, LP, raw.p, d, L, l_req, tvp, 2 + LP);  // (also clears tv, ndead, lam for the first pipeline run)
     }
+    if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
+    column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq, sharded(c) && centering ? pro.sums : nullptr);
     DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
     c.stats.pass_flops = 2.0 * double(n) * double(d) * double(l_req);
     c.stats.pass_bytes = double(esz) * (double(n) * d + double(n) * l_req + double(d) * l_req);
@@ -484,7 +484,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     DBuf T(c.dev, sizeof(double) * LP * LP), Y(c.dev, sizeof(double) * dp * LP);
     DBuf Bt(c.dev, sizeof(double) * dp * LP), S(c.dev, sizeof(double) * LP * LP), Uh(c.dev, sizeof(double) * LP * LP);
     DBuf inv(c.dev, sizeof(double) * LP), M2(c.dev, sizeof(double) * LP * LP);
-    void* Uout = nullptr;  // where the pipeline left U (n x LP)
+    void* Uout = nullptr;  // where the pipeline left U (n x LP; its first kp columns)
+    const int64_t kp = std::min(LP, round_up(std::max<int64_t>(k, 1), 16));
     // The whole device pipeline.  It runs OPTIMISTICALLY first (robust = false): every power iteration re-bases with
     // the single-Cholesky fast path and no host round trip; the kernels record the worst pivot breakdown in `ndead`,
     // which is read together with the results.  Only if a breakdown happened is the fit redone with robust = true.
@@ -571,14 +572,20 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // economy SVD of B (l x d) (svddc, pca.rs:682): eigen-decomposition of B B^T in fp64
     op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Bt.f64(), LP, Bt.f64(), LP, 0.0, S.f64(), LP);
     // only the leading L x L block of S is non-zero (columns L..LP-1 of every iterate are exact zero padding)
-    op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, false, LP);  // (zero padding of Uh included)
+    // Optimistic run: the two-stage solver alone, its closeness verdict restricted to the k pairs that reach the outputs
+    // (the oversampling tail may cluster at the noise floor: its vectors only have to span it) and OR-ed into `ndead` -- a
+    // flagged spectrum (exact multiplicities among the wanted singular values) redoes the fit on the robust path, which
+    // solves with Jacobi.  Saves the two fallback launches that return at once on every separated spectrum.
+    if (!robust) op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, false, LP, std::max<int64_t>(k, 1), ndead);
+    else op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, true, LP);  // (zero padding of Uh included)
     op_sigma_inv(c.dev, lam, sig, inv.f64(), LP, dt == F32 ? 1e-7 : 1e-12);
     // V[:, j] = B^T u_j / sigma_j
     op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Bt.f64(), LP, Uh.f64(), LP, 0.0, V, LP, inv.f64());
 
     // U = Q Uh = Usrc (T Uh) (pca.rs:683) and svd_flip (pca.rs:684)
+    // (only the k columns svd_flip signs and fit_transform returns: kp = k rounded up to whole 16-column tiles)
     op_dgemm(c.dev, false, false, LP, LP, LP, 1.0, T.f64(), LP, Uh.f64(), LP, 0.0, M2.f64(), LP);
-    op_gemm_xp(c.dev, dt, Usrc, n, LP, LP, nullptr, M2.f64(), LP, LP, nullptr, Ubuf, LP, nullptr);
+    op_gemm_xp(c.dev, dt, Usrc, n, LP, LP, nullptr, M2.f64(), kp, LP, nullptr, Ubuf, LP, nullptr);
     Uout = Ubuf;
     };  // pipeline
 
@@ -587,7 +594,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     std::vector<double> hres(size_t(res_len - o_tv)), sg;
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
-        if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, LP, LP, ri.row_offset, flip);
+        if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip);
         dev_d2h(c.dev, hres.data(), tvp, sizeof(double) * hres.size());
         dev_sync(c.dev);
         int hdead = 0;
@@ -596,10 +603,10 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     }
     if (slot_flip) {
         const double* hf = &hres[o_flip - o_tv];
-        sg = flip_slot_keys(c, dt) ? signs_from_triple(std::vector<double>(hf + 3 * LP, hf + 4 * LP), LP)
-                                   : signs_from_triple(std::vector<double>(hf, hf + 3 * LP), LP);
+        sg = flip_slot_keys(c, dt) ? signs_from_triple(std::vector<double>(hf + 3 * kp, hf + 4 * kp), kp)
+                                   : signs_from_triple(std::vector<double>(hf, hf + 3 * kp), kp);
     } else {
-        sg = flip_signs(c, dt, Uout, n, LP, LP, ri.row_offset);
+        sg = flip_signs(c, dt, Uout, n, kp, LP, ri.row_offset);
     }
     const double* hV = &hres[o_V - o_tv];
     const double* hs = &hres[o_sig - o_tv];

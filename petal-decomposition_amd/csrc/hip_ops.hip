@@ -904,8 +904,8 @@ __global__ __launch_bounds__(256) void k_pack_p3(const double* __restrict__ P, i
 #define PETAL_XP3_DEPTH 1   // raw X chunks in flight per wave (2 measured slower)
 #define PETAL_XP3_OCC 2     // waves per SIMD the register budget is cut for
 #endif
-template <int RT, int NT, int DEPTH, bool CENTER, int WVK = 4>  // WVK = waves (row tiles of 16 RT rows) per workgroup
-__global__ __launch_bounds__(64 * WVK, PETAL_XP3_OCC) void k_xp3(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
+template <int RT, int NT, int DEPTH, bool CENTER, int WVK = 4, int OCC = PETAL_XP3_OCC>  // WVK = waves (row tiles of 16 RT rows) per workgroup
+__global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
                                                             const float* __restrict__ mu, const bf16x8* __restrict__ Ppk3,
                                                             int NTtot, int nt0, int N, const float* __restrict__ bias,
                                                             float* __restrict__ Z, int64_t ldz) {
@@ -1027,6 +1027,158 @@ __global__ __launch_bounds__(64 * WVK, PETAL_XP3_OCC) void k_xp3(const float* __
             if (c + 1 < nchunk) store_p(buf ^ 1, pn);
             XP3_STAMP(5);
         }
+    }
+#ifdef PETAL_DEBUG_COUNTERS
+    if (lane == 0) {
+        for (int e = 0; e < 6; ++e) atomicAdd((unsigned long long*)&g_cyc[20 + e], (unsigned long long)ph[e]);
+        atomicAdd((unsigned long long*)&g_cyc[26], 1ull);
+    }
+#endif
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int col = 16 * (nt0 + u) + 4 * q;
+        if (col >= N) continue;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int64_t row = row0 + 16 * t + i;
+            if (row < n) *reinterpret_cast<f32x4*>(Z + row * ldz + col) = acc[t][u] + bv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1, split-product form with the X stream on LDS-DMA ("k_xp4").  Same arithmetic, same MFMA order and therefore the same
+// bits as k_xp3; what changes is how the operands reach the wave.  k_xp3 prefetches ONE 32-column chunk of X per wave into
+// registers: in-kernel stamps (dev/xp3_phases.py) show the MFMA phase of a chunk at 2050 of ~4800 cycles and the rest of the
+// chunk waiting -- for loads that could only be issued one chunk ahead, and at the workgroup barrier for whichever of the four
+// waves waited longest.  Here every wave keeps a TWO-deep ring of its own 8-KB X chunks in LDS, filled by
+// global_load_lds_dwordx4 (no register destination, so the prefetch distance costs LDS, not VGPRs): chunk c + 2 is requested
+// as soon as chunk c has been read out of its slot and is needed two chunk-times later.  The P chunk (shared by the eight
+// waves of the one workgroup a CU holds: 2 x 64 KB of X rings + 2 x 15 KB of P + mu = the whole 160 KB) arrives the same way,
+// one chunk ahead.  Counted waits only: the wave's DMAs retire in order, so `s_waitcnt vmcnt(8)` -- the eight pieces of X
+// chunk c + 1 may stay in flight -- covers X chunk c and this wave's share of P chunk c; a raw s_barrier then publishes P
+// (no vmcnt(0) anywhere in the loop, which is what __syncthreads() would emit).
+// LDS images are lane-linear (a DMA piece = 64 lanes x 16 B = 1 KB, lane l at +16 l).
+typedef __attribute__((address_space(1))) const void* glds_src_t;
+typedef __attribute__((address_space(3))) void* glds_dst_t;
+template <int NT, bool CENTER>
+__global__ __launch_bounds__(512) void k_xp4(const float* __restrict__ X, int64_t n, int K, int64_t ldx, const float* __restrict__ mu,
+                                             const bf16x8* __restrict__ Ppk3, int NTtot, int nt0, int N,
+                                             const float* __restrict__ bias, float* __restrict__ Z, int64_t ldz) {
+    constexpr int RT = 4, WV = 8;
+    constexpr int PPIECES = NT * 3, PBYTES = PPIECES * 1024;       // P chunk: NT tiles x 3 planes, 1 KB each
+    constexpr int XSLOT = RT * 2 * 1024;                            // one X chunk of one wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_xp4[];
+    unsigned char* const sXr = sm_xp4;                              // [WV][2][XSLOT]
+    unsigned char* const sPr = sm_xp4 + WV * 2 * XSLOT;             // [2][PBYTES]
+    float* const sMu = reinterpret_cast<float*>(sPr + 2 * PBYTES);  // [K]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * WV + wave) * (16 * RT);
+    const int nchunk = K >> 5;                                      // (the host sends K % 32 != 0 to k_xp3)
+    if (CENTER) {
+        for (int k = tid; k < K; k += 64 * WV) sMu[k] = mu[k];
+        __syncthreads();                                            // (before the first DMA: a plain barrier, nothing in flight)
+    }
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // DMA pieces are WHOLE cache lines: piece p = rows 8 p .. 8 p + 7 of the wave's 64, the 128 bytes of chunk c of each (lane l:
+    // row 8 p + (l >> 3), bytes 16 (l & 7) ..), so every line is requested by exactly one instruction.  (Fragment-shaped pieces
+    // -- 16 rows x 64 B, each line touched by two instructions -- issued at 300-500 cycles per instruction under load.)
+    // The ring slot is then the plain row-major image [64 rows][128 B] of the chunk.
+    const float* xrow[2 * RT];
+#pragma unroll
+    for (int p8 = 0; p8 < 2 * RT; ++p8) {
+        const int64_t r = row0 + 8 * p8 + (lane >> 3);
+        xrow[p8] = X + (r < n ? r : (n - 1)) * ldx + 4 * (lane & 7);
+    }
+    unsigned char* const myX = sXr + wave * 2 * XSLOT;
+    auto dma_x = [&](int c) {                                       // 8 pieces: chunk c of this wave's rows -> ring slot c & 1
+        unsigned char* dst = myX + (c & 1) * XSLOT;
+#pragma unroll
+        for (int p8 = 0; p8 < 2 * RT; ++p8)
+            __builtin_amdgcn_global_load_lds((glds_src_t)(xrow[p8] + 32 * c), (glds_dst_t)(dst + p8 * 1024), 16, 0, 0);
+    };
+    const bf16x8* const psrc = Ppk3 + (int64_t)nt0 * 192 + lane;
+    auto dma_p = [&](int c) {                                       // this wave's share of P chunk c (pieces wave, wave + 8)
+        unsigned char* dst = sPr + (c & 1) * PBYTES;
+        const bf16x8* src = psrc + (int64_t)c * NTtot * 192;
+#pragma unroll
+        for (int j = 0; j < (PPIECES + WV - 1) / WV; ++j) {
+            const int piece = wave + WV * j;
+            if (piece < PPIECES) __builtin_amdgcn_global_load_lds((glds_src_t)(src + piece * 64), (glds_dst_t)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    dma_p(0);
+    dma_x(0);
+    if (nchunk > 1) dma_x(1);
+#ifdef PETAL_DEBUG_COUNTERS
+    long long ph[6] = {0, 0, 0, 0, 0, 0};
+    long long tq = __builtin_amdgcn_s_memtime();
+#define XP4_STAMP(i) do { const long long _t = __builtin_amdgcn_s_memtime(); ph[i] += _t - tq; tq = _t; } while (0)
+#else
+#define XP4_STAMP(i) do {} while (0)
+#endif
+    for (int c = 0; c < nchunk; ++c) {
+        // in flight, oldest first: [X(c)] P(c) [X(c + 1)] -- everything but the eight pieces of X(c + 1) must have landed
+        if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        XP4_STAMP(0);
+        __builtin_amdgcn_s_barrier();                               // every wave's share of P(c) is in; nobody reads P(c - 1) any more
+        asm volatile("" ::: "memory");
+        XP4_STAMP(1);
+        if (c + 1 < nchunk) dma_p(c + 1);                           // into the slot P(c - 1) just left
+        // X(c): out of the ring, centred, split
+        bf16x8 ah[RT], am[RT], al[RT];
+        {
+            const unsigned char* xs = myX + (c & 1) * XSLOT + i * 128 + q * 32;   // row 16 t + i, columns 8 q .. 8 q + 7
+            f32x8 m = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (CENTER) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(sMu + 32 * c + 8 * q), hi = *reinterpret_cast<const f32x4*>(sMu + 32 * c + 8 * q + 4);
+                m = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(xs + t * 2048), hi = *reinterpret_cast<const f32x4*>(xs + t * 2048 + 16);
+                f32x8 a = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (CENTER) a -= m;
+                split3(a, ah[t], am[t], al[t]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        XP4_STAMP(2);
+        if (c + 2 < nchunk) dma_x(c + 2);                           // the slot X(c) has just been read out of
+        __builtin_amdgcn_sched_barrier(0);
+        XP4_STAMP(3);
+        const bf16x8* sPb = reinterpret_cast<const bf16x8*>(sPr + (c & 1) * PBYTES) + lane;
+        bf16x8 bh = sPb[0], bm = sPb[64], bl = sPb[128];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            bf16x8 nh = bh, nm = bm, nl = bl;
+            if (u + 1 < NT) { nh = sPb[(u * 3 + 3) * 64]; nm = sPb[(u * 3 + 4) * 64]; nl = sPb[(u * 3 + 5) * 64]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {  // (operand roles and order of the six piece products as in k_xp3: identical results)
+                f32x4 c4 = acc[t][u];
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[t], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[t], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[t], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[t], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[t], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[t], c4, 0, 0, 0);
+                acc[t][u] = c4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bh = nh; bm = nm; bl = nl;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        XP4_STAMP(4);
     }
 #ifdef PETAL_DEBUG_COUNTERS
     if (lane == 0) {
@@ -3328,7 +3480,7 @@ template <int TMAX, int STEP>  // L <= 8 TMAX; PAD = 8 STEP zero columns
 __global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restrict__ A, int L, int64_t lda, double* __restrict__ dd,
                                                            double* __restrict__ ee, double* __restrict__ HV,
                                                            double* __restrict__ tau, double* __restrict__ gg,
-                                                           int* __restrict__ flag, double* __restrict__ V, int64_t ldv, int Lz) {
+                                                           int* __restrict__ flag, double* __restrict__ V, int64_t ldv, int Lz, int reset_flag) {
     extern __shared__ __attribute__((aligned(16))) double sm_tri[];
     const int tid = threadIdx.x;
     const int ld = tri_ld(L, STEP);
@@ -3343,7 +3495,7 @@ __global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restr
         const int r = e / ld, c = e - r * ld;
         W[e] = c < L ? A[(int64_t)r * lda + c] : 0.0;
     }
-    if (tid == 0) *flag = 0;
+    if (tid == 0 && reset_flag) *flag = 0;   // (a caller-owned verdict word accumulates: it is not reset here)
     __syncthreads();
     long long _t0 = 0;
 #ifdef PETAL_DEBUG_COUNTERS
@@ -4353,6 +4505,30 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
                 if (muf) hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, true>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
                 else hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, false>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
             } while (0)
+            // LDS-DMA ring form (k_xp4): whole 32-column chunks, mu + rings within the 160 KB of one workgroup per CU
+            // (measured slower than k_xp3 -- 68 vs 62 us at 100000 x 512, 594 vs 570 us at 1e6 -- so it is opt-in: DESIGN section 9)
+            static const int xp4_env = [] { const char* e = getenv("PETAL_XP4"); return e ? atoi(e) : 0; }();
+            const size_t lds4 = (size_t)8 * 2 * 8192 + (size_t)2 * w * 3 * 1024 + (muf ? sizeof(float) * K : 0);
+            if (xp4_env && K % 32 == 0 && K >= 64 && lds4 <= 160 * 1024 && n >= 512) {
+#define XP4_LAUNCH(NTv)                                                                                                                   \
+                do {                                                                                                                        \
+                    const int blocks4 = cdiv(n, 512);                                                                                       \
+                    set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp4<NTv, true>) : reinterpret_cast<const void*>(k_xp4<NTv, false>)); \
+                    if (muf) hipLaunchKernelGGL((k_xp4<NTv, true>), dim3(blocks4), dim3(512), lds4, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
+                    else hipLaunchKernelGGL((k_xp4<NTv, false>), dim3(blocks4), dim3(512), lds4, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
+                } while (0)
+                switch (w) {
+                    case 5: XP4_LAUNCH(5); break;
+                    case 4: XP4_LAUNCH(4); break;
+                    case 3: XP4_LAUNCH(3); break;
+                    case 2: XP4_LAUNCH(2); break;
+                    default: XP4_LAUNCH(1); break;
+                }
+#undef XP4_LAUNCH
+                launch_check();
+                nt0 += w;
+                continue;
+            }
             switch (w) {
                 case 5: XP3_LAUNCH(RTv, 5); break;
                 case 4: XP3_LAUNCH(RTv, 4); break;
@@ -4993,7 +5169,8 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_mode, ndead, (int)Lz);
     launch_check();
 }
-void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool clustered, int64_t Lz, int64_t ncheck) {
+void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool clustered, int64_t Lz, int64_t ncheck,
+             int* verdict) {
     if (L == 0) return;
     const bool pad_done = Lz <= L;   // else: rows / columns L .. Lz - 1 of V are to be zeroed here
     if (L > EIG_MAXL) throw std::runtime_error("eigh: matrix too large for the one-workgroup Jacobi solver");
@@ -5003,6 +5180,10 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     int* flag = nullptr;
     char* ts = nullptr;
     const bool two_stage = !jacobi_only && !clustered && L >= 3 && L <= 2048;
+    // verdict given (and the order is one the register-resident kernels take): the two-stage result is delivered as it is and
+    // the verdict goes to the caller's device word, who decides what to do about a flagged spectrum (RandomizedPca redoes the
+    // fit on its robust path) -- the two fallback launches, which return at once on every separated spectrum, are not issued
+    const bool ext_verdict = verdict != nullptr && two_stage && L <= 138;
     // k_tridiag_r (orders up to 138) writes the padding itself; every other route gets one 2-D clear of the Lz x Lz frame first
     if (!pad_done && !(two_stage && L <= 138)) HIP_CHECK(hipMemset2DAsync(V, sizeof(double) * ldv, 0, sizeof(double) * Lz, Lz, d->stream));
     if (two_stage) {
@@ -5022,12 +5203,13 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         double* HV = gg + L;
         double* Wg = inlds ? nullptr : HV + L * L;
         flag = reinterpret_cast<int*>(ts + bytes - 64);
+        if (ext_verdict) flag = verdict;   // (the closeness verdict ORs into the caller's word; no Jacobi launches behind it)
         if (regs) {
 #define PETAL_TRI_LAUNCH(TM, ST)                                                                                                   \
     do {                                                                                                                           \
         const size_t lds_r = sizeof(double) * ((size_t)L * tri_ld((int)L, ST) + 8 * TM + tri_sp_len(TM));                          \
         set_max_lds(d, reinterpret_cast<const void*>(k_tridiag_r<TM, ST>));                                                        \
-        hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag, V, ldv, (int)(pad_done ? 0 : Lz)); \
+        hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag, V, ldv, (int)(pad_done ? 0 : Lz), ext_verdict ? 0 : 1); \
     } while (0)
             if (L <= 80) PETAL_TRI_LAUNCH(10, 2);
             else if (L <= 132) PETAL_TRI_LAUNCH(18, 2);
@@ -5064,6 +5246,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         }
     }
     struct Cleanup { Dev* d; char* p; ~Cleanup() { if (p) dev_free(d, p); } } cleanup{d, ts};
+    if (ext_verdict) return;
     if (jaca_lds_bytes((int)L) <= 160 * 1024 - 256) {
         // split solver: A in LDS + rotation log, eigenvectors replayed on L waves
         const int Le = (int)((L + 1) & ~1), half = Le / 2, rounds = Le - 1;

@@ -137,8 +137,10 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
 // ncheck > 0: only the leading ncheck eigenpairs are delivered to full accuracy -- the two-stage solver's closeness verdict
 // looks at those alone (a cluster further down, e.g. the noise-level Ritz values of a subspace iteration, gets vectors that
 // are accurate to eps ||A|| / gap only and need not be mutually orthogonal; it no longer sends the whole problem to Jacobi).
+// verdict (nullable, device int): instead of running the Jacobi fallback behind a flagged two-stage solve, OR a non-zero value into
+// *verdict and deliver the two-stage result as it is (orders the register-resident kernels take; other orders ignore it).
 void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel = 1e-15,
-             bool clustered = false, int64_t Lz = 0, int64_t ncheck = 0);
+             bool clustered = false, int64_t Lz = 0, int64_t ncheck = 0, int* verdict = nullptr);
 // Residual verdict of a Rayleigh-Ritz step without a host round trip: with the Ritz vectors Vr (rows x >= nc, ld), their
 // images CV = C Vr and the Ritz values theta,  out[0] = max_{j < nc} ||CV[:, j] - theta_j Vr[:, j]||_2^2,  out[1] = theta[0],
 // out[2] = 1 if one of those nc norms is not finite.  One launch; the caller reads `out` with its other results.
