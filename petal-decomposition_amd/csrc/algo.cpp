@@ -236,9 +236,11 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
             }
         dev_h2d_async(dv, Y.p, h.data(), Y.bytes);   // (through the pinned ring: no host wait)
     }
-    auto orth = [&](DBuf& src, DBuf& dst) {  // dst = orthonormal basis of range(src), two Cholesky-QR rounds
+    // dst = orthonormal basis of range(src): two Cholesky-QR rounds (one leaves ||Q^T Q - I|| ~ eps cond(src)^2, up to 1e-4
+    // after a product with C: good enough for the basis the NEXT product is applied to, not for a Rayleigh-Ritz step)
+    auto orth = [&](DBuf& src, DBuf& dst, int rounds = 2) {
         const double* in = src.f64();
-        for (int rep = 0; rep < 2; ++rep) {
+        for (int rep = 2 - rounds; rep < 2; ++rep) {
             op_dgemm(dv, true, false, p, p, dp, 1.0, in, p, in, p, 0.0, G.f64(), p);
             op_chol_inv(dv, G.f64(), p, p, T.f64(), p, 1e-14);
             double* out = rep == 0 ? R.f64() : dst.f64();
@@ -260,7 +262,7 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
     double h3[3];
     for (int it = 0; it < 40; ++it) {
         if (it == 0) op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, Y.f64(), p, 0.0, R.f64(), p), std::swap(Y, R);
-        orth(Y, Q);
+        orth(Y, Q, it % 2 == 1 ? 2 : 1);   // (the Rayleigh-Ritz step of the odd iterations needs the orthonormal basis)
         op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, Q.f64(), p, 0.0, Y.f64(), p);  // Y = C Q
         if (it % 2 == 1) {  // Rayleigh-Ritz + residual check every second product (never converged after the first)
             if (resid3) {

@@ -1370,7 +1370,7 @@ __global__ __launch_bounds__(256, 2) void k_atb_mfma(const float* __restrict__ A
 template <int NT, bool CA, int WV, int MT = 4>  // MT = column tiles of A per wave (4: 64 columns, 16-B loads; 2: 32 columns, 8-B loads)
 __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
                                                      const float* __restrict__ B, int64_t ldb, int N, int n0col, int64_t n,
-                                                     int64_t chunk, float* __restrict__ part, int Npart) {
+                                                     int64_t chunk, float* __restrict__ part, int Npart, int n_tail) {
     constexpr int BITEMS = NT * 64;                       // operand items of one B stage (8 elements each)
     constexpr bool Z2 = BITEMS > 64 * WV;                 // the first NT - WV waves carry a second item (tile WV + wave)
     typedef float fvecm __attribute__((ext_vector_type(MT)));
@@ -1384,7 +1384,12 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
     if ((int64_t)by * chunk >= n) return;   // (the last group of eight may be short; uniform per workgroup)
     const int m0 = (bx * WV + wave) * (16 * MT);
     const int64_t rbeg = (int64_t)by * chunk, rend = min(n, rbeg + chunk);
-    const int nstage = (int)((rend - rbeg) >> 5);
+    const int nfull = (int)((rend - rbeg) >> 5);
+    // n is a multiple of 32; the n_tail (< 32) ragged rows behind it ride along as ONE partial stage of the last row chunk:
+    // its rows past the end are loaded from the last valid row (finite) on the A side and as zeros on the B side, so they add
+    // nothing.  (Round 2 gave them to the fp32 kernel as an extra slab: two 8-us launches per product at 250000 rows.)
+    const int tail = (rend == n) ? n_tail : 0;
+    const int nstage = nfull + (tail > 0 ? 1 : 0);
     // uniform row bases (advance 32 rows per stage) + ONE 32-bit per-lane offset each: no per-load address arithmetic
     const float* abase = A + rbeg * lda;
     const float* zbase = B + rbeg * ldb;
@@ -1404,13 +1409,25 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
     // every chunk is a whole number of 32-row stages (the host hands the < 32 ragged rows of the matrix to the fp32 kernel)
     auto load_a = [&](int st, fvecm(&av)[8]) {
         const float* p = abase + (int64_t)st * 32 * lda;
+        if (st < nfull) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const fvecm*>(p + (int64_t)e * lda + aoff);
+            for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const fvecm*>(p + (int64_t)e * lda + aoff);
+        } else {  // the partial stage (uniform branch): rows past the end -> the last valid row
+            const unsigned acol = aoff - (unsigned)((int64_t)(8 * q) * lda);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const fvecm*>(p + (int64_t)min(8 * q + e, tail - 1) * lda + acol);
+        }
     };
     auto load_z1 = [&](int st, f32x8& zr, bool on, unsigned zoff) {
         const float* p = zbase + (int64_t)st * 32 * ldb;
+        if (st < nfull) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) zr[e] = p[(int64_t)e * ldb + zoff];  // always a valid address (column clamped)
+            for (int e = 0; e < 8; ++e) zr[e] = p[(int64_t)e * ldb + zoff];  // always a valid address (column clamped)
+        } else {
+            const unsigned zcol = zoff - (unsigned)((int64_t)(8 * q) * ldb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zr[e] = (8 * q + e < tail) ? p[(int64_t)(8 * q + e) * ldb + zcol] : 0.f;
+        }
         (void)on;
     };
     auto stage_z1 = [&](int buf, f32x8 zr, int u, bool on) {
@@ -1511,22 +1528,27 @@ __global__ __launch_bounds__(256) void k_atb_f64(const T* __restrict__ A, int64_
     typedef T tx2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    // Gram matrix (sym): only the (128 x 64) blocks that reach the diagonal or lie above it are launched -- the grid's x index
-    // enumerates them row by row (block row bx keeps the panels by >= 2 bx); the rest is mirrored afterwards
-    int bx = blockIdx.x, by = blockIdx.y;
+    // Gram matrix (sym): only the (32 x 64) WAVE tiles that reach the diagonal or lie above it are computed -- the grid's x
+    // index times four plus the wave enumerates them slice by slice (the 32-row slice a keeps the panels b >= a / 2); the rest
+    // is mirrored afterwards.  (Round 2 enumerated 128 x 64 workgroup blocks: 75 % of the square at d = 256 against 62.5 % here,
+    // 62.5 % against 56 % at d = 512.)
+    int m0, n0;
     if (sym) {
         const int gy = (N + 63) / 64;
-        int t = blockIdx.x;
-        bx = 0;
+        int t = blockIdx.x * 4 + wave, a = 0;
         for (;;) {
-            const int kept = gy - min(gy, 2 * bx);
+            const int kept = gy - min(gy, a >> 1);
+            if (kept == 0) return;              // past the last live tile (the last workgroup may be short)
             if (t < kept) break;
             t -= kept;
-            ++bx;
+            ++a;
         }
-        by = min(gy, 2 * bx) + t;
+        m0 = 32 * a;
+        n0 = (min(gy, a >> 1) + t) * (16 * NE);
+    } else {
+        m0 = (blockIdx.x * 4 + wave) * 32;
+        n0 = blockIdx.y * (16 * NE);
     }
-    const int m0 = (bx * 4 + wave) * 32, n0 = by * (16 * NE);
     if (m0 >= M) return;
     const int64_t rbeg = (int64_t)blockIdx.z * chunk, rend = min(n, rbeg + chunk);
     const int mc = min(m0 + 2 * i, M - 2), ncl = min(n0 + NE * i, N - NE);  // clamped: out-of-range outputs are never stored
@@ -4659,9 +4681,10 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         const int mslices = cdiv(M, 32), npanels = ne5 ? (int)(N / 80) : cdiv(N, 64);
         const int gx = cdiv(M, 128);
         int active = gx * npanels;  // workgroups per row chunk
-        if (sym) {
-            active = 0;
-            for (int bx = 0; bx < gx; ++bx) active += npanels - std::min(npanels, 2 * bx);
+        if (sym) {   // live 32 x 64 wave tiles, four to a workgroup
+            int tiles = 0;
+            for (int a = 0; a < mslices; ++a) tiles += npanels - std::min(npanels, a / 2);
+            active = cdiv(tiles, 4);
         }
         // row split: workgroups are dealt round-robin to the 256 CUs (up to three resident on each: the kernel's register
         // budget), so the launch takes ceil(active * ns / 256) / ns of the single-split time; pick the ns that minimises it
@@ -4731,7 +4754,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     const int64_t n_main = split3_mode ? n / cq * cq : n, n_tail = n - n_main;  // split-product kernels: whole stages
     const int64_t chunk = ((n_main + nsplit - 1) / nsplit + cq - 1) / cq * cq;
     nsplit = (n_main + chunk - 1) / chunk;
-    const int64_t nslab = nsplit + (n_tail ? 1 : 0);
+    const int64_t nslab = nsplit;   // (the split-product kernels take the ragged rows along in their last row chunk)
     float* part = (float*)dev_alloc(d, sizeof(float) * nslab * M * N);
     const int NTtot = int(N / 16);
     TagScope ts(d);
@@ -4752,8 +4775,8 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
             const dim3 grid(8 * cdiv(M, 256), (unsigned)cdiv(nsplit, 8)), block(512);   // 8 waves x 32 columns per workgroup
 #define ATB3W_LAUNCH(NTv)                                                                                                             \
             do {                                                                                                                      \
-                if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, 8, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
-                else hipLaunchKernelGGL((k_atb3<NTv, false, 8, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+                if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, 8, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
+                else hipLaunchKernelGGL((k_atb3<NTv, false, 8, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
             } while (0)
             switch (w) {
                 case 9: ATB3W_LAUNCH(9); break;
@@ -4768,21 +4791,6 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
             }
 #undef ATB3W_LAUNCH
             launch_check();
-            if (n_tail) {  // the ragged rows (< one stage): one more slab from the fp32 kernel, in two sub-panels of <= 5 tiles
-                const float* At = Af + n_main * lda; const float* Bt = Bf + n_main * ldb;
-                float* pt = part + nsplit * M * N;
-                for (int s0 = 0; s0 < w;) {
-                    const int ws = std::min(5, w - s0);
-                    switch (ws) {
-                        case 5: launch_atb<5>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * (nt0 + s0), mb, n_tail, 64, pt, 1); break;
-                        case 4: launch_atb<4>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * (nt0 + s0), mb, n_tail, 64, pt, 1); break;
-                        case 3: launch_atb<3>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * (nt0 + s0), mb, n_tail, 64, pt, 1); break;
-                        case 2: launch_atb<2>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * (nt0 + s0), mb, n_tail, 64, pt, 1); break;
-                        default: launch_atb<1>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * (nt0 + s0), mb, n_tail, 64, pt, 1); break;
-                    }
-                    s0 += ws;
-                }
-            }
             nt0 += w;
             continue;
         }
@@ -4790,8 +4798,8 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
             const dim3 grid(8 * cdiv(M, 512), (unsigned)cdiv(nsplit, 8)), block(512);
 #define ATB3_LAUNCH(NTv)                                                                                                              \
             do {                                                                                                                      \
-                if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
-                else hipLaunchKernelGGL((k_atb3<NTv, false, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N); \
+                if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
+                else hipLaunchKernelGGL((k_atb3<NTv, false, 8>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
             } while (0)
             switch (w) {
                 case 5: ATB3_LAUNCH(5); break;
@@ -4804,17 +4812,6 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
             launch_check();
         }
         if (split3_mode) {
-            if (n_tail) {  // the ragged rows (< one stage): one more slab from the fp32 kernel
-                const float* At = Af + n_main * lda; const float* Bt = Bf + n_main * ldb;
-                float* pt = part + nsplit * M * N;
-                switch (w) {
-                    case 5: launch_atb<5>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 64, pt, 1); break;
-                    case 4: launch_atb<4>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 64, pt, 1); break;
-                    case 3: launch_atb<3>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 64, pt, 1); break;
-                    case 2: launch_atb<2>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 64, pt, 1); break;
-                    default: launch_atb<1>(d, At, lda, (int)M, ma, Bt, ldb, (int)N, 16 * nt0, mb, n_tail, 64, pt, 1); break;
-                }
-            }
             nt0 += w;
             continue;
         }
@@ -5384,31 +5381,33 @@ void op_jacobi_svd_rows(Dev* d, double* A, int64_t L, int64_t lda, double* U, in
     launch_check();
     dev_free(d, G);
 }
-// one block, 256 threads: thread groups of 8 lanes per column, fixed order (deterministic)
+// one block per wanted column (a maximum is order-independent: the atomic max on the bit patterns of non-negative doubles is
+// deterministic); out3 is cleared by the host wrapper first
 __global__ __launch_bounds__(256) void k_ritz_residual(const double* __restrict__ CV, const double* __restrict__ Vr, int64_t rows, int64_t ld,
                                                        int nc, const double* __restrict__ theta, double* __restrict__ out3) {
     __shared__ double red[256];
-    __shared__ int badf;
-    if (threadIdx.x == 0) badf = 0;
-    __syncthreads();
-    double worst = 0;
-    for (int j = threadIdx.x >> 3; j < nc; j += 32) {
-        double s2 = 0;
-        const double th = theta[j];
-        for (int64_t i = threadIdx.x & 7; i < rows; i += 8) { const double v = CV[i * ld + j] - th * Vr[i * ld + j]; s2 += v * v; }
-        s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
-        if (!(s2 < 1e300)) badf = 1; else worst = fmax(worst, s2);
-    }
-    red[threadIdx.x] = worst;
+    const int j = blockIdx.x;
+    const double th = theta[j];
+    double s2 = 0;
+    for (int64_t i = threadIdx.x; i < rows; i += 256) { const double v = CV[i * ld + j] - th * Vr[i * ld + j]; s2 += v * v; }
+    red[threadIdx.x] = s2;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + st]);
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out3[0] = red[0]; out3[1] = theta[0]; out3[2] = badf ? 1.0 : 0.0; }
+    if (threadIdx.x == 0) {
+        const double tot = red[0];
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(out3);
+        if (!(tot < 1e300)) atomicMax(o + 2, (unsigned long long)__double_as_longlong(1.0));
+        else atomicMax(o, (unsigned long long)__double_as_longlong(tot));
+        if (j == 0) out3[1] = th;
+    }
 }
 void op_ritz_residual(Dev* d, const double* CV, const double* Vr, int64_t rows, int64_t ld, int64_t nc, const double* theta, double* out3) {
-    hipLaunchKernelGGL(k_ritz_residual, dim3(1), dim3(256), 0, d->stream, CV, Vr, rows, ld, (int)nc, theta, out3);
+    HIP_CHECK(hipMemsetAsync(out3, 0, sizeof(double) * 3, d->stream));
+    if (nc <= 0) return;
+    hipLaunchKernelGGL(k_ritz_residual, dim3((unsigned)nc), dim3(256), 0, d->stream, CV, Vr, rows, ld, (int)nc, theta, out3);
     launch_check();
 }
 // one block per column j: the eigenvector's sign is NORMALISED first (its first component of largest magnitude made positive).

@@ -442,6 +442,37 @@ def test_run_to_run_bitwise_determinism(ctx):
     assert np.array_equal(p.components(), q.components()) and np.array_equal(p.singular_values(), q.singular_values())
 
 
+def test_lds_dma_k1_variant_is_bit_identical():
+    """k_xp4 (opt-in, PETAL_XP4=1: K1 with X and P arriving through LDS-DMA rings, counted vmcnt waits and a raw barrier) runs
+    the same MFMA sequence as k_xp3: exact on integer data and BIT-IDENTICAL to the default kernel on random data, ragged row
+    counts included.  The switch is read once per process, so the variant runs in a child."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    import petal_decomposition_amd as petal
+    rng = np.random.default_rng(9)
+    n, d, l = 5003, 512, 74
+    x = (rng.standard_normal((n, d)) * 3 + 1).astype(np.float32)
+    p = rng.standard_normal((d, l)).astype(np.float32)
+    mu = x.mean(0).astype(np.float32)
+    ctx = petal.Context(0)
+    z0 = np.asarray(petal.gemm_xp(x, p, mu, ctx=ctx))
+    ctx.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), x=x, p=p, mu=mu)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import petal_decomposition_amd as petal; "
+                "import parity_cases as pc; c = petal.Context(0); d = np.load(%r); "
+                "np.save(%r, np.asarray(petal.gemm_xp(d['x'], d['p'], d['mu'], ctx=c))); "
+                "[pc.gemm_exact(c, n, K, N, seed=n + K) for (n, K, N) in [(4099, 512, 74), (2048, 64, 80), (777, 96, 33), (1000, 160, 16)]]"
+                % (root, os.path.join(root, "tests"), os.path.join(tmp, "in.npz"), os.path.join(tmp, "z.npy")))
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PETAL_XP4="1"), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        z1 = np.load(os.path.join(tmp, "z.npy"))
+    assert np.array_equal(z0, z1)
+
+
 def test_cfg4_share_against_the_oracle():
     """ONE rank's share of BASELINE configs[3] -- 250000 x 1024 fp32, k = 128 (l = 138), n_iter = 7 (src/pca.rs:680) -- against the
     fp64 LAPACK oracle run from the same Omega (about a minute of host time on the GPU box), both GEMM modes: singular values to
