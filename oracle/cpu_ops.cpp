@@ -315,6 +315,14 @@ void op_jacobi_svd_rows(Dev*, double* A, int64_t L, int64_t lda, double* U, int6
         for (int64_t i = 0; i < L; ++i) U[i * ldu + j] = G[idx[j] * L + i];
     }
 }
+void op_refill_zero_cols(Dev*, double* Y, int64_t rows, int64_t cols, int64_t ldy, const double* Src, int64_t lds) {
+    for (int64_t j = 0; j < cols; ++j) {
+        bool zero = true;
+        for (int64_t i = 0; i < rows && zero; ++i) zero = Y[i * ldy + j] == 0.0;
+        if (zero)
+            for (int64_t i = 0; i < rows; ++i) Y[i * ldy + j] = Src[i * lds + j];
+    }
+}
 void op_dscal(Dev*, double* x, int64_t count, double alpha) {
     for (int64_t i = 0; i < count; ++i) x[i] *= alpha;
 }

@@ -524,6 +524,13 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
             op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Pcur, LP, Yp, LP, 0.0, G, LP);
             op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);
             op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Y.f64(), LP);
+            // A column the dependence test dropped (its part of Z below ~1e-3 of the part already spanned: from a random start
+            // every column of Z = Xc Omega is dominated by sigma_1, so a spectrum wider than 1e3 loses its tail here) is
+            // refilled with the matching column of Omega instead of staying zero: orthogonalised against the kept columns
+            // below, the next product shows it the largest direction still missing, and the block regains its width within an
+            // iteration or two -- what the crate's pivoted LU (pca.rs:709-713) achieves by never letting the block lose
+            // rank.  Truly rank-deficient data keeps dropping the refilled columns, down to the final QR (sigma = 0).
+            op_refill_zero_cols(c.dev, Y.f64(), dp, L, LP, P.f64(), LP);
             orthonormalize_small(c, Y, dp, L, LP, 1e-13);
             dev_set_tag(c.dev, TAG_XP);
             op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Y.f64(), LP, LP, nullptr, Z.p, LP, nullptr);  // pca.rs:714

@@ -5454,6 +5454,23 @@ void op_whiten_k(Dev* d, const double* U, int64_t ldu, const double* lam, int64_
     hipLaunchKernelGGL(k_whiten_k, dim3((unsigned)ncp), dim3(256), 0, d->stream, U, ldu, lam, rows, nc, ncp, scale, KT, KTs);
     launch_check();
 }
+__global__ __launch_bounds__(256) void k_refill_zero_cols(double* __restrict__ Y, int64_t rows, int64_t ldy, const double* __restrict__ Src, int64_t lds) {
+    __shared__ int nz;
+    const int64_t j = blockIdx.x;
+    if (threadIdx.x == 0) nz = 0;
+    __syncthreads();
+    bool any = false;
+    for (int64_t i = threadIdx.x; i < rows; i += 256) any = any || (Y[i * ldy + j] != 0.0);
+    if (any) nz = 1;
+    __syncthreads();
+    if (nz) return;
+    for (int64_t i = threadIdx.x; i < rows; i += 256) Y[i * ldy + j] = Src[i * lds + j];
+}
+void op_refill_zero_cols(Dev* d, double* Y, int64_t rows, int64_t cols, int64_t ldy, const double* Src, int64_t lds) {
+    if (rows == 0 || cols == 0) return;
+    hipLaunchKernelGGL(k_refill_zero_cols, dim3((unsigned)cols), dim3(256), 0, d->stream, Y, rows, ldy, Src, lds);
+    launch_check();
+}
 void op_dscal(Dev* d, double* x, int64_t count, double alpha) {
     if (!count) return;
     hipLaunchKernelGGL(k_dscal, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, x, count, alpha);

@@ -162,6 +162,9 @@ void op_whiten_k(Dev*, const double* U, int64_t ldu, const double* lam, int64_t 
 // (This is the order its one caller wants: A = R^-1 of a thin QR X = Q R, whose left singular vectors are the right
 // singular vectors of X and whose inverse singular values are X's, largest first.)  A is destroyed.
 void op_jacobi_svd_rows(Dev*, double* A, int64_t L, int64_t lda, double* U, int64_t ldu, double* s_inv);
+// Every column j < cols of Y (rows x cols, ldy) that is exactly zero is replaced by column j of Src (lds): the robust re-basing
+// of RandomizedPca refills the directions its dependence test dropped with fresh (random) ones instead of shrinking the block.
+void op_refill_zero_cols(Dev*, double* Y, int64_t rows, int64_t cols, int64_t ldy, const double* Src, int64_t lds);
 // x[i] *= alpha
 void op_dscal(Dev*, double* x, int64_t count, double alpha);
 // y[i] += alpha * x[i]

@@ -368,6 +368,34 @@ def test_rank_deficient_fp32_on_the_mfma_path(ctx):
     assert np.abs(back - x).max() < 1e-3 * np.abs(x).max()
 
 
+def test_fp32_wide_spectrum_through_the_single_pass_qr(ctx):
+    """sigma_1 / sigma_k = 1e4 in fp32 (ADVICE round 2): the final thin QR takes its Gram matrix from H = P^T (Xc^T Z) with ONE Cholesky;
+    a pivot lost to the fp32 rounding of P and Z is now recorded and sends the fit to the Cholesky-QR2 redo instead of silently
+    dropping a component.  Either way the result must hold what fp32 data can hold at this spread -- relative errors of
+    eps32 sigma_1 / sigma_j: singular values to 2e-3 at the small end and 1e-5 at the large end, orthonormal components, and
+    agreement with the fp64 oracle run from the same Omega."""
+    import petal_decomposition_amd as petal
+    from oracle import petal_oracle as po
+    rng = np.random.default_rng(91)
+    n, d, k = 20000, 256, 32
+    u, _ = np.linalg.qr(rng.standard_normal((n, 2 * k)))
+    v, _ = np.linalg.qr(rng.standard_normal((d, 2 * k)))
+    s = 10.0 ** (-4.0 * np.arange(2 * k) / (k - 1))          # sigma_1 / sigma_k = 1e4, then on down to 1e-8
+    x = ((u * s) @ v.T * 100.0).astype(np.float32)
+    om = rng.standard_normal((d, k + 10))
+    o = po.RandomizedPcaOracle(k, centering=False, n_iter=7).fit(x.astype(np.float64), omega=om)
+    m = petal.RandomizedPca(k, centering=False, ctx=ctx, n_iter=7).fit(x, omega=om.astype(np.float32))
+    sg = m.singular_values().astype(np.float64)
+    c = m.components().astype(np.float64)
+    assert np.all(np.isfinite(sg)) and np.all(np.isfinite(c))
+    rel = np.abs(sg / o.singular - 1.0)
+    allowed = np.maximum(1e-5, 30 * 6e-8 * o.singular[0] / o.singular)          # eps32 sigma_1 / sigma_j, with head-room
+    assert np.all(rel <= allowed), (rel / allowed).max()
+    assert np.abs(c @ c.T - np.eye(k)).max() < 5e-4
+    comp = pc.rowwise_rel(c, o.components)
+    assert comp[: k // 2].max() < 1e-3 and np.all(comp <= np.maximum(1e-4, 3e3 * 6e-8 * o.singular[0] / o.singular)), comp
+
+
 def test_cfg4_shard_shape_properties():
     """One rank's share of BASELINE configs[3] (250000 x 1024 fp32, k = 128, n_iter = 7: l = 138, two column panels, the
     largest LDS-resident Cholesky / Jacobi sizes), too big for the oracle in seconds: size-independent properties instead --

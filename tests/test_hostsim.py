@@ -87,3 +87,24 @@ def test_accurate_route_for_ill_conditioned_fp64(ctx):
     ss = (s - s.mean(0)) / s.std(0)
     corr = np.abs(ys.T @ ss / len(s))
     assert corr.max(axis=1).min() > 0.99 and len(set(corr.argmax(axis=1))) == 4
+
+
+def test_wide_spectrum_robust_path_refills_dropped_directions(ctx):
+    """sigma_1 / sigma_l = 10^5: the optimistic single-Cholesky re-basing breaks down (cond(Yp^T Yp) beyond fp64) and the robust
+    redo's dependence test drops the tail of the block at the first iteration (every column of Xc Omega is dominated by
+    sigma_1); the dropped columns are refilled with fresh directions, so the block regains its width and ALL k components come
+    back (round 2 returned sigma = 0 for the smallest ones) -- the crate's pivoted LU (src/pca.rs:709-713) never loses rank."""
+    import petal_decomposition_amd as petal
+    from oracle import petal_oracle as po
+    rng = np.random.default_rng(91)
+    n, d, k = 4000, 128, 16
+    u, _ = np.linalg.qr(rng.standard_normal((n, 2 * k)))
+    v, _ = np.linalg.qr(rng.standard_normal((d, 2 * k)))
+    s = 10.0 ** (-4.0 * np.arange(2 * k) / (k - 1))
+    x = ((u * s) @ v.T * 100.0).astype(np.float32)
+    om = rng.standard_normal((d, k + 10))
+    o = po.RandomizedPcaOracle(k, centering=False, n_iter=7).fit(x.astype(np.float64), omega=om)
+    m = petal.RandomizedPca(k, centering=False, ctx=ctx, n_iter=7).fit(x, omega=om.astype(np.float32))
+    assert np.all(m.singular_values() > 0)
+    assert np.abs(m.singular_values() / o.singular - 1.0).max() < 1e-4
+    assert pc.rowwise_rel(m.components().astype(np.float64), o.components).max() < 1e-3
