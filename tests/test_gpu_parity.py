@@ -347,6 +347,11 @@ def test_gram_route_singular_value_floor():
     ctx.close()
 
 
+def test_accurate_route_for_ill_conditioned_fp64(ctx):
+    """the fp64 accuracy route through exact Pca AND the FastICA whitening (ill-conditioned mixing, sigma ratios to 1e-5..1e-6)"""
+    pc.accurate_route_case(ctx)
+
+
 def test_rank_deficient_fp32_on_the_mfma_path(ctx):
     """Rank 10 data in 128 dims with l = k + 10 = 26 > rank, at a size that runs the MFMA kernels: the optimistic
     single-Cholesky re-basing must report pivot breakdowns and the fit must redo itself on the robust path
@@ -394,6 +399,57 @@ def test_fp32_wide_spectrum_through_the_single_pass_qr(ctx):
     assert np.abs(c @ c.T - np.eye(k)).max() < 5e-4
     comp = pc.rowwise_rel(c, o.components)
     assert comp[: k // 2].max() < 1e-3 and np.all(comp <= np.maximum(1e-4, 3e3 * 6e-8 * o.singular[0] / o.singular)), comp
+
+
+def _planted(rng, n, d, s, dtype=np.float32, mean=0.0):
+    r = len(s)
+    u, _ = np.linalg.qr(rng.standard_normal((n, r)))
+    v, _ = np.linalg.qr(rng.standard_normal((d, r)))
+    return ((u * s) @ v.T * 50.0 + mean * rng.standard_normal(d)).astype(dtype)
+
+
+@pytest.mark.parametrize("family", ["geo1", "geo2", "geo3", "geo5", "step", "flat_head", "floor", "rank_lt_k"])
+def test_rpca_spectrum_sweep_against_the_oracle(ctx, family):
+    """RandomizedPca against the fp64 LAPACK oracle (same Omega, the crate's n_iter = 7) over spectrum SHAPES the planted configs do
+    not have: geometric decays of 10 .. 1e5 across the block, a step, an exactly flat head (a cluster among the wanted values: the
+    eigen verdict sends the fit to the Jacobi redo; vectors compared as a subspace), a noise floor inside the oversampling
+    columns, rank below k.  Tolerances follow what fp32 data holds: sigma_j to max(1e-5, 30 eps32 sigma_1 / sigma_j)."""
+    import petal_decomposition_amd as petal
+    from oracle import petal_oracle as po
+    rng = np.random.default_rng(sum(map(ord, family)))
+    n, d, k = 6000, 192, 16
+    l = k + 10
+    if family.startswith("geo"):
+        s = 10.0 ** (-float(family[3:]) * np.arange(2 * k) / (l - 1))
+    elif family == "step":
+        s = np.where(np.arange(2 * k) < k // 2, 1.0, 1e-3) * (1.0 - 0.01 * np.arange(2 * k))
+    elif family == "flat_head":
+        s = np.concatenate([np.ones(6), 0.5 * 0.9 ** np.arange(2 * k - 6)])
+    elif family == "floor":
+        s = np.concatenate([0.8 ** np.arange(k + 3), np.full(k - 3, 1e-4)])
+    else:
+        s = np.concatenate([0.7 ** np.arange(k - 5), np.zeros(k + 5)])
+    x = _planted(rng, n, d, s, mean=3.0)
+    om = rng.standard_normal((d, l))
+    o = po.RandomizedPcaOracle(k, n_iter=7).fit(x.astype(np.float64), omega=om)
+    m = petal.RandomizedPca(k, ctx=ctx, n_iter=7).fit(x, omega=om.astype(np.float32))
+    sg, c = m.singular_values().astype(np.float64), m.components().astype(np.float64)
+    assert np.all(np.isfinite(sg)) and np.all(np.isfinite(c))
+    live = o.singular > 1e-6 * o.singular[0]                                   # (below that fp32 data holds nothing)
+    allowed = np.maximum(1e-5, 30 * 6e-8 * o.singular[0] / np.maximum(o.singular, 1e-300))
+    rel = np.abs(sg / np.maximum(o.singular, 1e-300) - 1.0)
+    assert np.all(rel[live] <= allowed[live]), (family, (rel[live] / allowed[live]).max())
+    assert np.all(sg[~live] <= 1e-5 * o.singular[0])
+    assert np.allclose(m.explained_variance_ratio()[live], o.explained_variance_ratio()[live], rtol=1e-4, atol=1e-9)
+    if family == "flat_head":   # the six equal values span ONE subspace: compare projectors there, vectors behind it
+        p1, p2 = c[:6].T @ c[:6], o.components[:6].T @ o.components[:6]
+        assert np.abs(p1 - p2).max() < 1e-4
+        assert pc.rowwise_rel(c[6:], o.components[6:]).max() < 1e-4
+    else:
+        comp = pc.rowwise_rel(c[live], o.components[live])
+        gap = np.minimum(np.abs(np.diff(o.singular, prepend=np.inf)), np.abs(np.diff(o.singular, append=0.0)))[live]
+        # a vector is determined to ~eps32 sigma_1 / gap (perturbation theory): the tolerance follows the oracle's own gaps
+        assert np.all(comp <= np.maximum(2e-5, 100 * 6e-8 * o.singular[0] / np.maximum(gap, 1e-300))), (family, comp)
 
 
 def test_cfg4_shard_shape_properties():

@@ -64,29 +64,7 @@ def test_ica_literal_convergence_test_at_nc2(ctx):
 
 
 def test_accurate_route_for_ill_conditioned_fp64(ctx):
-    """host logic of the fp64 accuracy route (Cholesky-QR2 + one-sided Jacobi on R^-1, selected when the Gram route's own
-    estimate puts a wanted singular value below 10^-3.5 sigma_1): 1e-9 down to sigma_k = 1e-6 sigma_1, like the crate's gesvd
-    (src/linalg.rs:70-91); the GPU form of this check is test_gpu_parity.py::test_gram_route_singular_value_floor"""
-    import petal_decomposition_amd as petal
-    rng = np.random.default_rng(44)
-    n, d = 600, 10
-    u, _ = np.linalg.qr(rng.standard_normal((n, d)))
-    v, _ = np.linalg.qr(rng.standard_normal((d, d)))
-    sig = 10.0 ** (-np.arange(d) * (6.0 / (d - 1)))          # 1 .. 1e-6
-    x = (u * sig) @ v.T
-    m = petal.PcaBuilder.new(d).centering(False).context(ctx).build().fit(x)
-    assert np.abs(m.singular_values() / sig - 1.0).max() <= 1e-9
-    assert pc.rowwise_rel(m.components(), v.T).max() <= 1e-9
-    # FastICA's whitening divides by sigma: sources of an ill-conditioned mixing come back through the same route
-    s = rng.laplace(size=(4000, 4))
-    a = np.linalg.qr(rng.standard_normal((4, 4)))[0] * np.array([1.0, 1e-2, 1e-4, 1e-5])
-    xi = s @ a.T
-    ica = petal.FastIca(np.random.default_rng(1), ctx)
-    y = np.asarray(ica.fit_transform(xi))
-    ys = (y - y.mean(0)) / y.std(0)
-    ss = (s - s.mean(0)) / s.std(0)
-    corr = np.abs(ys.T @ ss / len(s))
-    assert corr.max(axis=1).min() > 0.99 and len(set(corr.argmax(axis=1))) == 4
+    pc.accurate_route_case(ctx)
 
 
 def test_wide_spectrum_robust_path_refills_dropped_directions(ctx):
