@@ -1447,9 +1447,17 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
         if (wave < NT) stage_z1(0, zr0, wave, zon0);
         if (z2w) stage_z1(0, zr1, WV + wave, zon1);
     }
+#ifdef PETAL_DEBUG_COUNTERS
+    long long ph3[6] = {0, 0, 0, 0, 0, 0};
+    long long tq3 = __builtin_amdgcn_s_memtime();
+#define ATB3_STAMP(i) do { const long long _t = __builtin_amdgcn_s_memtime(); ph3[i] += _t - tq3; tq3 = _t; } while (0)
+#else
+#define ATB3_STAMP(i) do {} while (0)
+#endif
     for (int st = 0; st < nstage; ++st) {
         const int buf = st & 1;
         __syncthreads();  // stage st of B is in sB[buf]; nobody still reads sB[buf ^ 1]
+        ATB3_STAMP(0);
         bf16x8 ah[MT], am[MT], al[MT];
         if (CA) {  // centred in place (a centred COPY would keep 32 more registers alive across the four splits)
 #pragma unroll
@@ -1461,12 +1469,14 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
             split3(x, ah[t], am[t], al[t]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        ATB3_STAMP(1);
         if (st + 1 < nstage) {  // fly under this stage's MFMAs; B first (vmcnt retires in order, see k_xp3)
             if (wave < NT) load_z1(st + 1, zr0, zon0, zoff0);
             if (z2w) load_z1(st + 1, zr1, zon1, zoff1);
             load_a(st + 1, av);
         }
         __builtin_amdgcn_sched_barrier(0);
+        ATB3_STAMP(2);
         // B fragments one tile ahead of the MFMAs that use them (pinned: hoisting all 15 reads costs 48 more registers)
         bf16x8 bh = sB[buf][0 * 64 + lane], bm = sB[buf][1 * 64 + lane], bl = sB[buf][2 * 64 + lane];
 #pragma unroll
@@ -1489,11 +1499,19 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
             bh = nh; bm = nm; bl = nl;
         }
         __builtin_amdgcn_sched_barrier(0);
+        ATB3_STAMP(3);
         if (st + 1 < nstage) {
             if (wave < NT) stage_z1(buf ^ 1, zr0, wave, zon0);
             if (z2w) stage_z1(buf ^ 1, zr1, WV + wave, zon1);
         }
+        ATB3_STAMP(4);
     }
+#ifdef PETAL_DEBUG_COUNTERS
+    if (lane == 0) {
+        for (int e = 0; e < 5; ++e) atomicAdd((unsigned long long*)&g_cyc[10 + e], (unsigned long long)ph3[e]);
+        atomicAdd((unsigned long long*)&g_cyc[15], (unsigned long long)nstage);
+    }
+#endif
     // D[row = 4 q + r][col = i] of tile (t, u):  m = m0 + MT (4 q + r) + t,  col = n0col + 16 u + i
     float* out = part + (int64_t)by * M * Npart;
 #pragma unroll
@@ -4698,7 +4716,16 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
             const double cost = double((active * ns + 255) / 256) / double(ns) * (active * ns <= 256 ? 1.25 : 1.0);
             if (cost < best * 0.97) { best = cost; nsplit = ns; }
         }
+        // among the splits that tie with the best one, the finest up to 96: whole "rounds" of workgroups cost the same in this
+        // model, but a finer split keeps three workgroups on a CU and shortens the tail of the launch (500000 x 512: 2909 us at
+        // 28 splits, 2863 at 42, 2837 at 56, 2757 at 84 -- against 0.4 us of k_sum_parts2 per extra slab)
+        for (int64_t ns = nsplit + 1; ns <= std::min<int64_t>(ns_max, 96); ++ns) {
+            const double cost = double((active * ns + 255) / 256) / double(ns) * (active * ns <= 256 ? 1.25 : 1.0);
+            if (cost <= best * 1.005) nsplit = ns;
+        }
         (void)mslices;
+        static const int ns_env = [] { const char* e = getenv("PETAL_GRAM_NS"); return e ? atoi(e) : 0; }();   // (development knob)
+        if (ns_env > 0) nsplit = std::min<int64_t>(ns_env, ns_max);
         const int64_t chunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
         nsplit = (n + chunk - 1) / chunk;
         double* part = (double*)dev_alloc(d, sizeof(double) * nsplit * M * N);
