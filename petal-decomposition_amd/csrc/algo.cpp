@@ -511,11 +511,11 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         if (!robust) {
             // fast path: one fp64 Cholesky of Yp^T Yp, valid while every pivot stays positive (cond(Yp) <~ 3e7: errors
             // of a few per cent in the weakest pivots merely leave cond(P) ~ 1.x); breakdowns are recorded in ndead.
-            // Y = Yp T is formed inside the next product's operand-packing kernel (op_gemm_xp_prod), not by a launch of its own.
+            // Y = Yp R^-1 is formed inside the next product's operand-packing kernel (op_rebase_xp), by substitution, not by a
+            // launch of its own; R^-1 itself is not needed during the iteration.
             op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Yp, LP, Yp, LP, 0.0, G, LP);
-            op_chol_inv(c.dev, G, L, LP, T.f64(), LP, 1e-15, ndead, LP);
-            dev_set_tag(c.dev, TAG_XP);
-            op_gemm_xp_prod(c.dev, dt, X.p, n, dp, X.ld, muT.p, Yp, LP, LP, T.f64(), LP, LP, Y.f64(), LP, Z.p, LP);  // pca.rs:714
+            dev_set_tag(c.dev, TAG_XP);   // (only the product kernel itself is bracketed)
+            op_rebase_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, G, L, LP, 1e-15, ndead, Yp, LP, LP, T.f64(), LP, Y.f64(), LP, Z.p, LP);  // pca.rs:714
             dev_set_tag(c.dev, TAG_NONE);
         } else {
             // ill-conditioned iterate: precondition with the tall side first.  Z = Xc P gives Z^T Z = P^T (Xc^T Z) =

@@ -2212,6 +2212,70 @@ __global__ __launch_bounds__(256) void k_dgemm_reduce(const double* __restrict__
     C[i * ldc + j] = alpha * acc * (colscale ? colscale[j] : 1.0) + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
 }
 
+// P = A . R^-1 for an upper-triangular R given in "RT form" (k_chol_inv2, rt_form: diagonal 16 x 16 blocks hold T_JJ = R_JJ^-1, the
+// blocks above them R itself): blocked forward substitution P_J = (A_J - sum_{I < J} P_I R_IJ) T_JJ on the fp64 matrix cores, ONE
+// WAVE per 16 rows of A (rows are independent), transposed so that results feed the next product without leaving the registers:
+// X_J = A_J^T lives in the accumulator layout of v_mfma_f64_16x16x4 (register r of lane l = X[(l >> 4) + 4 r][l & 15]);
+// P_I^T = T_II^T X_I and X_J -= R_IJ^T P_I^T take those registers directly as the B operands of MFMA r (the k index is summed
+// over, so the accumulator's k' = (l >> 4) + 4 r order is as good as any when the A operand uses the same one).  The R / T
+// operands come straight from L2 (16 consecutive doubles per row), none of them on the dependency chain, which is
+// nb x 8 MFMAs long.  Epilogue as k_dgemm's: P (fp64) and the three bf16 operand planes of the next split-product GEMM (k_pack_p3's
+// layout), through one LDS transpose.  M (the order of R) is a multiple of 16, <= 144; K a multiple of 16.
+typedef double cf64x4 __attribute__((ext_vector_type(4)));
+constexpr int TRSM_MAXM = 144;
+__host__ __device__ inline size_t trsm_lds_bytes(int M) { return sizeof(double) * 16 * (size_t)(M + 2); }
+template <int NB>   // NB = M / 16 at compile time: straight-line code, so every operand load is issued ahead of the MFMA chain
+__global__ __launch_bounds__(64) void k_trsm_pack(const double* __restrict__ A, int64_t lda, const double* __restrict__ RT, int64_t ldt,
+                                                  int64_t K, double* __restrict__ P_out, int64_t ldpo,
+                                                  bf16x8* __restrict__ pk3, int NTtot) {
+    extern __shared__ __attribute__((aligned(16))) double sP[];   // [16][M + 2]
+    const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+    constexpr int M = 16 * NB, ldsp = M + 2;
+    const int64_t i0 = (int64_t)blockIdx.x * 16;
+    cf64x4 X[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[J][r] = A[(i0 + li) * lda + 16 * J + lk + 4 * r];
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        const double* rrow = RT + (int64_t)(16 * I + lk) * ldt + li;   // row 16 I + lk (+ 4 r), column (16 J +) li
+        cf64x4 pt = cf64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pt = __builtin_amdgcn_mfma_f64_16x16x4f64(rrow[(int64_t)4 * r * ldt + 16 * I], X[I][r], pt, 0, 0, 0);
+#pragma unroll
+        for (int J = I + 1; J < NB; ++J) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                X[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-rrow[(int64_t)4 * r * ldt + 16 * J], pt[r], X[J], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sP[li * ldsp + 16 * I + lk + 4 * r] = pt[r];
+    }
+    __syncthreads();
+    if (P_out)
+        for (int e = lane; e < 16 * M; e += 64) {
+            const int r = e / M, c = e - r * M;
+            P_out[(i0 + r) * ldpo + c] = sP[r * ldsp + c];
+        }
+    if (pk3) {
+        for (int idx = lane; idx < 2 * M; idx += 64) {   // item = 8 rows (group g) of column col
+            const int g = idx / M, col = idx - g * M;
+            f32x8 x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (float)sP[(8 * g + e) * ldsp + col];
+            bf16x8 h, m, l;
+            split3(x, h, m, l);
+            const int64_t c = i0 >> 5, tile = c * NTtot + (col >> 4);
+            const int ln = (col & 15) + 16 * (int)(((i0 & 31) + 8 * g) >> 3);
+            pk3[(tile * 3 + 0) * 64 + ln] = h;
+            pk3[(tile * 3 + 1) * 64 + ln] = m;
+            pk3[(tile * 3 + 2) * 64 + ln] = l;
+        }
+    }
+}
+
 // One workgroup.  The working copy of G lives in LDS as a packed upper triangle (L (L+1) / 2 doubles, 83.5 KB at
 // L = 144); T = R^-1 is built in LDS too when it fits, else directly in global memory.
 //   factorisation: right-looking, ONE barrier per column: rows are left unscaled (U[j][c], d_j = U[j][j]) and the
@@ -2412,7 +2476,7 @@ __host__ __device__ inline size_t chol2_lds_bytes(int L) {
 // larger matrix (blocked factorisation of L > 200: the dependence test stays relative to the ORIGINAL diagonal)
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T,
                                                             int64_t ldt, double rel_tol, int* __restrict__ ndead_out, int Lz,
-                                                            const double* __restrict__ gd_ref) {
+                                                            const double* __restrict__ gd_ref, int rt_form) {
     extern __shared__ __attribute__((aligned(16))) double sm_chol[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int np = L * (L + 1) / 2;
@@ -2547,6 +2611,16 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
     __syncthreads();
     DBG_T(11);
     if (tid == 0 && ndead_out) { int cdead = 0; for (int j = 0; j < L; ++j) cdead += dead[j]; if (cdead > *ndead_out) *ndead_out = cdead; }
+    if (rt_form) {
+        // "RT form": the caller applies R^-1 by a blocked triangular solve (k_trsm_pack) and only needs the inverses of the
+        // diagonal blocks -- the explicit off-diagonal inverse below (30 % of this kernel) is skipped.  Output: diagonal 16 x 16
+        // blocks = T_JJ = R_JJ^-1, blocks above them = R itself, zeros below.
+        for (int e = tid; e < L * L; e += nt) {
+            const int r = e / L, c = e - r * L;
+            T[(int64_t)r * ldt + c] = c >= r ? (((r >> 4) == (c >> 4)) ? Tc[cp(r, c)] : Rc[cp(r, c)]) : 0.0;
+        }
+        return;
+    }
     // ---- off-diagonal blocks of T = R^-1: T_IJ = -T_II sum_{K = I+1 .. J} R_IK T_KJ, as 16 x 16 block products on the fp64
     //      matrix cores.  First R~_IK = T_II R_IK for every off-diagonal block (in place: a block is read and written by
     //      one wave only), then block super-diagonal by block super-diagonal T_IJ = -sum_K R~_IK T_KJ.
@@ -4405,10 +4479,10 @@ static void launch_xp(Dev* d, const float* X, int64_t n, int K, int64_t ldx, con
 // split-product path forms it inside its pack kernel, every other path gets it from a GEMM launch first
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
-                         int64_t prod_lda, double* prod_out, int64_t prod_ldo);
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt);
 void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                 int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq) {
-    gemm_xp_impl(d, dt, X, n, K, ldx, mu, P, N, ldp, bias, Z, ldz, sumsq, nullptr, 0, 0, nullptr, 0);
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, P, N, ldp, bias, Z, ldz, sumsq, nullptr, 0, 0, nullptr, 0, false);
 }
 void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* A, int64_t M,
                      int64_t lda, const double* T, int64_t N, int64_t ldt, double* P_out, int64_t ldpo, void* Z, int64_t ldz) {
@@ -4416,7 +4490,7 @@ void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_
                        aligned16(X) && (!mu || aligned16(mu)) && ldz % 4 == 0 && aligned16(Z) && K < (1 << 24) && N < (1 << 24);
     if (fused) {
         double* tmpo = P_out ? nullptr : (double*)dev_alloc(d, sizeof(double) * K * N);
-        gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, N, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out ? P_out : tmpo, P_out ? ldpo : N);
+        gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, N, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out ? P_out : tmpo, P_out ? ldpo : N, false);
         if (tmpo) dev_free(d, tmpo);
         return;
     }
@@ -4430,7 +4504,7 @@ void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_
 }
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
-                         int64_t prod_lda, double* prod_out, int64_t prod_ldo) {
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt) {
     if (n == 0 || N == 0) return;
     const bool mfma = dt == F32 && K % 16 == 0 && K > 0 && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
                       K < (1 << 24) && N < (1 << 24) && N % 16 == 0 && ldz % 4 == 0 && aligned16(Z) && (!bias || aligned16(bias));
@@ -4501,6 +4575,19 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         if (prod_A) {
             // P = prod_A . P: the fp64 GEMM kernel writes the product (prod_out) AND its operand planes from its epilogue
             if (K % 32 == 16) HIP_CHECK(hipMemsetAsync(Ppk3 + (total - (int64_t)NTtot * 64) * 3, 0, sizeof(bf16x8) * NTtot * 192, d->stream));
+            if (prod_rt)   // P is R in RT form: blocked triangular solve instead of the product with the explicit inverse
+                switch ((int)(N / 16)) {
+#define PETAL_TRSM_CASE(NB)                                                                                                        \
+    case NB:                                                                                                                       \
+        hipLaunchKernelGGL(k_trsm_pack<NB>, dim3(cdiv(K, 16)), dim3(64), trsm_lds_bytes(16 * NB), d->stream, prod_A, prod_lda, P,  \
+                           ldp, K, prod_out, prod_ldo, Ppk3, NTtot);                                                               \
+        break
+                    PETAL_TRSM_CASE(1); PETAL_TRSM_CASE(2); PETAL_TRSM_CASE(3); PETAL_TRSM_CASE(4); PETAL_TRSM_CASE(5);
+                    PETAL_TRSM_CASE(6); PETAL_TRSM_CASE(7); PETAL_TRSM_CASE(8); PETAL_TRSM_CASE(9);
+#undef PETAL_TRSM_CASE
+                    default: throw std::runtime_error("k_trsm_pack: order out of range");
+                }
+            else
             hipLaunchKernelGGL(k_dgemm, dim3(cdiv(N, 16), cdiv(K, 16)), dim3(16, 16), 0, d->stream, false, false, K, N, prod_M, 1.0,
                                prod_A, prod_lda, P, ldp, 0.0, prod_out, prod_ldo, prod_M, (double*)nullptr, (const double*)nullptr,
                                Ppk3, NTtot);
@@ -5157,7 +5244,7 @@ static void chol_inv_blocked(Dev* d, const double* G, int64_t L, int64_t ldg, do
         if (j0 > 0)  // block row J of the Schur complement (its diagonal block and everything right of it)
             op_dgemm(d, true, false, bj, L - j0, j0, -1.0, R + j0, L, R + j0, L, 1.0, W + j0 * L + j0, L);
         hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)bj), d->stream, W + j0 * L + j0, (int)bj, L,
-                           T + j0 * ldt + j0, ldt, rel_tol, ndead, (int)bj, (const double*)(gd + j0));
+                           T + j0 * ldt + j0, ldt, rel_tol, ndead, (int)bj, (const double*)(gd + j0), 0);
         launch_check();
         if (rest > 0)
             op_dgemm(d, true, false, bj, rest, bj, 1.0, T + j0 * ldt + j0, ldt, W + j0 * L + j0 + bj, L, 0.0, R + j0 * L + j0 + bj, L);
@@ -5172,6 +5259,27 @@ static void chol_inv_blocked(Dev* d, const double* G, int64_t L, int64_t ldg, do
     dev_free(d, tmp); dev_free(d, gd); dev_free(d, R); dev_free(d, W);
 }
 
+// One re-basing step of the power iteration (see ops.h).  With the split-product kernels and L <= 140 the inverse of R is never
+// formed: k_chol_inv2 stops after the diagonal-block inverses ("RT form") and k_trsm_pack applies R^-1 by blocked substitution
+// while it packs the operand planes of the product that follows.
+void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
+                  int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
+                  double* P_out, int64_t ldpo, void* Z, int64_t ldz) {
+    static const bool no_rt = getenv("PETAL_NO_TRSM") != nullptr;
+    const bool fused = dt == F32 && gemm_split_product(d) && n >= 64 && K % 16 == 0 && K > 0 && M % 16 == 0 && ldx % 4 == 0 &&
+                       aligned16(X) && (!mu || aligned16(mu)) && ldz % 4 == 0 && aligned16(Z) && K < (1 << 24) && M < (1 << 24);
+    if (!fused || no_rt || L == 0 || L > CHOL2_MAXL || M > TRSM_MAXM || M < L || P_out == nullptr) {
+        op_chol_inv(d, G, L, ldg, T, ldt, rel_tol, ndead, M);
+        op_gemm_xp_prod(d, dt, X, n, K, ldx, mu, A, M, lda, T, M, ldt, P_out, ldpo, Z, ldz);
+        return;
+    }
+    set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
+    hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead,
+                       (int)M, (const double*)nullptr, 1);
+    launch_check();
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, M, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, true);
+}
+
 void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz) {
     if (L == 0) return;
     if (Lz < L) Lz = L;
@@ -5180,7 +5288,7 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     if (L <= CHOL2_MAXL && !force_old) {
         set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
         hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol,
-                           ndead, (int)Lz, (const double*)nullptr);
+                           ndead, (int)Lz, (const double*)nullptr, 0);
         launch_check();
         return;
     }

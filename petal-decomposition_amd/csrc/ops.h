@@ -74,6 +74,12 @@ void op_gemm_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ld
 void op_gemm_xp_prod(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
                      const double* A, int64_t M, int64_t lda, const double* T, int64_t N, int64_t ldt,
                      double* P_out, int64_t ldpo, void* Z, int64_t ldz);
+// One re-basing step of the power iteration: G (L x L, ldg) = R^T R, P_out (K x M fp64, ldpo) = A R^-1 (A: K x M, lda; columns
+// L .. M of the result are zero), Z = (X - mu) . P_out.  Same results contract as op_chol_inv(G -> T, Lz = M) followed by
+// op_gemm_xp_prod(A, T); T (M x M, ldt) is SCRATCH here -- it may hold R^-1 or a factored form of it, callers must not read it.
+void op_rebase_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
+                  int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
+                  double* P_out, int64_t ldpo, void* Z, int64_t ldz);
 // C[M x N] (f64, ldc) = (A - muA)^T . (B - muB),  A: n x M (lda), B: n x N (ldb), reduction over n rows.
 // precise: every product and the whole accumulation in fp64 (needed where the result's small eigenvalues
 // matter: exact Pca, FastICA whitening); otherwise fp32 MFMA chunks combined in fp64.
