@@ -170,6 +170,19 @@ void op_sigma_inv(Dev*, const double* lam, double* sig, double* inv, int64_t cou
     const double s0 = count ? sig[0] : 0.0;
     for (int64_t i = 0; i < count; ++i) inv[i] = (sig[i] > thr * s0 && sig[i] > 0) ? 1.0 / sig[i] : 0.0;
 }
+void op_components_out(Dev*, int dt, const double* Bt, int64_t ldb, const double* Uh, int64_t ldu, const double* lam, double thr,
+                       int64_t d, int64_t L, int64_t k, void* comp) {
+    const double s0 = std::sqrt(std::max(lam[0], 0.0));
+    for (int64_t j = 0; j < k; ++j) {
+        const double sj = std::sqrt(std::max(lam[j], 0.0)), inv = (sj > thr * s0 && sj > 0) ? 1.0 / sj : 0.0;
+        for (int64_t i = 0; i < d; ++i) {
+            double a = 0;
+            for (int64_t l = 0; l < L; ++l) a += Bt[i * ldb + l] * Uh[l * ldu + j];
+            if (dt == F32) static_cast<float*>(comp)[j * d + i] = float(a * inv);
+            else static_cast<double*>(comp)[j * d + i] = a * inv;
+        }
+    }
+}
 void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz) {
     if (Lz < L) Lz = L;
     std::vector<double> R(size_t(L) * L, 0.0);

@@ -450,16 +450,16 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
 
     // Everything the host reads back sits in ONE device buffer behind the all-reduced [Yp | tv] pair, so a fit ends with one
     // device-to-host copy (five separate small copies cost 4 us each):
-    //   res = [ Yp (dp LP) | tv | ndead | lam (LP) | V (dp LP) | sig (LP) | mu64 (2 dp) | flip (4 LP) ]
-    const int64_t o_tv = dp * LP, o_dead = o_tv + 1, o_lam = o_dead + 1, o_V = o_lam + LP, o_sig = o_V + dp * LP, o_mu = o_sig + LP,
-                  o_flip = o_mu + 2 * dp, res_len = o_flip + 4 * LP;
+    //   res = [ Yp (dp LP) | tv | ndead | lam (LP) | mu64 (2 dp) | flip (4 LP) ]
+    // and the components leave in their own k x d buffer, already in the caller's layout and type (op_components_out): 128 KB at
+    // configs[1] instead of the 320 KB fp64 d x l matrix V, and nothing for the host to transpose.
+    const int64_t o_tv = dp * LP, o_dead = o_tv + 1, o_lam = o_dead + 1, o_mu = o_lam + LP, o_flip = o_mu + 2 * dp, res_len = o_flip + 4 * LP;
+    DBuf comp_dev(c.dev, esz * size_t(std::max<int64_t>(k, 1)) * d);
     DBuf res(c.dev, sizeof(double) * res_len);
     double* const Yp = res.f64();
     double* const tvp = res.f64() + o_tv;
     int* const ndead = reinterpret_cast<int*>(res.f64() + o_dead);
     double* const lam = res.f64() + o_lam;
-    double* const V = res.f64() + o_V;
-    double* const sig = res.f64() + o_sig;
     double* const mu64 = res.f64() + o_mu;
     double* const flip = res.f64() + o_flip;
     DBuf muT;
@@ -485,7 +485,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     double* const G = Gb.f64();
     DBuf T(c.dev, sizeof(double) * LP * LP), Y(c.dev, sizeof(double) * dp * LP);
     DBuf Bt(c.dev, sizeof(double) * dp * LP), S(c.dev, sizeof(double) * LP * LP), Uh(c.dev, sizeof(double) * LP * LP);
-    DBuf inv(c.dev, sizeof(double) * LP), M2(c.dev, sizeof(double) * LP * LP);
+    DBuf M2(c.dev, sizeof(double) * LP * LP);
     void* Uout = nullptr;  // where the pipeline left U (n x LP; its first kp columns)
     const int64_t kp = std::min(LP, round_up(std::max<int64_t>(k, 1), 16));
     // The whole device pipeline.  It runs OPTIMISTICALLY first (robust = false): every power iteration re-bases with
@@ -587,25 +587,29 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // solves with Jacobi.  Saves the two fallback launches that return at once on every separated spectrum.
     if (!robust) op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, false, LP, std::max<int64_t>(k, 1), ndead);
     else op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, true, LP);  // (zero padding of Uh included)
-    op_sigma_inv(c.dev, lam, sig, inv.f64(), LP, dt == F32 ? 1e-7 : 1e-12);
-    // V[:, j] = B^T u_j / sigma_j
-    op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Bt.f64(), LP, Uh.f64(), LP, 0.0, V, LP, inv.f64());
+    // rows of V^T: v_j = B^T u_j / sigma_j, sigma_j = sqrt(lam_j) (the host takes the same square roots of lam)
+    op_components_out(c.dev, dt, Bt.f64(), LP, Uh.f64(), LP, lam, dt == F32 ? 1e-7 : 1e-12, d, L, k, comp_dev.p);
 
     // U = Q Uh = Usrc (T Uh) (pca.rs:683) and svd_flip (pca.rs:684)
-    // (only the k columns svd_flip signs and fit_transform returns: kp = k rounded up to whole 16-column tiles)
-    op_dgemm(c.dev, false, false, LP, LP, LP, 1.0, T.f64(), LP, Uh.f64(), LP, 0.0, M2.f64(), LP);
-    op_gemm_xp(c.dev, dt, Usrc, n, LP, LP, nullptr, M2.f64(), kp, LP, nullptr, Ubuf, LP, nullptr);
+    // (only the k columns svd_flip signs and fit_transform returns: kp = k rounded up to whole 16-column tiles; the small
+    // product T Uh is formed by the operand-packing kernel of the n x l product)
+    op_gemm_xp_prod(c.dev, dt, Usrc, n, LP, LP, nullptr, T.f64(), LP, LP, Uh.f64(), kp, LP, M2.f64(), LP, Ubuf, LP);
     Uout = Ubuf;
     };  // pipeline
 
     // results (pca.rs:543-547): one copy queued behind the pipeline, ONE synchronisation
     const bool slot_flip = !sharded(c) || dt == F32;  // (sharded fp64 decides the signs in three dependent all-reduce rounds)
     std::vector<double> hres(size_t(res_len - o_tv)), sg;
+    static const bool host_tl = getenv("PETAL_HOST_TIMELINE") != nullptr;
+    double t_q = 0, t_s = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
         if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip);
         dev_d2h(c.dev, hres.data(), tvp, sizeof(double) * hres.size());
+        if (k > 0) dev_d2h(c.dev, components, comp_dev.p, esz * size_t(k) * d);
+        t_q = timer.ms();
         dev_sync(c.dev);
+        t_s = timer.ms();
         int hdead = 0;
         std::memcpy(&hdead, &hres[o_dead - o_tv], sizeof(int));
         if (attempt == 1 || hdead == 0) break;
@@ -617,16 +621,20 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     } else {
         sg = flip_signs(c, dt, Uout, n, kp, LP, ri.row_offset);
     }
-    const double* hV = &hres[o_V - o_tv];
-    const double* hs = &hres[o_sig - o_tv];
+    const double* hlam = &hres[o_lam - o_tv];
+    std::vector<double> hs(size_t(std::max<int64_t>(k, 1)), 0.0);
+    for (int64_t j = 0; j < k; ++j) hs[j] = std::sqrt(std::max(hlam[j], 0.0));
     const double* hmu = &hres[o_mu - o_tv];
     double htv = hres[0];
     if (tv_from_sq) {  // sum (x - mu)^2 = sum x^2 - n mu^2 per column, in fp64
         htv = 0;
         for (int64_t j = 0; j < d; ++j) htv += std::max(0.0, hmu[dp + j] - ri.n_total * hmu[j] * hmu[j]);
     }
-    for (int64_t j = 0; j < k; ++j) {
-        for (int64_t i = 0; i < d; ++i) put_elem(components, dt, j * d + i, sg[j] * hV[size_t(i) * LP + j]);
+    for (int64_t j = 0; j < k; ++j) {   // svd_flip's sign on row j of the components (already in place, pca.rs:684)
+        if (sg[j] < 0) {
+            if (dt == F32) { float* r = static_cast<float*>(components) + j * d; for (int64_t i = 0; i < d; ++i) r[i] = -r[i]; }
+            else { double* r = static_cast<double*>(components) + j * d; for (int64_t i = 0; i < d; ++i) r[i] = -r[i]; }
+        }
         put_elem(singular, dt, j, hs[j]);
     }
     for (int64_t i = 0; i < d; ++i) put_elem(means, dt, i, hmu[i]);
@@ -639,6 +647,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         op_scale_cols(c.dev, dt, Uout, n, k, LP, dsc.f64());
         emit(c, dt, Uout, n, k, LP, *y_out);
     }
+    if (host_tl) std::fprintf(stderr, "rpca_fit host: queued %.1f us, synced %.1f us, done %.1f us\n", t_q * 1e3, t_s * 1e3, timer.ms() * 1e3);
     finish_stats(c, timer);
 }
 

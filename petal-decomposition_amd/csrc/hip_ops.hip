@@ -2198,6 +2198,11 @@ __global__ __launch_bounds__(256) void k_dgemm(bool ta, bool tb, int64_t M, int6
             pk3[(tile * 3 + 0) * 64 + lane] = h;
             pk3[(tile * 3 + 1) * 64 + lane] = m;
             pk3[(tile * 3 + 2) * 64 + lane] = l;
+            if ((M & 31) == 16 && i0 + 16 == M) {   // the last 32-row chunk is half empty: its upper operand groups are zeros
+                bf16x8 z; for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) pk3[(tile * 3 + pl) * 64 + lane + 32] = z;
+            }
         }
     }
 }
@@ -2272,6 +2277,11 @@ __global__ __launch_bounds__(64) void k_trsm_pack(const double* __restrict__ A, 
             pk3[(tile * 3 + 0) * 64 + ln] = h;
             pk3[(tile * 3 + 1) * 64 + ln] = m;
             pk3[(tile * 3 + 2) * 64 + ln] = l;
+            if ((K & 31) == 16 && i0 + 16 == K) {   // half-empty last chunk: zero operand groups for the rows that do not exist
+                bf16x8 z; for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) pk3[(tile * 3 + pl) * 64 + ln + 32] = z;
+            }
         }
     }
 }
@@ -4316,6 +4326,57 @@ __global__ void k_sigma_inv(const double* __restrict__ lam, double* __restrict__
     sig[e] = s;
     inv[e] = (s > thr * s0 && s > 0.0) ? 1.0 / s : 0.0;
 }
+// The fitted components straight in the caller's layout and type (pca.rs:543: rows of V^T): comp[j][i] = (T)(B^T u_j)[i] / sigma_j
+// for j < k, from Bt (d x l fp64), the eigenvectors Uh (columns) and eigenvalues lam of B B^T.  1 / sigma_j is formed here
+// (sigma_j = sqrt(lam_j); 0 below thr sigma_0, the rule of k_sigma_inv), so the fit ends with one small launch and a k x d copy in
+// the output type instead of a scaling launch, an fp64 d x l product and a d x l fp64 copy.  Block = 64 i's x 16 j's.
+template <class T>
+__global__ __launch_bounds__(256) void k_components_out(const double* __restrict__ Bt, int64_t ldb, const double* __restrict__ Uh,
+                                                        int64_t ldu, const double* __restrict__ lam, double thr, int64_t d, int L,
+                                                        int64_t k, T* __restrict__ comp) {
+    __shared__ double sB[64][65];       // [i][l] of the current 64-wide slice of l
+    __shared__ double sU[64][16];       // [l][j]
+    const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 16;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int l0 = 0; l0 < L; l0 += 64) {
+        // (all of a slice's loads are issued before the first LDS store waits for one: a runtime-trip loop of load -> store
+        // pairs pays an L2 round trip per pair)
+        double vb[16], vu[4];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = (tid >> 6) + 4 * u, l = l0 + (tid & 63);
+            vb[u] = (i0 + r < d && l < L) ? Bt[(i0 + r) * ldb + l] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = l0 + (tid >> 4) + 16 * u;
+            vu[u] = (l < L && j0 + ti < k) ? Uh[(int64_t)l * ldu + j0 + ti] : 0.0;
+        }
+        __syncthreads();   // (the previous slice's readers are done)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sB[(tid >> 6) + 4 * u][tid & 63] = vb[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sU[(tid >> 4) + 16 * u][ti] = vu[u];
+        __syncthreads();
+#pragma unroll 8
+        for (int l = 0; l < 64; ++l) {
+            const double u = sU[l][tj];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += sB[ti + 16 * r][l] * u;
+        }
+    }
+    const int64_t j = j0 + tj;
+    if (j < k) {
+        const double s = sqrt(fmax(lam[j], 0.0)), s0 = sqrt(fmax(lam[0], 0.0));
+        const double inv = (s > thr * s0 && s > 0.0) ? 1.0 / s : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t i = i0 + ti + 16 * r;
+            if (i < d) comp[j * d + i] = (T)(acc[r] * inv);
+        }
+    }
+}
 // column means from the per-block partial sums of k_colsum_part2, in one launch: fixed-order fp64 sum of the parts,
 // mu64[j] = sum / n_total for j < d (the sums of squares at d <= j < w stay unscaled), muT[j] = (T)mu64[j]
 template <class T>
@@ -4446,7 +4507,6 @@ void op_sigma_inv(Dev* d, const double* lam, double* sig, double* inv, int64_t c
     hipLaunchKernelGGL(k_sigma_inv, dim3(cdiv(count, 256)), dim3(256), 0, d->stream, lam, sig, inv, count, thr);
     launch_check();
 }
-
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // split-product (bf16x3, see k_xp3) kernels unless the ctx asks for the fp32-MFMA ones (petal_ctx_set_gemm_mode /
 // PETAL_GEMM=fp32)
@@ -4456,6 +4516,16 @@ static void set_max_lds(Dev* d, const void* fn) {
     if (d->max_lds_set.count(fn)) return;
     HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     d->max_lds_set.insert(fn);
+}
+void op_components_out(Dev* d, int dt, const double* Bt, int64_t ldb, const double* Uh, int64_t ldu, const double* lam, double thr,
+                       int64_t dd, int64_t L, int64_t k, void* comp) {
+    if (k == 0 || dd == 0) return;
+    const dim3 grid(cdiv(dd, 64), cdiv(k, 16));
+    if (dt == F32)
+        hipLaunchKernelGGL(k_components_out<float>, grid, dim3(256), 0, d->stream, Bt, ldb, Uh, ldu, lam, thr, dd, (int)L, k, (float*)comp);
+    else
+        hipLaunchKernelGGL(k_components_out<double>, grid, dim3(256), 0, d->stream, Bt, ldb, Uh, ldu, lam, thr, dd, (int)L, k, (double*)comp);
+    launch_check();
 }
 static int num_cus(Dev* d) {
     if (!d->num_cu) { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, d->device)); d->num_cu = prop.multiProcessorCount; }
@@ -4574,7 +4644,6 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
         if (prod_A) {
             // P = prod_A . P: the fp64 GEMM kernel writes the product (prod_out) AND its operand planes from its epilogue
-            if (K % 32 == 16) HIP_CHECK(hipMemsetAsync(Ppk3 + (total - (int64_t)NTtot * 64) * 3, 0, sizeof(bf16x8) * NTtot * 192, d->stream));
             if (prod_rt)   // P is R in RT form: blocked triangular solve instead of the product with the explicit inverse
                 switch ((int)(N / 16)) {
 #define PETAL_TRSM_CASE(NB)                                                                                                        \
@@ -5149,17 +5218,20 @@ void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode)
 // G = A^T A for a tall-skinny fp64 A (K x Mn, Mn a multiple of 16): the re-basing Gram matrices (l x l from a d x l
 // iterate).  One workgroup per upper 16 x 16 tile, its four waves take a quarter of K each on the fp64 matrix cores and
 // add through LDS; the mirror tile is written too.  (The general kernel needs a split-K launch plus a reduce launch here.)
-__global__ __launch_bounds__(256) void k_syrk_f64(const double* __restrict__ A, int64_t lda, int Mn, int64_t K,
-                                                  double* __restrict__ C, int64_t ldc) {
+// SYM = false: C = A^T B for two such matrices (every tile computed; H = P^T Yp of the one-pass thin QR).
+template <bool SYM>
+__global__ __launch_bounds__(256) void k_syrk_f64(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+                                                  int Mn, int64_t K, double* __restrict__ C, int64_t ldc) {
     __shared__ double red[3][4][64];
     const int nt = Mn >> 4;
     int t = blockIdx.x, ti = 0;
-    while (t >= nt - ti) { t -= nt - ti; ++ti; }
-    const int tj = ti + t;
+    if (SYM) { while (t >= nt - ti) { t -= nt - ti; ++ti; } t += ti; }
+    else { ti = t / nt; t -= ti * nt; }
+    const int tj = t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
     const int64_t kq = ((K + 3) / 4 + 3) / 4 * 4, kbeg = wave * kq, kend = min(K, kbeg + kq);
     const double* pa = A + 16 * ti + i;
-    const double* pb = A + 16 * tj + i;
+    const double* pb = B + 16 * tj + i;
     f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
     // the kernel is pure load latency (a wave's 32 MFMAs take 1 us): all operands of a 128-row batch are requested at once
     for (int64_t kb = kbeg; kb < kend; kb += 128) {
@@ -5169,7 +5241,7 @@ __global__ __launch_bounds__(256) void k_syrk_f64(const double* __restrict__ A, 
             const int64_t k = kb + 4 * u + q;
             const bool in = k < kend;
             a[u] = in ? pa[k * lda] : 0.0;
-            b[u] = in ? pb[k * lda] : 0.0;
+            b[u] = in ? pb[k * ldb] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
@@ -5185,7 +5257,7 @@ __global__ __launch_bounds__(256) void k_syrk_f64(const double* __restrict__ A, 
             const double v = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
             const int row = 16 * ti + q + 4 * r, col = 16 * tj + i;
             C[(int64_t)row * ldc + col] = v;
-            if (ti != tj) C[(int64_t)col * ldc + row] = v;
+            if (SYM && ti != tj) C[(int64_t)col * ldc + row] = v;
         }
     }
 }
@@ -5193,9 +5265,12 @@ __global__ __launch_bounds__(256) void k_syrk_f64(const double* __restrict__ A, 
 void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const double* colscale) {
     if (M == 0 || N == 0) return;
-    if (!colscale && ta && !tb && A == B && lda == ldb && M == N && M % 16 == 0 && M <= 256 && K >= 64 && alpha == 1.0 && beta == 0.0) {
+    if (!colscale && ta && !tb && M == N && M % 16 == 0 && M <= 256 && K >= 64 && alpha == 1.0 && beta == 0.0) {
         const int nt = (int)(M / 16);
-        hipLaunchKernelGGL(k_syrk_f64, dim3(nt * (nt + 1) / 2), dim3(256), 0, d->stream, A, lda, (int)M, K, C, ldc);
+        if (A == B && lda == ldb)
+            hipLaunchKernelGGL(k_syrk_f64<true>, dim3(nt * (nt + 1) / 2), dim3(256), 0, d->stream, A, lda, B, ldb, (int)M, K, C, ldc);
+        else
+            hipLaunchKernelGGL(k_syrk_f64<false>, dim3(nt * nt), dim3(256), 0, d->stream, A, lda, B, ldb, (int)M, K, C, ldc);
         launch_check();
         return;
     }

@@ -126,6 +126,10 @@ void op_dgemm(Dev*, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double al
 // sig[i] = sqrt(max(lam[i], 0)); inv[i] = sig[i] > thr * sig[0] ? 1 / sig[i] : 0   (the two op_dvec steps of an SVD from
 // eigenvalues, in one launch)
 void op_sigma_inv(Dev*, const double* lam, double* sig, double* inv, int64_t count, double thr);
+// comp[j][i] (k x d row-major, the input dtype) = (Bt u_j)[i] / sigma_j: rows of V^T from Bt (d x L, ldb), the eigenvectors Uh
+// (columns, ldu) and eigenvalues lam of B B^T; sigma_j = sqrt(max(lam_j, 0)), 1 / sigma_j = 0 at or below thr * sigma_0.
+void op_components_out(Dev*, int dtype, const double* Bt, int64_t ldb, const double* Uh, int64_t ldu, const double* lam, double thr,
+                       int64_t d, int64_t L, int64_t k, void* comp);
 // G (L x L, SPD up to rounding) = R^T R;  T = R^{-1} (upper triangular, L x L, ldt).
 // A pivot with r_jj^2 <= rel_tol * G_jj (or G_jj <= 0) marks column j as dependent: T[:, j] = 0.
 // Only the upper triangle of G is read.  ndead (nullable, device int): *ndead = max(*ndead, number of dependent columns).
