@@ -124,9 +124,11 @@ std::vector<double> signs_from_triple(const std::vector<double>& h, int64_t L) {
 // all-reduced keys of the sharded fp32 form in the last L -- for a caller that ships it to the host with its other results
 // (flip_slot_keys() says which part to decode with signs_from_triple()).  Not for sharded fp64 (three dependent rounds).
 bool flip_slot_keys(const petal_ctx& c, int dtype) { return sharded(c) && dtype == F32; }
-void flip_signs_to_slot(petal_ctx& c, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* slot) {
+// scanned = true: the product kernel already left the (max, row, sign) triple in the slot (op_gemm_xp_prod_absmax)
+void flip_signs_to_slot(petal_ctx& c, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* slot,
+                        bool scanned = false) {
     if (L == 0) return;
-    op_col_absmax(c.dev, dtype, U, n, L, ldu, row_offset, slot, slot + L, slot + 2 * L);
+    if (!scanned) op_col_absmax(c.dev, dtype, U, n, L, ldu, row_offset, slot, slot + L, slot + 2 * L);
     if (flip_slot_keys(c, dtype)) {
         op_flip_key(c.dev, slot, slot + 3 * L, L);
         allreduce_f64(c, slot + 3 * L, L, PETAL_MAX);
@@ -487,6 +489,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     DBuf Bt(c.dev, sizeof(double) * dp * LP), S(c.dev, sizeof(double) * LP * LP), Uh(c.dev, sizeof(double) * LP * LP);
     DBuf M2(c.dev, sizeof(double) * LP * LP);
     void* Uout = nullptr;  // where the pipeline left U (n x LP; its first kp columns)
+    const bool slot_flip = !sharded(c) || dt == F32;  // (sharded fp64 decides the signs in three dependent all-reduce rounds)
     const int64_t kp = std::min(LP, round_up(std::max<int64_t>(k, 1), 16));
     // The whole device pipeline.  It runs OPTIMISTICALLY first (robust = false): every power iteration re-bases with
     // the single-Cholesky fast path and no host round trip; the kernels record the worst pivot breakdown in `ndead`,
@@ -593,18 +596,21 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // U = Q Uh = Usrc (T Uh) (pca.rs:683) and svd_flip (pca.rs:684)
     // (only the k columns svd_flip signs and fit_transform returns: kp = k rounded up to whole 16-column tiles; the small
     // product T Uh is formed by the operand-packing kernel of the n x l product)
-    op_gemm_xp_prod(c.dev, dt, Usrc, n, LP, LP, nullptr, T.f64(), LP, LP, Uh.f64(), kp, LP, M2.f64(), LP, Ubuf, LP);
+    if (slot_flip)   // ... and svd_flip's column scan by its epilogue
+        op_gemm_xp_prod_absmax(c.dev, dt, Usrc, n, LP, LP, nullptr, T.f64(), LP, LP, Uh.f64(), kp, LP, M2.f64(), LP, Ubuf, LP,
+                               ri.row_offset, flip, flip + kp, flip + 2 * kp);
+    else
+        op_gemm_xp_prod(c.dev, dt, Usrc, n, LP, LP, nullptr, T.f64(), LP, LP, Uh.f64(), kp, LP, M2.f64(), LP, Ubuf, LP);
     Uout = Ubuf;
     };  // pipeline
 
     // results (pca.rs:543-547): one copy queued behind the pipeline, ONE synchronisation
-    const bool slot_flip = !sharded(c) || dt == F32;  // (sharded fp64 decides the signs in three dependent all-reduce rounds)
     std::vector<double> hres(size_t(res_len - o_tv)), sg;
     static const bool host_tl = getenv("PETAL_HOST_TIMELINE") != nullptr;
     double t_q = 0, t_s = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
-        if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip);
+        if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip, true);
         dev_d2h(c.dev, hres.data(), tvp, sizeof(double) * hres.size());
         if (k > 0) dev_d2h(c.dev, components, comp_dev.p, esz * size_t(k) * d);
         t_q = timer.ms();

@@ -908,7 +908,8 @@ template <int RT, int NT, int DEPTH, bool CENTER, int WVK = 4, int OCC = PETAL_X
 __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
                                                             const float* __restrict__ mu, const bf16x8* __restrict__ Ppk3,
                                                             int NTtot, int nt0, int N, const float* __restrict__ bias,
-                                                            float* __restrict__ Z, int64_t ldz) {
+                                                            float* __restrict__ Z, int64_t ldz, double* __restrict__ amax,
+                                                            int64_t am_ld) {
     constexpr int PITEMS = NT * 192;               // 16-B items of one P chunk (NT tiles x 3 planes x 64 lanes)
     constexpr int NTHR = 64 * WVK;
     constexpr int PI = (PITEMS + NTHR - 1) / NTHR;  // per thread
@@ -1044,6 +1045,69 @@ __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__
         for (int t = 0; t < RT; ++t) {
             const int64_t row = row0 + 16 * t + i;
             if (row < n) *reinterpret_cast<f32x4*>(Z + row * ldz + col) = acc[t][u] + bv;
+        }
+    }
+    if (amax) {
+        // svd_flip's scan (pca.rs:826-839: per column the first row of largest |u|) on the accumulators instead of a pass over the
+        // stored product: one partial (max, row, sign) per workgroup and column, k_absmax_part2's format, reduced by
+        // k_absmax_final.  Ordering key: |u|'s bits above (lowest row first, sign) -- a plain unsigned maximum.
+        unsigned long long* sK = reinterpret_cast<unsigned long long*>(sm_xp3);   // [WVK][NT 16]
+        __syncthreads();   // (the last chunk's P stage is dead)
+        constexpr int NG = (NT * 4 + 15) / 16;     // column slots of a lane (NT tiles x 4), in groups of 16
+        unsigned long long key[NG * 16];
+#pragma unroll
+        for (int sl = 0; sl < NG * 16; ++sl) key[sl] = 0;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int col = 16 * (nt0 + u) + 4 * q;
+            if (bias && col < N) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const float v = acc[t][u][e] + bv[e];
+                    const int lrow = wave * (16 * RT) + 16 * t + i;
+                    if (row0 + 16 * t + i < n && v == v) {
+                        const unsigned long long kk = ((unsigned long long)__float_as_uint(fabsf(v)) << 32) |
+                                                      ((unsigned long long)(unsigned)(0x7fffffff - lrow) << 1) | (__float_as_uint(v) >> 31);
+                        key[u * 4 + e] = kk > key[u * 4 + e] ? kk : key[u * 4 + e];
+                    }
+                }
+            }
+        }
+        // maximum over the 16 row lanes of each slot as a transposing butterfly (15 exchanges per group of 16 slots instead of
+        // 64): at distance h a lane keeps the half of its slots that matches its bit h and hands over the other half; after four
+        // steps lane i holds slot i of the group
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int h = 8; h >= 1; h >>= 1) {
+#pragma unroll
+                for (int sl = 0; sl < h; ++sl) {
+                    const unsigned long long a = key[16 * g + sl], b = key[16 * g + sl + h];
+                    const bool up = (i & h) != 0;
+                    const unsigned long long o = __shfl_xor(up ? a : b, h, 64), keep = up ? b : a;
+                    key[16 * g + sl] = o > keep ? o : keep;
+                }
+            }
+            const int sl = 16 * g + i;                      // = 4 u + e
+            if (sl < NT * 4) sK[wave * (NT * 16) + (sl >> 2) * 16 + 4 * q + (sl & 3)] = key[16 * g];
+        }
+        __syncthreads();
+        for (int c = tid; c < NT * 16; c += NTHR) {
+            unsigned long long key = sK[c];
+#pragma unroll
+            for (int w = 1; w < WVK; ++w) { const unsigned long long o = sK[w * (NT * 16) + c]; key = o > key ? o : key; }
+            const int col = 16 * nt0 + c;
+            if (col < am_ld) {
+                const int64_t o = (int64_t)blockIdx.x * am_ld + col, plane = (int64_t)gridDim.x * am_ld;
+                const bool any = key != 0;
+                const int lrow = 0x7fffffff - (int)((key & 0xffffffffull) >> 1);
+                amax[o] = any ? (double)__uint_as_float((unsigned)(key >> 32)) : -1.0;
+                amax[plane + o] = any ? (double)((int64_t)blockIdx.x * (WVK * 16 * RT) + lrow) : (double)INFINITY;
+                amax[2 * plane + o] = (any && (key & 1)) ? -1.0 : 1.0;
+            }
         }
     }
 }
@@ -4547,9 +4611,11 @@ static void launch_xp(Dev* d, const float* X, int64_t n, int K, int64_t ldx, con
 
 // prod_A != nullptr: the small operand is the product prod_A (K x prod_M) . P (prod_M x N) (op_gemm_xp_prod); only the
 // split-product path forms it inside its pack kernel, every other path gets it from a GEMM launch first
+// (split-product path only) svd_flip's column scan of the product, from the kernel's accumulators: cols columns, results as op_col_absmax's
+struct AbsmaxReq { int64_t cols, row_offset; double *absmax, *idx, *sign; };
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
-                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt);
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am = nullptr);
 void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                 int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq) {
     gemm_xp_impl(d, dt, X, n, K, ldx, mu, P, N, ldp, bias, Z, ldz, sumsq, nullptr, 0, 0, nullptr, 0, false);
@@ -4572,14 +4638,29 @@ void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_
     op_gemm_xp(d, dt, X, n, K, ldx, mu, P, N, ldp, nullptr, Z, ldz, nullptr);
     if (tmp) dev_free(d, tmp);
 }
+void op_gemm_xp_prod_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* A, int64_t M,
+                            int64_t lda, const double* T, int64_t N, int64_t ldt, double* P_out, int64_t ldpo, void* Z, int64_t ldz,
+                            int64_t row_offset, double* absmax, double* idx, double* sign) {
+    const bool fused = dt == F32 && gemm_split_product(d) && n >= 64 && K % 16 == 0 && K > 0 && N % 16 == 0 && N > 0 && ldx % 4 == 0 &&
+                       aligned16(X) && (!mu || aligned16(mu)) && ldz % 4 == 0 && aligned16(Z) && K < (1 << 24) && N < (1 << 24) &&
+                       n < (int64_t(1) << 31) && P_out != nullptr;
+    if (!fused) {
+        op_gemm_xp_prod(d, dt, X, n, K, ldx, mu, A, M, lda, T, N, ldt, P_out, ldpo, Z, ldz);
+        op_col_absmax(d, dt, Z, n, N, ldz, row_offset, absmax, idx, sign);
+        return;
+    }
+    const AbsmaxReq am{N, row_offset, absmax, idx, sign};
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, N, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, false, &am);
+}
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
-                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt) {
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am) {
     if (n == 0 || N == 0) return;
     const bool mfma = dt == F32 && K % 16 == 0 && K > 0 && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
                       K < (1 << 24) && N < (1 << 24) && N % 16 == 0 && ldz % 4 == 0 && aligned16(Z) && (!bias || aligned16(bias));
     const bool mfma64 = dt == F64 && K % 8 == 0 && K > 0 && ldx % 2 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
                         K < (1 << 24) && N < (1 << 24) && N % 16 == 0;
+    if (am && !(mfma && gemm_split_product(d) && !sumsq)) throw std::logic_error("gemm_xp_impl: abs-max epilogue outside the split-product path");
     if (mfma64) {  // fp64 inputs: the fp64 matrix cores, 32-row wave tiles, column panels of <= 5 tiles
         const int NTtot = cdiv(N, 16);
         const int64_t total = (K / 8) * (int64_t)NTtot * 64;
@@ -4666,6 +4747,9 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         launch_check();
         constexpr int RTv = PETAL_XP3_RT, DPv = PETAL_XP3_DEPTH;
         const float* Xf = (const float*)X; const float* muf = (const float*)mu; const float* bf = (const float*)bias; float* Zf = (float*)Z;
+        static_assert(RTv == 4, "both workgroup shapes below cover 256 rows: one abs-max partial per 256 rows");
+        const int64_t am_parts = cdiv(n, 256), am_ld = am ? am->cols : 0;
+        double* am_part = am ? (double*)dev_alloc(d, sizeof(double) * 3 * am_parts * am_ld) : nullptr;
         TagScope ts(d);
         // Column panels: as few passes over X as 9-tile panels allow, the tiles spread evenly over them.  A panel of <= 5 tiles
         // runs on 64-row wave tiles (RT = 4), one of 6 .. 9 tiles on 32-row wave tiles (RT = 2: 72 accumulator registers at 9
@@ -4680,8 +4764,8 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
             do {                                                                                                                            \
                 const int blocksw = cdiv(n, 256);                                                                                           \
                 if (lds > 64 * 1024) set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp3<2, NTv, DPv, true, 8>) : reinterpret_cast<const void*>(k_xp3<2, NTv, DPv, false, 8>)); \
-                if (muf) hipLaunchKernelGGL((k_xp3<2, NTv, DPv, true, 8>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
-                else hipLaunchKernelGGL((k_xp3<2, NTv, DPv, false, 8>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
+                if (muf) hipLaunchKernelGGL((k_xp3<2, NTv, DPv, true, 8>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
+                else hipLaunchKernelGGL((k_xp3<2, NTv, DPv, false, 8>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
             } while (0)
             if (w >= 6) {   // eight 32-row waves per workgroup: the P chunk is staged once per 256 rows, as in the 64-row form
                 switch (w) {
@@ -4698,14 +4782,14 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
             do {                                                                                                                            \
                 const int blocksw = cdiv(n, 64 * RTw);                                                                                      \
                 if (lds > 64 * 1024) set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp3<RTw, NTv, DPv, true>) : reinterpret_cast<const void*>(k_xp3<RTw, NTv, DPv, false>)); \
-                if (muf) hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, true>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
-                else hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, false>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
+                if (muf) hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, true>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
+                else hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, false>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
             } while (0)
             // LDS-DMA ring form (k_xp4): whole 32-column chunks, mu + rings within the 160 KB of one workgroup per CU
             // (measured slower than k_xp3 -- 68 vs 62 us at 100000 x 512, 594 vs 570 us at 1e6 -- so it is opt-in: DESIGN section 9)
             static const int xp4_env = [] { const char* e = getenv("PETAL_XP4"); return e ? atoi(e) : 0; }();
             const size_t lds4 = (size_t)8 * 2 * 8192 + (size_t)2 * w * 3 * 1024 + (muf ? sizeof(float) * K : 0);
-            if (xp4_env && K % 32 == 0 && K >= 64 && lds4 <= 160 * 1024 && n >= 512) {
+            if (xp4_env && !am && K % 32 == 0 && K >= 64 && lds4 <= 160 * 1024 && n >= 512) {
 #define XP4_LAUNCH(NTv)                                                                                                                   \
                 do {                                                                                                                        \
                     const int blocks4 = cdiv(n, 512);                                                                                       \
@@ -4738,6 +4822,12 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
             nt0 += w;
         }
         ts.stop();
+        if (am) {
+            hipLaunchKernelGGL(k_absmax_final, dim3((unsigned)am->cols), dim3(64), 0, d->stream, am_part, am_part + am_parts * am_ld,
+                               am_part + 2 * am_parts * am_ld, am_parts, am_ld, am->row_offset, am->absmax, am->idx, am->sign);
+            launch_check();
+            dev_free(d, am_part);
+        }
         dev_free(d, Ppk3);
         return;
     }

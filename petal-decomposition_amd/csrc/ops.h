@@ -74,6 +74,12 @@ void op_gemm_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ld
 void op_gemm_xp_prod(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
                      const double* A, int64_t M, int64_t lda, const double* T, int64_t N, int64_t ldt,
                      double* P_out, int64_t ldpo, void* Z, int64_t ldz);
+// op_gemm_xp_prod followed by op_col_absmax over the N columns of the product Z (svd_flip's scan, pca.rs:826-839), the scan taken
+// from the product kernel's accumulators where that kernel runs (no second pass over Z).
+void op_gemm_xp_prod_absmax(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
+                            const double* A, int64_t M, int64_t lda, const double* T, int64_t N, int64_t ldt,
+                            double* P_out, int64_t ldpo, void* Z, int64_t ldz,
+                            int64_t row_offset, double* absmax, double* idx, double* sign);
 // One re-basing step of the power iteration: G (L x L, ldg) = R^T R, P_out (K x M fp64, ldpo) = A R^-1 (A: K x M, lda; columns
 // L .. M of the result are zero), Z = (X - mu) . P_out.  Same results contract as op_chol_inv(G -> T, Lz = M) followed by
 // op_gemm_xp_prod(A, T); T (M x M, ldt) is SCRATCH here -- it may hold R^-1 or a factored form of it, callers must not read it.
