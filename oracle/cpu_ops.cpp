@@ -215,15 +215,18 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
         }
     }
 }
-void op_ritz_residual(Dev*, const double* CV, const double* Vr, int64_t rows, int64_t ld, int64_t nc, const double* theta, double* out3) {
+void op_ritz_residual(Dev*, const double* CV, int64_t ldc, const double* Vr, int64_t ldv, int64_t rows, int64_t nc, const double* theta,
+                      const int* flag, double* out3, double* w_out) {
     double worst = 0, bad = 0;
+    if (w_out) for (int64_t j = 0; j < nc; ++j) w_out[j] = theta[j];
     for (int64_t j = 0; j < nc; ++j) {
         double s2 = 0;
-        for (int64_t i = 0; i < rows; ++i) { const double r = CV[i * ld + j] - theta[j] * Vr[i * ld + j]; s2 += r * r; }
+        for (int64_t i = 0; i < rows; ++i) { const double r = CV[i * ldc + j] - theta[j] * Vr[i * ldv + j]; s2 += r * r; }
         if (!std::isfinite(s2)) bad = 1;
         else worst = std::max(worst, s2);
     }
-    out3[0] = worst; out3[1] = theta[0]; out3[2] = bad;
+    if (flag && *flag != 0) bad = 1;
+    out3[0] = worst; out3[1] = nc > 0 ? theta[0] : 0.0; out3[2] = bad;
 }
 void op_whiten_k(Dev*, const double* U, int64_t ldu, const double* lam, int64_t rows, int64_t nc, int64_t ncp, double scale,
                  double* KT, double* KTs) {
@@ -244,7 +247,8 @@ void op_whiten_k(Dev*, const double* U, int64_t ldu, const double* lam, int64_t 
     }
 }
 void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool /*clustered*/, int64_t Lz,
-             int64_t /*ncheck*/, int* /*verdict*/) {
+             int64_t /*ncheck*/, int* verdict, bool verdict_fresh) {
+    if (verdict && verdict_fresh) *verdict = 0;
     for (int64_t r = 0; r < Lz; ++r)
         for (int64_t c = 0; c < Lz; ++c)
             if (r >= L || c >= L) V[r * ldv + c] = 0.0;

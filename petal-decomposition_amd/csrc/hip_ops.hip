@@ -4137,13 +4137,17 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
     // straight from LDS); the scalar loops below are LDS-bound -- two reads per FMA -- and cost 20 us per product at nc = 64
     const bool use_mfma = (nc & 15) == 0;
     const int ntile = nc >> 4;
+    // ONE barrier per sum: consecutive calls alternate between two slots of s_red, so a call's writes cannot overtake the
+    // reads of the call before it (whose slot is rewritten only two calls later, with the call in between's barrier behind them)
+    int sum_slot = 0;
     auto block_sum = [&](double v) {
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        __syncthreads();
-        if (lane == 0) s_red[wv] = v;
+        double* slot = s_red + 16 * sum_slot;
+        sum_slot ^= 1;
+        if (lane == 0) slot[wv] = v;
         __syncthreads();
         double t = 0;
-        for (int w = 0; w < nw; ++w) t += s_red[w];
+        for (int w = 0; w < nw; ++w) t += slot[w];
         return t;
     };
     double ss = 0;
@@ -5467,8 +5471,8 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     launch_check();
 }
 void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool clustered, int64_t Lz, int64_t ncheck,
-             int* verdict) {
-    if (L == 0) return;
+             int* verdict, bool verdict_fresh) {
+    if (L == 0) { if (verdict && verdict_fresh) HIP_CHECK(hipMemsetAsync(verdict, 0, sizeof(int), d->stream)); return; }
     const bool pad_done = Lz <= L;   // else: rows / columns L .. Lz - 1 of V are to be zeroed here
     if (L > EIG_MAXL) throw std::runtime_error("eigh: matrix too large for the one-workgroup Jacobi solver");
     // Two-stage solver first (tridiagonalisation on one workgroup, then one wave per eigenpair over the chip); the Jacobi
@@ -5481,6 +5485,8 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     // the verdict goes to the caller's device word, who decides what to do about a flagged spectrum (RandomizedPca redoes the
     // fit on its robust path) -- the two fallback launches, which return at once on every separated spectrum, are not issued
     const bool ext_verdict = verdict != nullptr && two_stage && L <= 138;
+    // (verdict_fresh: the caller's word is cleared first -- by the tridiagonalisation kernel itself where it runs)
+    if (verdict && verdict_fresh && !ext_verdict) HIP_CHECK(hipMemsetAsync(verdict, 0, sizeof(int), d->stream));
     // k_tridiag_r (orders up to 138) writes the padding itself; every other route gets one 2-D clear of the Lz x Lz frame first
     if (!pad_done && !(two_stage && L <= 138)) HIP_CHECK(hipMemset2DAsync(V, sizeof(double) * ldv, 0, sizeof(double) * Lz, Lz, d->stream));
     if (two_stage) {
@@ -5506,7 +5512,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     do {                                                                                                                           \
         const size_t lds_r = sizeof(double) * ((size_t)L * tri_ld((int)L, ST) + 8 * TM + tri_sp_len(TM));                          \
         set_max_lds(d, reinterpret_cast<const void*>(k_tridiag_r<TM, ST>));                                                        \
-        hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag, V, ldv, (int)(pad_done ? 0 : Lz), ext_verdict ? 0 : 1); \
+        hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag, V, ldv, (int)(pad_done ? 0 : Lz), (ext_verdict && !verdict_fresh) ? 0 : 1); \
     } while (0)
             if (L <= 80) PETAL_TRI_LAUNCH(10, 2);
             else if (L <= 132) PETAL_TRI_LAUNCH(18, 2);
@@ -5681,33 +5687,44 @@ void op_jacobi_svd_rows(Dev* d, double* A, int64_t L, int64_t lda, double* U, in
     launch_check();
     dev_free(d, G);
 }
-// one block per wanted column (a maximum is order-independent: the atomic max on the bit patterns of non-negative doubles is
-// deterministic); out3 is cleared by the host wrapper first
-__global__ __launch_bounds__(256) void k_ritz_residual(const double* __restrict__ CV, const double* __restrict__ Vr, int64_t rows, int64_t ld,
-                                                       int nc, const double* __restrict__ theta, double* __restrict__ out3) {
-    __shared__ double red[256];
-    const int j = blockIdx.x;
-    const double th = theta[j];
-    double s2 = 0;
-    for (int64_t i = threadIdx.x; i < rows; i += 256) { const double v = CV[i * ld + j] - th * Vr[i * ld + j]; s2 += v * v; }
-    red[threadIdx.x] = s2;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+// ONE block: lane <-> column (row-major reads stay coalesced), the 16 waves split the rows and add through LDS in a fixed order;
+// the largest squared residual, theta_0 and the bad flag (a non-finite residual, or the eigen-solver's closeness verdict `flag`
+// when given) are written directly -- no clear, no atomics
+__global__ __launch_bounds__(1024) void k_ritz_residual(const double* __restrict__ CV, int64_t ldc, const double* __restrict__ Vr, int64_t ldv,
+                                                        int64_t rows, int nc, const double* __restrict__ theta, const int* __restrict__ flag,
+                                                        double* __restrict__ out3, double* __restrict__ w_out) {
+    __shared__ double red[16][65];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double worst = 0.0, bad = 0.0;   // (meaningful in wave 0)
+    for (int jb = 0; jb < nc; jb += 64) {
+        const int j = jb + lane;
+        const bool on = j < nc;
+        const double th = on ? theta[j] : 0.0;
+        double s2 = 0;
+        if (on)
+            for (int64_t i = wv; i < rows; i += 16) { const double v = CV[i * ldc + j] - th * Vr[i * ldv + j]; s2 += v * v; }
+        red[wv][lane] = s2;
+        __syncthreads();
+        if (wv == 0 && on) {
+            double tot = 0;
+            for (int w = 0; w < 16; ++w) tot += red[w][lane];
+            if (!(tot < 1e300)) bad = 1.0;
+            else worst = fmax(worst, tot);
+            if (w_out) w_out[j] = th;   // the nc wanted Ritz values, delivered to the caller's array by the way
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const double tot = red[0];
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(out3);
-        if (!(tot < 1e300)) atomicMax(o + 2, (unsigned long long)__double_as_longlong(1.0));
-        else atomicMax(o, (unsigned long long)__double_as_longlong(tot));
-        if (j == 0) out3[1] = th;
+    if (wv == 0) {
+        for (int off = 32; off > 0; off >>= 1) { worst = fmax(worst, __shfl_down(worst, off, 64)); bad = fmax(bad, __shfl_down(bad, off, 64)); }
+        if (lane == 0) {
+            if (flag && *flag != 0) bad = 1.0;
+            out3[0] = worst; out3[1] = nc > 0 ? theta[0] : 0.0; out3[2] = bad;
+        }
     }
 }
-void op_ritz_residual(Dev* d, const double* CV, const double* Vr, int64_t rows, int64_t ld, int64_t nc, const double* theta, double* out3) {
-    HIP_CHECK(hipMemsetAsync(out3, 0, sizeof(double) * 3, d->stream));
-    if (nc <= 0) return;
-    hipLaunchKernelGGL(k_ritz_residual, dim3((unsigned)nc), dim3(256), 0, d->stream, CV, Vr, rows, ld, (int)nc, theta, out3);
+void op_ritz_residual(Dev* d, const double* CV, int64_t ldc, const double* Vr, int64_t ldv, int64_t rows, int64_t nc, const double* theta,
+                      const int* flag, double* out3, double* w_out) {
+    hipLaunchKernelGGL(k_ritz_residual, dim3(1), dim3(1024), 0, d->stream, CV, ldc, Vr, ldv, rows, (int)nc, theta, flag, out3, w_out);
     launch_check();
 }
 // one block per column j: the eigenvector's sign is NORMALISED first (its first component of largest magnitude made positive).
