@@ -399,7 +399,8 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
 }
 
 // ---- FastICA ---------------------------------------------------------------------------------
-void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode) {
+void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode, int* zero2) {
+    if (zero2) { zero2[0] = 0; zero2[1] = 0; }
     std::vector<double> S(size_t(nc) * nc), Z(size_t(nc) * nc), w(nc), M(size_t(nc) * nc);
     op_dgemm(d, false, true, nc, nc, nc, 1.0, Win, nc, Win, nc, 0.0, S.data(), nc);  // W W^T (ica.rs:369)
     op_eigh(d, S.data(), nc, nc, Z.data(), nc, w.data());                            // columns of Z = eigenvectors

@@ -819,10 +819,11 @@ namespace {
 // holds w_init on entry and the result on exit.  Returns n_iter.
 int64_t ica_loop(petal_ctx& c, int dt, const void* X1T, int64_t n, int64_t nc, int64_t ld, double n_total, DBuf& W,
                  double tol, int64_t max_iter, int mode) {
+    // (the caller's buffer holds w_init; the iterate lives in a buffer of this function's and the two are exchanged at the end --
+    // no copy; the decorrelation launch also clears the loop state)
     DBuf W0(c.dev, W.bytes), GX(c.dev, sizeof(double) * (nc * nc + nc)), state(c.dev, 2 * sizeof(int));
-    dev_d2d(c.dev, W0.p, W.p, W.bytes);
-    op_symdecorr(c.dev, nc, W0.f64(), W.f64(), mode);  // ica.rs:329
-    dev_memset(c.dev, state.p, 0, state.bytes);
+    std::swap(W, W0);
+    op_symdecorr(c.dev, nc, W0.f64(), W.f64(), mode, state.as<int>());  // ica.rs:329
     int hstate[2] = {0, 0};
     auto enqueue = [&](int64_t it, int* progress) {
         dev_set_tag(c.dev, TAG_ICA);

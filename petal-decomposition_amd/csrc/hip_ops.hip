@@ -4269,7 +4269,9 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
 
 constexpr int ICA_TAIL_THREADS = 512;
 template <int MB>
-__global__ __launch_bounds__(ICA_TAIL_THREADS) void k_symdecorr(const double* Win, double* Wout, int nc, int mode, double* scratch) {
+__global__ __launch_bounds__(ICA_TAIL_THREADS) void k_symdecorr(const double* Win, double* Wout, int nc, int mode, double* scratch,
+                                                                int* zero2) {
+    if (zero2 && threadIdx.x < 2) zero2[threadIdx.x] = 0;   // (the loop's {converged, iterations} state, cleared by the way)
     constexpr bool use_lds = MB > 0;
     extern __shared__ __attribute__((aligned(16))) double sm_sd[];
     JacWs ws = jac_carve(sm_sd, nc, blockDim.x);
@@ -5296,14 +5298,14 @@ void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX
     if (wpk3) d->ica_wpk3_valid = true;
     dev_free(d, scratch);
 }
-void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode) {
+void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode, int* zero2) {
     d->ica_wpk3_valid = false;
     double* scratch = (double*)dev_alloc(d, sizeof(double) * (4 * nc * nc + nc));
     const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
     const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 3 * nc * (nc | 1) : 0));
     MB_DISPATCH(mb, {
         set_max_lds(d, reinterpret_cast<const void*>(k_symdecorr<MBv>));
-        hipLaunchKernelGGL(k_symdecorr<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, Win, Wout, (int)nc, mode, scratch);
+        hipLaunchKernelGGL(k_symdecorr<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, Win, Wout, (int)nc, mode, scratch, zero2);
     });
     launch_check();
     dev_free(d, scratch);

@@ -122,7 +122,7 @@ void op_ica_tail(Dev*, int64_t nc, double n_total, double* W, const double* GX_g
 // four ints of pinned host memory that kernels can store to (system-scope stores over PCIe); the host reads them directly
 volatile int* dev_host_progress(Dev*);
 // Wout = symmetric_decorrelation(Win) (ica.rs:363-381)
-void op_symdecorr(Dev*, int64_t nc, const double* Win, double* Wout, int mode);
+void op_symdecorr(Dev*, int64_t nc, const double* Win, double* Wout, int mode, int* zero2 = nullptr);  // zero2 (nullable): two device ints to clear
 
 // ---- f64 small-matrix ops ----------------------------------------------------------------------
 // colscale (nullable, N values): column j of alpha op(A) op(B) is multiplied by colscale[j] (beta must be 0)
