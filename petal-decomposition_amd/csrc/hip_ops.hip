@@ -2538,6 +2538,22 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
     return __hiloint2double(hi, lo);
 }
+// 1 / sqrt(d) for a positive, normal d: the hardware estimate (v_rsq_f64) and two Newton steps y <- y + (y / 2)(1 - d y^2) -- ~10
+// dependent instructions where the library routine's range handling makes it several times that, and it sits on the
+// critical path of every Cholesky pivot
+__device__ __forceinline__ double fast_rsqrt_pos(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = fma(-d * y, y, 1.0);
+        y = fma(0.5 * y, e, y);
+    }
+    return y;
+}
+__device__ __forceinline__ double bperm_d(double x, int src_lane) {   // x of lane src_lane (per-lane index), through the LDS crossbar
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(x)), hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ int cp(int k, int c) { return (c * (c + 1)) / 2 + k; }
 typedef double cf64x4 __attribute__((ext_vector_type(4)));
 // element (r, c) of an upper-triangular matrix kept column-packed; zero below the diagonal and outside the L x L matrix
@@ -2559,13 +2575,24 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
     double* gd = Tc + np;
     double* rinv = gd + L;
     int* dead = reinterpret_cast<int*>(rinv + L);
-    for (int e = tid; e < L * L; e += nt) {
-        const int r = e / L, c = e - r * L;
-        if (c >= r) {
-            const double g = G[(int64_t)r * ldg + c];
-            Rc[cp(r, c)] = g;
-            Tc[cp(r, c)] = 0.0;
-            if (c == r) gd[r] = gd_ref ? gd_ref[r] : g;
+    // (loads in batches of four: a runtime-trip loop of load -> LDS-store pairs pays an L2 round trip per pair, eleven in a row
+    // at l = 74)
+    for (int e0 = tid; e0 < L * L; e0 += 4 * nt) {
+        double gv[4];
+        int rr[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * nt;
+            rr[u] = e / L; cc[u] = e - rr[u] * L;
+            gv[u] = (e < L * L && cc[u] >= rr[u]) ? G[(int64_t)rr[u] * ldg + cc[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e0 + u * nt < L * L && cc[u] >= rr[u]) {
+                Rc[cp(rr[u], cc[u])] = gv[u];
+                Tc[cp(rr[u], cc[u])] = 0.0;
+                if (cc[u] == rr[u]) gd[rr[u]] = gd_ref ? gd_ref[rr[u]] : gv[u];
+            }
         }
     }
     for (int e = tid; e < Lz * Lz; e += nt) {  // zero padding of the output beyond the factored block
@@ -2579,6 +2606,11 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
     const int nb = (L + 15) / 16;
     for (int J = 0; J < nb; ++J) {
         const int jb = 16 * J;
+        // (the reference diagonal of this block's pivots, requested before the update phase so that its LDS latency is not paid
+        // in the factoring wave's chain; broadcast reads, only wave 0 uses them)
+        double gdv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gdv[i] = (tid < 64 && jb + i < L) ? gd[jb + i] : 0.0;
         // (1) block row J -= (finished rows above)^T (finished rows above), one 16 x 16 tile per wave pass on the fp64 matrix
         //     cores: C(J, Ct) -= sum_K R_KJ^T R_K,Ct.  MFMA 16x16x4 f64: lane l feeds A[l & 15][l >> 4], B[l >> 4][l & 15];
         //     register r of lane l is C[(l >> 4) + 4 r][l & 15].
@@ -2607,34 +2639,50 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
             __syncthreads();
         }
         DBG_T(8);
-        // (2) diagonal block in the registers of wave 0: lane c holds column jb + c; right-looking factorisation with the
-        //     pivots and multipliers broadcast by v_readlane, reciprocal square roots instead of sqrt + divisions
+        // (2) diagonal block in the registers of wave 0, right-looking.  Lane (g, c) = (lane >> 4, lane & 15) holds the four rows
+        //     g, g + 4, g + 8, g + 12 of column jb + c of the (symmetric) Schur complement, so a pivot step needs FIVE values from
+        //     other lanes -- the scaled pivot row at its own column and at its four rows -- through the LDS crossbar
+        //     (ds_bpermute: no SGPR round trip), where the one-column-per-lane form needed 15 - i multipliers by v_readlane pairs
+        //     (~460 cycles per pivot, 40 % of this kernel).  Same operations on the same operands in the same order: the upper
+        //     triangle comes out bit-identical.  Reciprocal square roots instead of sqrt + divisions.
         if (tid < 64) {
-            const int c = jb + tid;
-            double a[16], rv[16];
-            const double gv = (tid < 16 && c < L) ? gd[c] : 0.0;
+            const int c = tid & 15, g = tid >> 4, col = jb + c;
+            double a[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = (tid < 16 && i <= tid && c < L) ? Rc[cp(jb + i, c)] : 0.0;
+            for (int m = 0; m < 4; ++m) {
+                const int k = g + 4 * m, row = jb + k;
+                a[m] = (col < L && row < L) ? (k <= c ? Rc[cp(row, col)] : Rc[cp(col, row)]) : 0.0;
+            }
+            double myinv = 0.0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const double dii = readlane_d(a[i], i);
-                const double gi = readlane_d(gv, i);
-                const bool ok = (gi > 0.0) && (dii > rel_tol * gi);
-                const double inv = ok ? rsqrt(dii) : 0.0;
-                rv[i] = inv;
-                a[i] *= inv;
+                const int gi = i & 3, mi = i >> 2;
+                const double dii = readlane_d(a[mi], gi * 16 + i);
+                const bool ok = (gdv[i] > 0.0) && (dii > rel_tol * gdv[i]);
+                // the UNSCALED pivot row travels while the reciprocal square root is being computed (the exchange is off the
+                // critical path) and is scaled where it arrives: the same products as scaling at the source, bit for bit
+                const double su_c = bperm_d(a[mi], gi * 16 + c);  // S[i][my column]
+                double su_k[4];
 #pragma unroll
-                for (int k = i + 1; k < 16; ++k) a[k] -= readlane_d(a[i], k) * a[i];
+                for (int m = 0; m < 4; ++m) su_k[m] = (4 * m + 3 > i) ? bperm_d(a[mi], gi * 16 + g + 4 * m) : 0.0;   // S[i][my row k]
+                const double rs = fast_rsqrt_pos(ok ? dii : 1.0);
+                const double inv = ok ? rs : 0.0;                 // (a select, not a branch: 40 cycles per pivot)
+                const double r_own = a[mi] * inv;                 // row i of R, in the lanes that hold it (g == gi)
+                const double rc = su_c * inv;                     // R[i][my column]
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int k = g + 4 * m;
+                    const double rk = su_k[m] * inv;              // R[i][my row k]
+                    if (m == mi) a[m] = (g == gi) ? r_own : (k > i ? a[m] - rk * rc : a[m]);
+                    else if (4 * m + 3 > i) a[m] = (k > i) ? a[m] - rk * rc : a[m];
+                }
+                myinv = (tid == i) ? inv : myinv;                 // (kept in lane i: LDS writes inside the chain cost as much again)
             }
-            if (tid < 16 && c < L) {
+            if (tid < 16 && col < L) { rinv[col] = myinv; dead[col] = myinv > 0.0 ? 0 : 1; }
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (i <= tid) Rc[cp(jb + i, c)] = a[i];
-                double mine = 0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mine = (i == tid) ? rv[i] : mine;
-                rinv[c] = mine;
-                dead[c] = mine > 0.0 ? 0 : 1;
+            for (int m = 0; m < 4; ++m) {
+                const int k = g + 4 * m;
+                if (k <= c && col < L) Rc[cp(jb + k, col)] = a[m];
             }
         }
         __syncthreads();
@@ -2684,7 +2732,12 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
     }
     __syncthreads();
     DBG_T(11);
-    if (tid == 0 && ndead_out) { int cdead = 0; for (int j = 0; j < L; ++j) cdead += dead[j]; if (cdead > *ndead_out) *ndead_out = cdead; }
+    if (tid < 64 && ndead_out) {   // (wave 0 counts: a serial loop over L LDS reads by one thread was 2 us)
+        int cdead = 0;
+        for (int j = tid; j < L; j += 64) cdead += dead[j];
+        for (int off = 32; off > 0; off >>= 1) cdead += __shfl_down(cdead, off, 64);
+        if (tid == 0 && cdead > *ndead_out) *ndead_out = cdead;
+    }
     if (rt_form) {
         // "RT form": the caller applies R^-1 by a blocked triangular solve (k_trsm_pack) and only needs the inverses of the
         // diagonal blocks -- the explicit off-diagonal inverse below (30 % of this kernel) is skipped.  Output: diagonal 16 x 16
