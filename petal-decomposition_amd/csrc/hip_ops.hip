@@ -3732,9 +3732,15 @@ __global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restr
     double* W = sm_tri;
     double* sv = W + (size_t)L * ld;                              // 8 TMAX entries
     double* sp = sv + 8 * TMAX;                                   // tri_sp_len(TMAX) entries
-    for (int e = tid; e < L * ld; e += TRR_THREADS) {
-        const int r = e / ld, c = e - r * ld;
-        W[e] = c < L ? A[(int64_t)r * lda + c] : 0.0;
+    for (int e0 = tid; e0 < L * ld; e0 += 8 * TRR_THREADS) {     // (eight loads in flight per thread: a load -> LDS-store loop pays
+        double t8[8];                                            //  an L2 round trip per trip, thirteen in a row at L = 74)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * TRR_THREADS, r = e / ld, c = e - r * ld;
+            t8[u] = (e < L * ld && c < L) ? A[(int64_t)r * lda + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * TRR_THREADS; if (e < L * ld) W[e] = t8[u]; }
     }
     if (tid == 0 && reset_flag) *flag = 0;   // (a caller-owned verdict word accumulates: it is not reset here)
     __syncthreads();
@@ -4366,11 +4372,24 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
     if constexpr (MB > 0) {
         if (mode == 0 || nc <= 2) {
             Wl = Zt + 2 * nc * ldl;
-            for (int e = tid; e < nc * nc; e += nt) {  // D = GX / n - diag(g') W / n (ica.rs:334-342), straight into LDS
-                const int i = e / nc, j = e - i * nc;
-                const double wv_ = W[e];
-                Wl[i * ldl + j] = wv_;
-                S[i * ldl + j] = GX[e] * pinv - gp[i] * pinv * wv_;
+            // D = GX / n - diag(g') W / n (ica.rs:334-342), straight into LDS; the loads of four trips are in flight together (a
+            // load -> LDS-store loop pays a memory round trip per trip: eight in a row at nc = 64)
+            for (int e0 = tid; e0 < nc * nc; e0 += 4 * nt) {
+                double wv4[4], gx4[4], gp4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = min(e0 + u * nt, nc * nc - 1);
+                    wv4[u] = W[e]; gx4[u] = GX[e]; gp4[u] = gp[e / nc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * nt;
+                    if (e < nc * nc) {
+                        const int i = e / nc, j = e - i * nc;
+                        Wl[i * ldl + j] = wv4[u];
+                        S[i * ldl + j] = gx4[u] * pinv - gp4[u] * pinv * wv4[u];
+                    }
+                }
             }
             __syncthreads();
             res = wg_polar_ns(nc, S, Zt, Zt + nc * ldl, ws.red, ortho_tol2);  // ica.rs:343
