@@ -2307,20 +2307,36 @@ __global__ __launch_bounds__(64) void k_trsm_pack(const double* __restrict__ A, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) X[J][r] = A[(i0 + li) * lda + 16 * J + lk + 4 * r];
     }
+    // Block row I + 1 of RT is requested while block row I is being used (two register sets): with every operand requested up
+    // front the 45 tiles of NB = 9 need 360 registers and the compiler serialises them -- each MFMA then waits for its own L2
+    // round trip (50 us at l = 138)
+    cf64x4 rt[2][NB];
+    auto load_row = [&](int I, cf64x4(&dst)[NB]) {
+        const double* rrow = RT + (int64_t)(16 * I + lk) * ldt + li;   // row 16 I + lk (+ 4 r), column (16 J +) li
+#pragma unroll
+        for (int J = 0; J < NB; ++J)
+            if (J >= I) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[J][r] = rrow[(int64_t)4 * r * ldt + 16 * J];
+            }
+    };
+    load_row(0, rt[0]);
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
-        const double* rrow = RT + (int64_t)(16 * I + lk) * ldt + li;   // row 16 I + lk (+ 4 r), column (16 J +) li
+        if (I + 1 < NB) load_row(I + 1, rt[(I + 1) & 1]);
+        const cf64x4(&cur)[NB] = rt[I & 1];
         cf64x4 pt = cf64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pt = __builtin_amdgcn_mfma_f64_16x16x4f64(rrow[(int64_t)4 * r * ldt + 16 * I], X[I][r], pt, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) pt = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][r], X[I][r], pt, 0, 0, 0);
 #pragma unroll
         for (int J = I + 1; J < NB; ++J) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                X[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-rrow[(int64_t)4 * r * ldt + 16 * J], pt[r], X[J], 0, 0, 0);
+                X[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur[J][r], pt[r], X[J], 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) sP[li * ldsp + 16 * I + lk + 4 * r] = pt[r];
+        __builtin_amdgcn_sched_barrier(0);   // (keeps the loads of row I + 2 from being hoisted above this row's products)
     }
     __syncthreads();
     if (P_out)
