@@ -60,6 +60,17 @@ def test_rpca_parity(ctx, n, d, k, n_iter):
     pc.rpca_parity(ctx, n, d, k, n_iter, seed=n % 97, tol=1e-5)
 
 
+@pytest.mark.parametrize("k", [4, 20, 36, 52, 60, 84, 100, 116, 132])
+def test_rebasing_block_counts(ctx, k):
+    """l = k + 10 padded to 16, 32, ... 144: every block count (1 .. 9) of the triangular-solve re-basing (`k_trsm_pack<NB>`, the
+    Cholesky kernel's RT form) and of the K1 / K2 column panels, against the oracle with the same Omega; d = 320 (a multiple of 16:
+    the fused split-product path in bf16x3 mode), a row count that is no multiple of the 256-row workgroups (the abs-max
+    epilogue's partial last group).  The planted spectrum spans 1e3 over k values: from k = 100 on its neighbours are less than
+    7 % apart and fp32 DATA pins the last vectors to ~ 6e-8 sigma_1 / gap ~ 1e-4 only -- measured 1.0e-4 .. 1.4e-4 in both GEMM
+    modes alike (the fp32-MFMA mode does not run the triangular solve at all); the singular values stay at 2e-5."""
+    pc.rpca_parity(ctx, 3001, 320, k, 4, seed=60 + k, tol=2e-5 if k < 100 else 5e-4, tol_sigma=2e-5, device=True)
+
+
 def test_rpca_parity_variants(ctx):
     pc.rpca_parity(ctx, 6000, 96, 8, 7, seed=21, device=True)
     pc.rpca_parity(ctx, 3000, 64, 6, 7, seed=22, centering=False)
