@@ -221,7 +221,13 @@ bool topk_applies(int64_t d, int64_t dp, int64_t nc) {
 bool topk_verdict_ok(const double* r3) {
     return r3[2] == 0.0 && std::isfinite(r3[0]) && r3[1] > 0 && std::sqrt(std::max(r3[0], 0.0)) <= 1e-12 * r3[1];
 }
-bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc, double* V, double* w, double* resid3 = nullptr) {
+// gap_tol: the two-stage solver's closeness threshold for the Ritz problem (relative to ||H||; pairs closer than it go to the
+// Jacobi fallback, which always works to 1e-15) -- 1e-8 when C came from fp32 data (eigenvectors to eps / 1e-8 ~ 1e-8 are
+// beyond what the data pins), 1e-5 for fp64 data (2e-11).  With the fp64 threshold on fp32 data every spectrum graded over
+// more than five decades counted as "clustered" at its small end and each Rayleigh-Ritz step ran the full Jacobi solve (170 +
+// 40 us per step at p = 48, two steps per tall exact-Pca fit).
+bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc, double* V, double* w, double gap_tol,
+               double* resid3 = nullptr) {
     if (!topk_applies(d, dp, nc)) return false;
     const int64_t p = std::min<int64_t>(round_up(nc + 16, 16), dp);
     Dev* dv = c.dev;
@@ -256,7 +262,7 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
     auto rayleigh_ritz = [&](double* out3) {
         op_dgemm(dv, true, false, p, p, dp, 1.0, Q.f64(), p, Y.f64(), p, 0.0, H.f64(), p);    // Rayleigh quotient
         // (only the optimistic caller, who redoes the fit on a bad verdict, skips the fallback: here a flagged Ritz problem is solved by Jacobi as before)
-        op_eigh(dv, H.f64(), p, p, S.f64(), p, th.f64(), 1e-15, false, 0, nc, resid3 ? vf.as<int>() : nullptr, true);
+        op_eigh(dv, H.f64(), p, p, S.f64(), p, th.f64(), 1e-15, false, 0, nc, resid3 ? vf.as<int>() : nullptr, true, gap_tol);
         op_dgemm(dv, false, false, dp, nc, p, 1.0, Q.f64(), p, S.f64(), p, 0.0, V, dp);        // Ritz vectors
         op_dgemm(dv, false, false, dp, nc, p, 1.0, Y.f64(), p, S.f64(), p, 0.0, R.f64(), p);   // C (Q S)
         op_ritz_residual(dv, R.f64(), p, V, dp, dp, nc, th.f64(), resid3 ? vf.as<int>() : nullptr, out3, w);
@@ -710,7 +716,7 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     // only the top-k pairs reach the outputs (components, singular values, the k columns of U that svd_flip signs)
     DBuf Ckeep;  // (the eigen-solvers may destroy their input; the accurate route of fp64 fits factors the Gram matrix again)
     if (dt == F64) { Ckeep = DBuf(c.dev, C.bytes); dev_d2d(c.dev, Ckeep.p, C.p, C.bytes); }
-    const bool partial = topk_eigh(c, C.f64(), d, dp, k, V.f64(), lam.f64());
+    const bool partial = topk_eigh(c, C.f64(), d, dp, k, V.f64(), lam.f64(), dt == F32 ? 1e-8 : 1e-5);
     // (order d, not the padded dp: the zero padding would only add dp - d exact zero eigenvalues, a cluster that sends the
     // two-stage solver to its Jacobi fallback; V and lam beyond d stay at the zeros set above)
     if (!partial) op_eigh(c.dev, C.f64(), d, dp, V.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
@@ -942,7 +948,7 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
         DBuf Ckeep;  // (see pca_fit)
         if (dt == F64) { Ckeep = DBuf(c.dev, C.bytes); dev_d2d(c.dev, Ckeep.p, C.p, C.bytes); }
-        const bool topk = topk_eigh(c, C.f64(), d, dp, nc, U.f64(), lam.f64(), optimistic ? r3.f64() : nullptr);  // only the first nc pairs are used below
+        const bool topk = topk_eigh(c, C.f64(), d, dp, nc, U.f64(), lam.f64(), dt == F32 ? 1e-8 : 1e-5, optimistic ? r3.f64() : nullptr);  // only the first nc pairs are used below
         if (!topk) {
             dev_memset(c.dev, U.p, 0, U.bytes);
             dev_memset(c.dev, lam.p, 0, lam.bytes);

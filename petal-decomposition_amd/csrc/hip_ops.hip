@@ -5561,7 +5561,7 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     launch_check();
 }
 void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool clustered, int64_t Lz, int64_t ncheck,
-             int* verdict, bool verdict_fresh) {
+             int* verdict, bool verdict_fresh, double gap_tol_override) {
     if (L == 0) { if (verdict && verdict_fresh) HIP_CHECK(hipMemsetAsync(verdict, 0, sizeof(int), d->stream)); return; }
     const bool pad_done = Lz <= L;   // else: rows / columns L .. Lz - 1 of V are to be zeroed here
     if (L > EIG_MAXL) throw std::runtime_error("eigh: matrix too large for the one-workgroup Jacobi solver");
@@ -5582,7 +5582,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     if (two_stage) {
         // eigenvectors of eigenvalues closer than gap_tol ||A|| come out only eps / gap_tol accurate: fp32 results carry
         // 2e-8, fp64 results 2e-11; anything closer goes to Jacobi
-        const double gap_tol = tol_rel >= 1e-9 ? 1e-8 : 1e-5;
+        const double gap_tol = gap_tol_override > 0 ? gap_tol_override : (tol_rel >= 1e-9 ? 1e-8 : 1e-5);
         const int64_t ldw = L | 1;
         const size_t lds_in = sizeof(double) * ((size_t)L * ldw + 2 * L + 32);
         const bool inlds = lds_in <= 160 * 1024 - 256;

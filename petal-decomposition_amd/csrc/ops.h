@@ -156,7 +156,10 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
 // verdict (nullable, device int): instead of running the Jacobi fallback behind a flagged two-stage solve, OR a non-zero value into
 // *verdict and deliver the two-stage result as it is (orders the register-resident kernels take; other orders ignore it).
 void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel = 1e-15,
-             bool clustered = false, int64_t Lz = 0, int64_t ncheck = 0, int* verdict = nullptr, bool verdict_fresh = false);
+             bool clustered = false, int64_t Lz = 0, int64_t ncheck = 0, int* verdict = nullptr, bool verdict_fresh = false,
+             double gap_tol_override = 0.0);
+// (gap_tol_override > 0: the closeness threshold of the two-stage solver, relative to ||A||, instead of the one tol_rel implies --
+// a caller whose matrix came from fp32 data can accept eigenvectors to eps / 1e-8 while still asking the fallback for 1e-15)
 // (verdict_fresh: *verdict is cleared first instead of accumulated into; orders that ignore the verdict leave it 0)
 // Residual verdict of a Rayleigh-Ritz step without a host round trip: with the Ritz vectors Vr (rows x >= nc, ldv), their
 // images CV = C Vr (ldc) and the Ritz values theta,  out[0] = max_{j < nc} ||CV[:, j] - theta_j Vr[:, j]||_2^2,  out[1] = theta[0],
