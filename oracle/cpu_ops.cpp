@@ -170,6 +170,17 @@ void op_sigma_inv(Dev*, const double* lam, double* sig, double* inv, int64_t cou
     const double s0 = count ? sig[0] : 0.0;
     for (int64_t i = 0; i < count; ++i) inv[i] = (sig[i] > thr * s0 && sig[i] > 0) ? 1.0 / sig[i] : 0.0;
 }
+void op_scale_pad_cols(Dev*, const double* V, int64_t ldv, const double* inv, int64_t rows, int64_t r, int64_t rp, double* P) {
+    for (int64_t i = 0; i < rows; ++i)
+        for (int64_t j = 0; j < rp; ++j) P[i * rp + j] = j < r ? V[i * ldv + j] * inv[j] : 0.0;
+}
+void op_transpose_out(Dev*, int dt, const double* V, int64_t ldv, int64_t d, int64_t k, void* comp) {
+    for (int64_t j = 0; j < k; ++j)
+        for (int64_t i = 0; i < d; ++i) {
+            if (dt == F32) static_cast<float*>(comp)[j * d + i] = float(V[i * ldv + j]);
+            else static_cast<double*>(comp)[j * d + i] = V[i * ldv + j];
+        }
+}
 void op_components_out(Dev*, int dt, const double* Bt, int64_t ldb, const double* Uh, int64_t ldu, const double* lam, double thr,
                        int64_t d, int64_t L, int64_t k, void* comp) {
     const double s0 = std::sqrt(std::max(lam[0], 0.0));

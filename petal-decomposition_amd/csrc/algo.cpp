@@ -702,21 +702,28 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     column_means(c, X, ri.n_total, centering, mu64, muT, false, sharded(c) && centering ? pro.sums : nullptr);
 
     DBuf C(c.dev, sizeof(double) * dp * dp), V(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp);
-    DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp);
+    DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp), diag(c.dev, sizeof(double) * dp), r3(c.dev, sizeof(double) * 3);
+    DBuf compd(c.dev, esz * size_t(std::max<int64_t>(k, 1)) * d), U;
+    const bool slot_flip = !sharded(c) || dt == F32;  // (sharded fp64 decides the signs in three dependent all-reduce rounds)
+    std::vector<double> hdiag(dp), hs(dp), hmu(dp), deferred, sg;
+    int64_t r = 0, rp = 16;
+    // The device pipeline: nothing is read back in the middle except what a decision needs -- the subspace iteration's residual
+    // verdict every second product (an optimistic fixed-length iteration, as FastICA's whitening runs it, was measured: a tall
+    // Pca whose spectrum needs four products instead of two then pays the whole pipeline twice, 1.10 -> 1.74 ms) and, for fp64
+    // data, the spectrum that chooses the accurate route -- and one synchronisation at the end delivers the results.  The
+    // components leave in the caller's layout and type.
+    auto pipeline = [&](bool optimistic) -> bool {
     op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
     allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
-    // total_variance = sigma . sigma over ALL singular values (pca.rs:224) = trace of the Gram matrix
-    std::vector<double> hdiag(dp);
-    dev_copy2d(c.dev, hdiag.data(), sizeof(double), C.p, (dp + 1) * sizeof(double), sizeof(double), size_t(dp), 1);
-    dev_sync(c.dev);
-    double trace = 0;
-    for (int64_t j = 0; j < d; ++j) trace += hdiag[j];
+    // total_variance = sigma . sigma over ALL singular values (pca.rs:224) = trace of the Gram matrix: its diagonal is set aside
+    // before the eigen-solvers overwrite C
+    dev_copy2d(c.dev, diag.p, sizeof(double), C.p, (dp + 1) * sizeof(double), sizeof(double), size_t(dp), 2);
     dev_memset(c.dev, V.p, 0, V.bytes);
     dev_memset(c.dev, lam.p, 0, lam.bytes);
     // only the top-k pairs reach the outputs (components, singular values, the k columns of U that svd_flip signs)
     DBuf Ckeep;  // (the eigen-solvers may destroy their input; the accurate route of fp64 fits factors the Gram matrix again)
     if (dt == F64) { Ckeep = DBuf(c.dev, C.bytes); dev_d2d(c.dev, Ckeep.p, C.p, C.bytes); }
-    const bool partial = topk_eigh(c, C.f64(), d, dp, k, V.f64(), lam.f64(), dt == F32 ? 1e-8 : 1e-5);
+    const bool partial = topk_eigh(c, C.f64(), d, dp, k, V.f64(), lam.f64(), dt == F32 ? 1e-8 : 1e-5, optimistic ? r3.f64() : nullptr);
     // (order d, not the padded dp: the zero padding would only add dp - d exact zero eigenvalues, a cluster that sends the
     // two-stage solver to its Jacobi fallback; V and lam beyond d stay at the zeros set above)
     if (!partial) op_eigh(c.dev, C.f64(), d, dp, V.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
@@ -730,32 +737,39 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
         const double ratio = (hl[0] > 0 && hl[k - 1] > 0) ? std::sqrt(hl[k - 1] / hl[0]) : 0.0;
         if (ratio < GRAM_ROUTE_FLOOR) accurate = accurate_small_svd(c, X, muT.p, Ckeep.f64(), d, V.f64(), sig.f64());
     }
-    if (!accurate) op_dvec(c.dev, 0, lam.f64(), sig.f64(), dp, 0.0);
-    op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, dt == F32 ? 1e-6 : 1e-10);
+    if (!accurate) op_sigma_inv(c.dev, lam.f64(), sig.f64(), inv.f64(), dp, dt == F32 ? 1e-6 : 1e-10);
+    else op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, dt == F32 ? 1e-6 : 1e-10);
 
     // U[:, j] = Xc v_j / sigma_j for j < r: only the columns svd_flip looks at (all min(n, d) of them in the crate;
     // the signs of columns >= k never reach an output)
-    const int64_t r = partial ? k : std::min(n_total, d), rp = round_up(std::max<int64_t>(r, 1), 16);
+    r = partial ? k : std::min(n_total, d);
+    rp = round_up(std::max<int64_t>(r, 1), 16);
     DBuf Pm(c.dev, sizeof(double) * dp * rp);
-    dev_memset(c.dev, Pm.p, 0, Pm.bytes);
-    {
-        DBuf Vs(c.dev, V.bytes);
-        dev_d2d(c.dev, Vs.p, V.p, V.bytes);
-        op_dscale_cols(c.dev, Vs.f64(), dp, dp, dp, inv.f64());
-        dev_copy2d(c.dev, Pm.p, rp * sizeof(double), Vs.p, dp * sizeof(double), size_t(std::min(r, dp)) * sizeof(double), size_t(dp), 2);
-    }
-    DBuf U(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * rp);
+    op_scale_pad_cols(c.dev, V.f64(), dp, inv.f64(), dp, std::min(r, dp), rp, Pm.f64());
+    U = DBuf(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * rp);
     op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Pm.f64(), rp, rp, nullptr, U.p, rp, nullptr);
-    std::vector<double> sg = flip_signs(c, dt, U.p, n, r, rp, ri.row_offset);  // pca.rs:223
+    if (slot_flip) flip_signs(c, dt, U.p, n, r, rp, ri.row_offset, &deferred);  // pca.rs:223 (decision data queued, decoded below)
+    else sg = flip_signs(c, dt, U.p, n, r, rp, ri.row_offset);
+    op_transpose_out(c.dev, dt, V.f64(), dp, d, k, compd.p);
 
-    std::vector<double> hV(size_t(dp) * dp), hs(dp), hmu(dp);
-    dev_d2h(c.dev, hV.data(), V.p, V.bytes);
+    double h3[3] = {0, 1, 0};
+    dev_d2h(c.dev, hdiag.data(), diag.p, diag.bytes);
     dev_d2h(c.dev, hs.data(), sig.p, sig.bytes);
-    dev_d2h(c.dev, hmu.data(), mu64.p, mu64.bytes);
+    dev_d2h(c.dev, hmu.data(), mu64.p, sizeof(double) * dp);
+    if (k > 0) dev_d2h(c.dev, components, compd.p, esz * size_t(k) * d);
+    if (partial && optimistic) dev_d2h(c.dev, h3, r3.p, sizeof(h3));
     dev_sync(c.dev);
-    const double tvar = trace;
-    for (int64_t j = 0; j < k; ++j) {
-        for (int64_t i = 0; i < d; ++i) put_elem(components, dt, j * d + i, sg[j] * hV[size_t(i) * dp + j]);
+    return !(partial && optimistic) || topk_verdict_ok(h3);
+    };  // pipeline
+    pipeline(false);
+    if (slot_flip) sg = signs_from_triple(deferred, r);
+    double tvar = 0;
+    for (int64_t j = 0; j < d; ++j) tvar += hdiag[j];
+    for (int64_t j = 0; j < k; ++j) {   // svd_flip's sign on row j of the components (already in place)
+        if (sg[j] < 0) {
+            if (dt == F32) { float* row = static_cast<float*>(components) + j * d; for (int64_t i = 0; i < d; ++i) row[i] = -row[i]; }
+            else { double* row = static_cast<double*>(components) + j * d; for (int64_t i = 0; i < d; ++i) row[i] = -row[i]; }
+        }
         put_elem(singular, dt, j, hs[j]);
     }
     for (int64_t i = 0; i < d; ++i) put_elem(means, dt, i, hmu[i]);

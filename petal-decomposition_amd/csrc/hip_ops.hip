@@ -4535,6 +4535,33 @@ __global__ __launch_bounds__(256) void k_components_out(const double* __restrict
         }
     }
 }
+// exact Pca's small-matrix tail, two one-launch helpers:
+// P[i][j] = j < r ? V[i][j] * inv[j] : 0 (rows x rp, the right-hand side of U = Xc V / sigma, zero padded) ...
+__global__ void k_scale_pad_cols(const double* __restrict__ V, int64_t ldv, const double* __restrict__ inv, int64_t rows, int64_t r,
+                                 int64_t rp, double* __restrict__ P) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * rp) return;
+    const int64_t i = e / rp, j = e - i * rp;
+    P[e] = j < r ? V[i * ldv + j] * inv[j] : 0.0;
+}
+// ... and the components in the caller's layout and type: comp[j][i] = (T)V[i][j] for j < k, i < d (32 x 32 tiles through LDS)
+template <class T>
+__global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict__ V, int64_t ldv, int64_t d, int64_t k, T* __restrict__ comp) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + ty + 8 * u, j = j0 + tx;
+        tile[ty + 8 * u][tx] = (i < d && j < k) ? V[i * ldv + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t j = j0 + ty + 8 * u, i = i0 + tx;
+        if (j < k && i < d) comp[j * d + i] = (T)tile[tx][ty + 8 * u];
+    }
+}
 // column means from the per-block partial sums of k_colsum_part2, in one launch: fixed-order fp64 sum of the parts,
 // mu64[j] = sum / n_total for j < d (the sums of squares at d <= j < w stay unscaled), muT[j] = (T)mu64[j]
 template <class T>
@@ -4674,6 +4701,18 @@ static void set_max_lds(Dev* d, const void* fn) {
     if (d->max_lds_set.count(fn)) return;
     HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     d->max_lds_set.insert(fn);
+}
+void op_scale_pad_cols(Dev* d, const double* V, int64_t ldv, const double* inv, int64_t rows, int64_t r, int64_t rp, double* P) {
+    if (rows == 0 || rp == 0) return;
+    hipLaunchKernelGGL(k_scale_pad_cols, dim3(cdiv(rows * rp, 256)), dim3(256), 0, d->stream, V, ldv, inv, rows, r, rp, P);
+    launch_check();
+}
+void op_transpose_out(Dev* d, int dt, const double* V, int64_t ldv, int64_t dd, int64_t k, void* comp) {
+    if (dd == 0 || k == 0) return;
+    const dim3 grid(cdiv(dd, 32), cdiv(k, 32));
+    if (dt == F32) hipLaunchKernelGGL(k_transpose_out<float>, grid, dim3(256), 0, d->stream, V, ldv, dd, k, (float*)comp);
+    else hipLaunchKernelGGL(k_transpose_out<double>, grid, dim3(256), 0, d->stream, V, ldv, dd, k, (double*)comp);
+    launch_check();
 }
 void op_components_out(Dev* d, int dt, const double* Bt, int64_t ldb, const double* Uh, int64_t ldu, const double* lam, double thr,
                        int64_t dd, int64_t L, int64_t k, void* comp) {

@@ -132,6 +132,10 @@ void op_dgemm(Dev*, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double al
 // sig[i] = sqrt(max(lam[i], 0)); inv[i] = sig[i] > thr * sig[0] ? 1 / sig[i] : 0   (the two op_dvec steps of an SVD from
 // eigenvalues, in one launch)
 void op_sigma_inv(Dev*, const double* lam, double* sig, double* inv, int64_t count, double thr);
+// P (rows x rp row-major) = [ V[:, :r] diag(inv) | 0 ]  (V: ldv)
+void op_scale_pad_cols(Dev*, const double* V, int64_t ldv, const double* inv, int64_t rows, int64_t r, int64_t rp, double* P);
+// comp (k x d row-major, dtype) = V[:d, :k]^T
+void op_transpose_out(Dev*, int dtype, const double* V, int64_t ldv, int64_t d, int64_t k, void* comp);
 // comp[j][i] (k x d row-major, the input dtype) = (Bt u_j)[i] / sigma_j: rows of V^T from Bt (d x L, ldb), the eigenvectors Uh
 // (columns, ldu) and eigenvalues lam of B B^T; sigma_j = sqrt(max(lam_j, 0)), 1 / sigma_j = 0 at or below thr * sigma_0.
 void op_components_out(Dev*, int dtype, const double* Bt, int64_t ldb, const double* Uh, int64_t ldu, const double* lam, double thr,
