@@ -726,7 +726,10 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     const bool partial = topk_eigh(c, C.f64(), d, dp, k, V.f64(), lam.f64(), dt == F32 ? 1e-8 : 1e-5, optimistic ? r3.f64() : nullptr);
     // (order d, not the padded dp: the zero padding would only add dp - d exact zero eigenvalues, a cluster that sends the
     // two-stage solver to its Jacobi fallback; V and lam beyond d stay at the zeros set above)
-    if (!partial) op_eigh(c.dev, C.f64(), d, dp, V.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
+    // (... and the closeness verdict of the two-stage solver covers the k pairs that reach the outputs: the noise-floor
+    // eigenvalues behind them cluster on every planted spectrum and would send each such fit to the Jacobi solver -- 98 + 24 us of
+    // configs[0]'s 0.34 ms -- for vectors whose only use is a discarded sign)
+    if (!partial) op_eigh(c.dev, C.f64(), d, dp, V.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15, false, 0, std::max<int64_t>(k, 1));
     // fp64 data with wanted singular values below 10^-3.5 sigma_1 (by the Gram route's own estimate): the QR + one-sided
     // Jacobi route keeps them to eps sigma_1 / sigma_k like the crate's gesvd (linalg.rs:70-91); two more passes over X
     bool accurate = false;
