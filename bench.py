@@ -13,7 +13,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                 launch duration measured with HIP events on the launch stream inside the timed region
   cpu_baseline  the numpy/LAPACK oracle ("port") timed on this box's host cores on the same workload
 and informational ones (fp32_mfma_mode: the same fit on the fp32-MFMA kernels; northstar_gemm: the two GEMM kernels
-alone at 1e6 x 512 in both modes; fastica_cfg3; host_in: fit() fed a host ndarray, PCIe included -- never `value`).
+alone at 1e6 x 512 in both modes; fastica_cfg3; pca_cfg1: the exact Pca on configs[0]; host_in: fit() fed a host ndarray, PCIe
+included -- never `value`).
 """
 import argparse
 import json
@@ -290,6 +291,7 @@ def main():
 
         if world == 1 and not args.no_northstar:
             out["fastica_cfg3"] = fastica_cfg3(petal, ctx, torch, dev)
+            out["pca_cfg1"] = pca_cfg1(petal, ctx, torch, dev)
 
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x_host, omega, k, n_iter)
@@ -484,6 +486,24 @@ def bench_fastica(args, cfg, petal, ctx, torch, dist, dev, rank, world, collecti
                      "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "traffic": None, "kernel": "K7 fused FastICA step (fp32-equivalent flops)",
                      "avg_launch_ms": round(avg, 5), "flops_per_launch": st["ica_step_flops"], "bytes_per_launch": st["ica_step_bytes"]},
     }
+
+
+def pca_cfg1(petal, ctx, torch, dev):
+    """BASELINE configs[0] (informational): the exact (full-SVD) Pca on the reference's own CPU-runnable case, 1000 x 16 f64,
+    and on a tall fp32 matrix (200000 x 256, k = 32), X in HBM."""
+    from synth_data import synth_pca
+    res = {}
+    for name, (n, d, k, dt) in {"1000x16_f64_k4": (1000, 16, 4, np.float64), "200000x256_f32_k32": (200000, 256, 32, np.float32)}.items():
+        x = torch.from_numpy(synth_pca(n, d, k, seed=2, dtype=dt)).to(dev)
+        m = petal.Pca.new(k, ctx)
+        for _ in range(5):
+            m.fit(x)
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            m.fit(x)
+        res[name] = {"fit_ms": round((time.perf_counter() - t0) / reps * 1e3, 4)}
+    return res
 
 
 def fastica_cfg3(petal, ctx, torch, dev, n=200000, d=256, nc=32):
