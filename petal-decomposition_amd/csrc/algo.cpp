@@ -969,7 +969,7 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         if (!topk) {
             dev_memset(c.dev, U.p, 0, U.bytes);
             dev_memset(c.dev, lam.p, 0, lam.bytes);
-            op_eigh(c.dev, C.f64(), d, dp, U.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15);
+            op_eigh(c.dev, C.f64(), d, dp, U.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15, false, 0, nc);  // (closeness verdict over the nc pairs used)
         }
         if (dt == F64) {  // the whitening divides by sigma: below the Gram route's floor take the accurate route (see pca_fit)
             std::vector<double> hl(nc);
