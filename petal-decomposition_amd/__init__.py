@@ -577,9 +577,9 @@ class RandomizedPca(_PcaModel):
         if omega is None:
             omega = self.draw_omega(mx.cols, mx.dtype)
         omega = _host(omega, mx.dtype, (mx.cols, self._k + self.n_oversample))
-        comp = np.zeros((self._k, mx.cols), dtype=npdt)
-        means = np.zeros(mx.cols, dtype=npdt)
-        sing = np.zeros(self._k, dtype=npdt)
+        comp = np.empty((self._k, mx.cols), dtype=npdt)   # (every element is written by a successful fit; a failed one raises)
+        means = np.zeros(mx.cols, dtype=npdt)            # (an empty input without centering returns before the means are written)
+        sing = np.empty(self._k, dtype=npdt)
         tv = np.zeros(1, dtype=npdt)
         y, my = None, None
         if want_y:
