@@ -5581,8 +5581,12 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
 void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz) {
     if (L == 0) return;
     if (Lz < L) Lz = L;
-    if (L > CHOL_MAXL) { chol_inv_blocked(d, G, L, ldg, T, ldt, rel_tol, ndead, Lz); return; }
     static const bool force_old = getenv("PETAL_CHOL_OLD") != nullptr;
+    // Orders 142 .. 200 used to run k_chol_inv with T built directly in global memory (t_mode 0: neither LDS form of T fits
+    // beside the packed factor there) -- a mode no test reached and whose results were WRONG (RandomizedPca with 132 <= k <= 190:
+    // singular values off by 10 % .. 1e3, found by dev/fuzz_rpca.py in round 3).  They take the blocked form now, like the
+    // orders beyond 200; k_chol_inv only ever runs with T in LDS (order 141, or PETAL_CHOL_OLD=1 below that).
+    if (L > CHOL2_MAXL + 1) { chol_inv_blocked(d, G, L, ldg, T, ldt, rel_tol, ndead, Lz); return; }
     if (L <= CHOL2_MAXL && !force_old) {
         set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
         hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol,
@@ -5594,6 +5598,7 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     const size_t full = base + sizeof(double) * L * L, packed = base + sizeof(double) * (L * (L + 1) / 2);
     const size_t cap = 160 * 1024 - 256;
     const int t_mode = full <= cap ? 1 : (packed <= cap ? 2 : 0);
+    if (t_mode == 0) throw std::logic_error("op_chol_inv: order beyond the LDS forms of k_chol_inv");
     const size_t lds = t_mode == 1 ? full : (t_mode == 2 ? packed : base);
     set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv));
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_mode, ndead, (int)Lz);
