@@ -218,8 +218,12 @@ bool topk_applies(int64_t d, int64_t dp, int64_t nc) {
     const int64_t p = std::min<int64_t>(round_up(nc + 16, 16), dp);
     return !(nc <= 0 || p >= d || d <= 88 || p > 512);  // (beyond that the Rayleigh-Ritz solves cost more than they save)
 }
-bool topk_verdict_ok(const double* r3) {
-    return r3[2] == 0.0 && std::isfinite(r3[0]) && r3[1] > 0 && std::sqrt(std::max(r3[0], 0.0)) <= 1e-12 * r3[1];
+// tol: the accepted residual ||C v - theta v|| / theta_0.  The eigenvector of a SMALL wanted eigenvalue inherits residual / gap:
+// at sigma_k = 1e-3 sigma_1 with 15 % gaps, 1e-12 lets that vector be off by 4e-6 (measured 1.4e-7 on fp64 data, where the parity
+// bar is 1e-9) -- fp64 data therefore iterate down to 3e-14, a few times the rounding floor of the product C Q; fp32 data,
+// whose vectors are pinned to ~1e-6 at best, keep 1e-12.
+bool topk_verdict_ok(const double* r3, double tol = 1e-12) {
+    return r3[2] == 0.0 && std::isfinite(r3[0]) && r3[1] > 0 && std::sqrt(std::max(r3[0], 0.0)) <= tol * r3[1];
 }
 // gap_tol: the two-stage solver's closeness threshold for the Ritz problem (relative to ||H||; pairs closer than it go to the
 // Jacobi fallback, which always works to 1e-15) -- 1e-8 when C came from fp32 data (eigenvectors to eps / 1e-8 ~ 1e-8 are
@@ -227,7 +231,7 @@ bool topk_verdict_ok(const double* r3) {
 // more than five decades counted as "clustered" at its small end and each Rayleigh-Ritz step ran the full Jacobi solve (170 +
 // 40 us per step at p = 48, two steps per tall exact-Pca fit).
 bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc, double* V, double* w, double gap_tol,
-               double* resid3 = nullptr) {
+               double* resid3 = nullptr, double verdict_tol = 1e-12) {
     if (!topk_applies(d, dp, nc)) return false;
     const int64_t p = std::min<int64_t>(round_up(nc + 16, 16), dp);
     Dev* dv = c.dev;
@@ -282,7 +286,7 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
             rayleigh_ritz(r3.f64());
             dev_d2h(dv, h3, r3.p, sizeof(h3));
             dev_sync(dv);
-            if (topk_verdict_ok(h3)) { deliver(); return true; }
+            if (topk_verdict_ok(h3, verdict_tol)) { deliver(); return true; }
         }
     }
     return false;
@@ -723,7 +727,8 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     // only the top-k pairs reach the outputs (components, singular values, the k columns of U that svd_flip signs)
     DBuf Ckeep;  // (the eigen-solvers may destroy their input; the accurate route of fp64 fits factors the Gram matrix again)
     if (dt == F64) { Ckeep = DBuf(c.dev, C.bytes); dev_d2d(c.dev, Ckeep.p, C.p, C.bytes); }
-    const bool partial = topk_eigh(c, C.f64(), d, dp, k, V.f64(), lam.f64(), dt == F32 ? 1e-8 : 1e-5, optimistic ? r3.f64() : nullptr);
+    const double vtol = dt == F32 ? 1e-12 : 3e-14;
+    const bool partial = topk_eigh(c, C.f64(), d, dp, k, V.f64(), lam.f64(), dt == F32 ? 1e-8 : 1e-5, optimistic ? r3.f64() : nullptr, vtol);
     // (order d, not the padded dp: the zero padding would only add dp - d exact zero eigenvalues, a cluster that sends the
     // two-stage solver to its Jacobi fallback; V and lam beyond d stay at the zeros set above)
     // (... and the closeness verdict of the two-stage solver covers the k pairs that reach the outputs: the noise-floor
@@ -762,7 +767,7 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     if (k > 0) dev_d2h(c.dev, components, compd.p, esz * size_t(k) * d);
     if (partial && optimistic) dev_d2h(c.dev, h3, r3.p, sizeof(h3));
     dev_sync(c.dev);
-    return !(partial && optimistic) || topk_verdict_ok(h3);
+    return !(partial && optimistic) || topk_verdict_ok(h3, vtol);
     };  // pipeline
     pipeline(false);
     if (slot_flip) sg = signs_from_triple(deferred, r);
@@ -965,7 +970,8 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
         DBuf Ckeep;  // (see pca_fit)
         if (dt == F64) { Ckeep = DBuf(c.dev, C.bytes); dev_d2d(c.dev, Ckeep.p, C.p, C.bytes); }
-        const bool topk = topk_eigh(c, C.f64(), d, dp, nc, U.f64(), lam.f64(), dt == F32 ? 1e-8 : 1e-5, optimistic ? r3.f64() : nullptr);  // only the first nc pairs are used below
+        const double vtol = dt == F32 ? 1e-12 : 3e-14;
+        const bool topk = topk_eigh(c, C.f64(), d, dp, nc, U.f64(), lam.f64(), dt == F32 ? 1e-8 : 1e-5, optimistic ? r3.f64() : nullptr, vtol);  // only the first nc pairs are used below
         if (!topk) {
             dev_memset(c.dev, U.p, 0, U.bytes);
             dev_memset(c.dev, lam.p, 0, lam.bytes);
@@ -1004,7 +1010,7 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         dev_d2h(c.dev, hmu.data(), mu64.p, sizeof(double) * dp);
         if (topk && optimistic) dev_d2h(c.dev, h3, r3.p, sizeof(h3));
         dev_sync(c.dev);
-        return !(topk && optimistic) || topk_verdict_ok(h3);
+        return !(topk && optimistic) || topk_verdict_ok(h3, vtol);
     };
     if (!pipeline(true)) pipeline(false);
     if (n_iter) *n_iter = iters;
