@@ -295,7 +295,12 @@ def ica_par_parity(ctx, n, nc, seed, dtype=np.float32, tol=1e-4):
     wo, no = po.ica_par(x1.astype(np.float64), 1e-4, 200, w0)
     w, ni = petal.ica_par(x1, 1e-4, 200, w0.astype(dtype), ctx=ctx)
     assert abs(ni - no) <= 1, (ni, no)
-    assert np.abs(w @ wo.T - np.eye(nc)).max() <= (tol if ni == no else 10 * tol), np.abs(w @ wo.T - np.eye(nc)).max()
+    prod = w @ wo.T
+    if ni != no:
+        # one more / one fewer application of the map: a row whose update coefficient E[g(y) y] - E[g'(y)] is negative changes
+        # sign with every iteration (the crate's test looks at |w1 . w|), so the two W agree up to those row signs
+        prod = prod * np.sign(np.diag(prod))[:, None]
+    assert np.abs(prod - np.eye(nc)).max() <= (tol if ni == no else 10 * tol), np.abs(prod - np.eye(nc)).max()
 
 
 def ica_par_parity_on(ctx, x1, w0, tol=1e-4, dtype=np.float32):
@@ -304,7 +309,10 @@ def ica_par_parity_on(ctx, x1, w0, tol=1e-4, dtype=np.float32):
     wo, no = po.ica_par(x1.astype(np.float64), 1e-4, 200, w0.astype(np.float64))
     w, ni = petal.ica_par(np.ascontiguousarray(x1.astype(dtype)), 1e-4, 200, w0.astype(dtype), ctx=ctx)
     assert no < 200 and abs(ni - no) <= 1, (ni, no)
-    err = np.abs(w.astype(np.float64) @ wo.T - np.eye(nc)).max()
+    prod = w.astype(np.float64) @ wo.T
+    if ni != no:   # (see ica_par_parity: rows may differ in sign when the iteration counts differ by one)
+        prod = prod * np.sign(np.diag(prod))[:, None]
+    err = np.abs(prod - np.eye(nc)).max()
     assert err <= (tol if ni == no else 10 * tol), (err, ni, no)
     return err
 
