@@ -97,9 +97,10 @@ def test_eigh_orders_beyond_the_workgroup_size(ctx, d):
 
 
 @pytest.mark.parametrize("kind", ["clustered", "rank_deficient"])
-@pytest.mark.parametrize("d", [8, 74, 100, 138, 141])
+@pytest.mark.parametrize("d", [8, 74, 100, 138, 141, 142, 200, 260])
 def test_eigh_clusters_take_the_jacobi_fallback(ctx, d, kind):
-    """exact multiplicities and zero eigenvalues: the two-stage verdict flags them and the Jacobi result is delivered"""
+    """exact multiplicities and zero eigenvalues: the two-stage verdict flags them and the Jacobi result is delivered (orders
+    beyond 141: the global-memory Jacobi kernel behind the global-memory two-stage route)"""
     _check(ctx, _data(d, kind, np.float32, 300 + d), tol_sigma=4e-6, tol_orth=2e-5, tol_res=3e-6)
     _check(ctx, _data(d, kind, np.float64, 400 + d), tol_sigma=1e-12, tol_orth=1e-11, tol_res=1e-12)
 
