@@ -7,6 +7,7 @@ import numpy as np, torch
 import petal_decomposition_amd as petal
 import parity_cases as pc
 ctx = petal.Context(0)
+if os.environ.get("FUZZ_GEMM"): ctx.set_gemm_mode(os.environ["FUZZ_GEMM"])
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 which = sys.argv[3] if len(sys.argv) > 3 else "all"
