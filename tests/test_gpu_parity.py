@@ -71,7 +71,7 @@ def test_rebasing_block_counts(ctx, k):
     pc.rpca_parity(ctx, 3001, 320, k, 4, seed=60 + k, tol=2e-5 if k < 100 else 5e-4, tol_sigma=2e-5, device=True)
 
 
-@pytest.mark.parametrize("k", [131, 132, 140, 180, 190])
+@pytest.mark.parametrize("k", [131, 132, 190])
 def test_orders_between_the_one_workgroup_and_the_blocked_kernels(ctx, k):
     """l = k + 10 = 141 .. 200: beyond the fast Cholesky / eigen kernels (140 / 138), below the blocked forms' old threshold (200).
     A random-shape sweep (dev/fuzz_rpca.py) found this range WRONG in rounds 1-2 (the Cholesky kernel's build-T-in-global-memory
