@@ -82,6 +82,20 @@ def test_orders_between_the_one_workgroup_and_the_blocked_kernels(ctx, k):
     pc.rpca_parity(ctx, 4096, 320, k, 4, seed=1079, tol=1e-3, tol_sigma=1e-5, device=True)
 
 
+def test_rpca_random_shapes_fp64(ctx):
+    """A seeded random-shape sweep in fp64 (which pins the PATH: every kernel class the shape selects must reproduce the oracle to
+    1e-8, free of the fp32 data-conditioning noise): d a multiple of 16 or not, k from 1 to 230 (every Cholesky / eigen-solver
+    order class, one- and two-panel products), row counts around the 256-row workgroups, host and device inputs, with and without
+    centring.  The sweep that found the wrong Cholesky factors at orders 142 .. 200 (dev/fuzz_all.py), kept as a test."""
+    rng = np.random.default_rng(20260)
+    for case in range(28):
+        d = int(rng.choice([16, 24, 48, 64, 100, 128, 160, 200, 256, 272, 320, 400]))
+        n = int(rng.choice([255, 256, 257, 511, 1000, 3001, 4096]))
+        k = int(rng.integers(1, max(2, min(min(n, d) - 10, 230))))
+        pc.rpca_parity(ctx, n, d, k, int(rng.choice([4, 7])), seed=2000 + case, dtype=np.float64, tol=1e-8,
+                       device=bool(rng.integers(0, 2)), centering=bool(rng.integers(0, 4) > 0))
+
+
 def test_rpca_parity_variants(ctx):
     pc.rpca_parity(ctx, 6000, 96, 8, 7, seed=21, device=True)
     pc.rpca_parity(ctx, 3000, 64, 6, 7, seed=22, centering=False)
