@@ -2630,6 +2630,11 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
         // (1) block row J -= (finished rows above)^T (finished rows above), one 16 x 16 tile per wave pass on the fp64 matrix
         //     cores: C(J, Ct) -= sum_K R_KJ^T R_K,Ct.  MFMA 16x16x4 f64: lane l feeds A[l & 15][l >> 4], B[l >> 4][l & 15];
         //     register r of lane l is C[(l >> 4) + 4 r][l & 15].
+        // The diagonal tile (Ct = J, always wave 0's first) does not go back to LDS: the accumulator layout -- register r of lane
+        // (lk, li) = row lk + 4 r, column li -- IS the layout the factorisation below holds its block in, so wave 0 subtracts it
+        // from the old block in registers and factors straight on while the other waves finish their tiles (no tile of theirs
+        // is read by the factorisation, and none of them reads the diagonal tile): one barrier per block row instead of two.
+        cf64x4 dacc = cf64x4{0.0, 0.0, 0.0, 0.0};
         if (jb > 0) {
             const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
             for (int Ct = J + (tid >> 6); Ct < nb; Ct += nt >> 6) {
@@ -2646,13 +2651,13 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[u], pb[u], acc, 0, 0, 0);
                 }
+                if (Ct == J) { dacc = acc; continue; }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rr = jb + lk + 4 * r, cc = 16 * Ct + li;
                     if (rr <= cc && cc < L) Rc[cp(rr, cc)] -= acc[r];
                 }
             }
-            __syncthreads();
         }
         DBG_T(8);
         // (2) diagonal block in the registers of wave 0, right-looking.  Lane (g, c) = (lane >> 4, lane & 15) holds the four rows
@@ -2667,7 +2672,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int k = g + 4 * m, row = jb + k;
-                a[m] = (col < L && row < L) ? (k <= c ? Rc[cp(row, col)] : Rc[cp(col, row)]) : 0.0;
+                a[m] = (col < L && row < L) ? (k <= c ? Rc[cp(row, col)] : Rc[cp(col, row)]) - dacc[m] : 0.0;
             }
             double myinv = 0.0;
 #pragma unroll
