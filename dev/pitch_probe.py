@@ -1,5 +1,5 @@
 """dev: do K1 / K2 care about the row pitch of X?  (2048-byte rows put every 128-B column chunk of all rows on the same few memory
-channels: partition camping)  usage: python dev/pitch_test.py"""
+channels: partition camping)  usage: python dev/pitch_probe.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

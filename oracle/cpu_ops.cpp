@@ -117,7 +117,8 @@ void op_gemm_atb(Dev*, int dt, const void* A, int64_t lda, int64_t M, const void
         }
     }
 }
-void op_flip_key(Dev*, const double* t, double* key, int64_t L) {
+void op_flip_key(Dev*, const double* t, double* key, int64_t L, const int* flag) {
+    if (flag) key[L] = *flag != 0 ? 1.0 : 0.0;
     for (int64_t j = 0; j < L; ++j) {
         uint64_t bits = 0;
         const double a = t[j] < 0 ? 0.0 : t[j];

@@ -125,14 +125,30 @@ std::vector<double> signs_from_triple(const std::vector<double>& h, int64_t L) {
 // (flip_slot_keys() says which part to decode with signs_from_triple()).  Not for sharded fp64 (three dependent rounds).
 bool flip_slot_keys(const petal_ctx& c, int dtype) { return sharded(c) && dtype == F32; }
 // scanned = true: the product kernel already left the (max, row, sign) triple in the slot (op_gemm_xp_prod_absmax)
+// `verdict` (sharded fp32 only; device int): slot[4 L] = (*verdict != 0) rides the same MAX all-reduce, so every rank reads the
+// AGREED redo decision (a rank that branched on its own copy of a replicated flag could leave the others waiting in a collective).
 void flip_signs_to_slot(petal_ctx& c, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* slot,
-                        bool scanned = false) {
-    if (L == 0) return;
-    if (!scanned) op_col_absmax(c.dev, dtype, U, n, L, ldu, row_offset, slot, slot + L, slot + 2 * L);
+                        bool scanned = false, const int* verdict = nullptr) {
+    if (L == 0 && !(verdict && flip_slot_keys(c, dtype))) return;
+    if (!scanned && L > 0) op_col_absmax(c.dev, dtype, U, n, L, ldu, row_offset, slot, slot + L, slot + 2 * L);
     if (flip_slot_keys(c, dtype)) {
-        op_flip_key(c.dev, slot, slot + 3 * L, L);
-        allreduce_f64(c, slot + 3 * L, L, PETAL_MAX);
+        op_flip_key(c.dev, slot, slot + 3 * L, L, verdict);
+        allreduce_f64(c, slot + 3 * L, L + (verdict ? 1 : 0), PETAL_MAX);
     }
+}
+// A yes/no decision that changes which collectives follow (redo of a fit, the accurate route) must be the SAME on every rank.
+// The flags behind these decisions come from replicated kernels on all-reduced inputs and are expected to be bit-identical, but
+// "expected" is not a protocol: a one-rank disagreement would desynchronise the all-reduce sequence and hang the job.  Sharded
+// fits therefore branch on the MAX over the ranks (one 8-byte all-reduce + round trip; only on paths that already synchronise).
+bool agree_any(petal_ctx& c, bool local) {
+    if (!sharded(c)) return local;
+    DBuf w(c.dev, sizeof(double));
+    double v = local ? 1.0 : 0.0;
+    dev_h2d(c.dev, w.p, &v, sizeof(double));
+    allreduce_f64(c, w.f64(), 1, PETAL_MAX);
+    dev_d2h(c.dev, &v, w.p, sizeof(double));
+    dev_sync(c.dev);
+    return v != 0.0;
 }
 std::vector<double> flip_signs(petal_ctx& c, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu,
                                int64_t row_offset, std::vector<double>* deferred = nullptr) {
@@ -304,18 +320,24 @@ bool accurate_small_svd(petal_ctx& c, const DevMat& X, const void* muT, const do
     if (X.dtype != F64 || d > 1024 || d < 1) return false;
     Dev* dv = c.dev;
     DBuf T1(dv, sizeof(double) * dp * dp), T2(dv, sizeof(double) * dp * dp), T(dv, sizeof(double) * dp * dp), G2(dv, sizeof(double) * dp * dp);
-    DBuf nd(dv, 64), Q1(dv, sizeof(double) * size_t(std::max<int64_t>(n, 1)) * dp);
+    DBuf nd(dv, 64);
     dev_memset(dv, nd.p, 0, nd.bytes);
+    int hdead = 0;
+    // (every rank takes the same exits: the pivot flags are replicated, and agree_any() makes that a protocol)
+    auto broke_down = [&] {
+        dev_d2h(dv, &hdead, nd.p, sizeof(int));
+        dev_sync(dv);
+        return agree_any(c, hdead != 0);
+    };
     op_chol_inv(dv, C, d, dp, T1.f64(), dp, 1e-15, nd.as<int>(), dp);
+    if (broke_down()) return false;   // before the second copy of X is allocated or formed
+    DBuf Q1(dv, sizeof(double) * size_t(std::max<int64_t>(n, 1)) * dp);
     op_gemm_xp(dv, F64, X.p, n, dp, X.ld, muT, T1.f64(), dp, dp, nullptr, Q1.p, dp, nullptr);
     op_gemm_atb(dv, F64, Q1.p, dp, dp, nullptr, Q1.p, dp, dp, nullptr, n, G2.f64(), dp, true);
     allreduce_f64(c, G2.f64(), dp * dp, PETAL_SUM);
     op_chol_inv(dv, G2.f64(), d, dp, T2.f64(), dp, 1e-15, nd.as<int>(), dp);
     op_dgemm(dv, false, false, dp, dp, dp, 1.0, T1.f64(), dp, T2.f64(), dp, 0.0, T.f64(), dp);
-    int hdead = 0;
-    dev_d2h(dv, &hdead, nd.p, sizeof(int));
-    dev_sync(dv);
-    if (hdead != 0) return false;
+    if (broke_down()) return false;
     op_jacobi_svd_rows(dv, T.f64(), d, dp, V, dp, sig);
     return true;
 }
@@ -466,7 +488,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     //   res = [ Yp (dp LP) | tv | ndead | lam (LP) | mu64 (2 dp) | flip (4 LP) ]
     // and the components leave in their own k x d buffer, already in the caller's layout and type (op_components_out): 128 KB at
     // configs[1] instead of the 320 KB fp64 d x l matrix V, and nothing for the host to transpose.
-    const int64_t o_tv = dp * LP, o_dead = o_tv + 1, o_lam = o_dead + 1, o_mu = o_lam + LP, o_flip = o_mu + 2 * dp, res_len = o_flip + 4 * LP;
+    const int64_t o_tv = dp * LP, o_dead = o_tv + 1, o_lam = o_dead + 1, o_mu = o_lam + LP, o_flip = o_mu + 2 * dp, res_len = o_flip + 4 * LP + 1;  // (+ 1: the agreed redo verdict of a sharded fp32 fit)
     DBuf comp_dev(c.dev, esz * size_t(std::max<int64_t>(k, 1)) * d);
     DBuf res(c.dev, sizeof(double) * res_len);
     double* const Yp = res.f64();
@@ -621,15 +643,18 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     double t_q = 0, t_s = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
-        if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip, true);
+        if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip, true, attempt == 0 ? ndead : nullptr);
         dev_d2h(c.dev, hres.data(), tvp, sizeof(double) * hres.size());
         if (k > 0) dev_d2h(c.dev, components, comp_dev.p, esz * size_t(k) * d);
         t_q = timer.ms();
         dev_sync(c.dev);
         t_s = timer.ms();
+        if (attempt == 1) break;
         int hdead = 0;
         std::memcpy(&hdead, &hres[o_dead - o_tv], sizeof(int));
-        if (attempt == 1 || hdead == 0) break;
+        bool redo = hdead != 0;
+        if (sharded(c)) redo = flip_slot_keys(c, dt) ? hres[o_flip - o_tv + 4 * kp] != 0.0 : agree_any(c, redo);  // the agreed verdict
+        if (!redo) break;
     }
     if (slot_flip) {
         const double* hf = &hres[o_flip - o_tv];
@@ -742,8 +767,10 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
         std::vector<double> hl(k);
         dev_d2h(c.dev, hl.data(), lam.p, sizeof(double) * k);
         dev_sync(c.dev);
-        const double ratio = (hl[0] > 0 && hl[k - 1] > 0) ? std::sqrt(hl[k - 1] / hl[0]) : 0.0;
-        if (ratio < GRAM_ROUTE_FLOOR) accurate = accurate_small_svd(c, X, muT.p, Ckeep.f64(), d, V.f64(), sig.f64());
+        // (lam[k-1] <= 0 or fewer samples than features: rank-deficient, the accurate route's Cholesky would only break down --
+        // after allocating a second copy of X and two more passes)
+        const bool low = hl[0] > 0 && hl[k - 1] > 0 && n_total >= d && std::sqrt(hl[k - 1] / hl[0]) < GRAM_ROUTE_FLOOR;
+        if (agree_any(c, low)) accurate = accurate_small_svd(c, X, muT.p, Ckeep.f64(), d, V.f64(), sig.f64());
     }
     if (!accurate) op_sigma_inv(c.dev, lam.f64(), sig.f64(), inv.f64(), dp, dt == F32 ? 1e-6 : 1e-10);
     else op_dvec(c.dev, 1, sig.f64(), inv.f64(), dp, dt == F32 ? 1e-6 : 1e-10);
@@ -981,8 +1008,8 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
             std::vector<double> hl(nc);
             dev_d2h(c.dev, hl.data(), lam.p, sizeof(double) * nc);
             dev_sync(c.dev);
-            const double ratio = (hl[0] > 0 && hl[nc - 1] > 0) ? std::sqrt(hl[nc - 1] / hl[0]) : 0.0;
-            if (ratio < GRAM_ROUTE_FLOOR) {
+            const bool low = hl[0] > 0 && hl[nc - 1] > 0 && n_total >= d && std::sqrt(hl[nc - 1] / hl[0]) < GRAM_ROUTE_FLOOR;
+            if (agree_any(c, low)) {  // (rank-deficient data stay on the Gram route: see pca_fit)
                 DBuf sg(c.dev, sizeof(double) * dp);
                 if (accurate_small_svd(c, X, muT.p, Ckeep.f64(), d, U.f64(), sg.f64())) op_dvec(c.dev, 2, sg.f64(), lam.f64(), d, 0.0);
             }
@@ -1010,7 +1037,7 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         dev_d2h(c.dev, hmu.data(), mu64.p, sizeof(double) * dp);
         if (topk && optimistic) dev_d2h(c.dev, h3, r3.p, sizeof(h3));
         dev_sync(c.dev);
-        return !(topk && optimistic) || topk_verdict_ok(h3, vtol);
+        return !agree_any(c, (topk && optimistic) && !topk_verdict_ok(h3, vtol));   // every rank redoes, or none
     };
     if (!pipeline(true)) pipeline(false);
     if (n_iter) *n_iter = iters;

@@ -25,6 +25,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -1470,29 +1471,20 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // every chunk is a whole number of 32-row stages (the host hands the < 32 ragged rows of the matrix to the fp32 kernel)
+    // The ragged stage is PEELED out of the steady-state loop: the loop below sees whole 32-row stages only (a uniform base + one
+    // per-lane offset per load), and the partial stage of the last row chunk runs behind it, unpipelined, with its own clamped
+    // loads.  Round 3 selected between the two address forms with `st < nfull` INSIDE the loaders: both forms then stayed live
+    // across the software-pipelined loop, 128 -> 190 VGPRs at <5, *, 8, 2> (4 -> 2 waves per SIMD) and 14 spilled registers at
+    // <5, *, 8, 4> (tests/test_kernel_budgets.py now holds the budgets).
     auto load_a = [&](int st, fvecm(&av)[8]) {
         const float* p = abase + (int64_t)st * 32 * lda;
-        if (st < nfull) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const fvecm*>(p + (int64_t)e * lda + aoff);
-        } else {  // the partial stage (uniform branch): rows past the end -> the last valid row
-            const unsigned acol = aoff - (unsigned)((int64_t)(8 * q) * lda);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const fvecm*>(p + (int64_t)min(8 * q + e, tail - 1) * lda + acol);
-        }
+        for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const fvecm*>(p + (int64_t)e * lda + aoff);
     };
-    auto load_z1 = [&](int st, f32x8& zr, bool on, unsigned zoff) {
+    auto load_z1 = [&](int st, f32x8& zr, unsigned zoff) {
         const float* p = zbase + (int64_t)st * 32 * ldb;
-        if (st < nfull) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) zr[e] = p[(int64_t)e * ldb + zoff];  // always a valid address (column clamped)
-        } else {
-            const unsigned zcol = zoff - (unsigned)((int64_t)(8 * q) * ldb);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) zr[e] = (8 * q + e < tail) ? p[(int64_t)(8 * q + e) * ldb + zcol] : 0.f;
-        }
-        (void)on;
+        for (int e = 0; e < 8; ++e) zr[e] = p[(int64_t)e * ldb + zoff];  // always a valid address (column clamped)
     };
     auto stage_z1 = [&](int buf, f32x8 zr, int u, bool on) {
         if (!on) zr = f32x8{0, 0, 0, 0, 0, 0, 0, 0};  // columns beyond N contribute zeros
@@ -1502,27 +1494,7 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
         sB[buf][(u * 3 + 1) * 64 + lane] = m;
         sB[buf][(u * 3 + 2) * 64 + lane] = l;
     };
-    fvecm av[8];
-    f32x8 zr0, zr1 = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (nstage > 0) {
-        if (wave < NT) load_z1(0, zr0, zon0, zoff0);
-        if (z2w) load_z1(0, zr1, zon1, zoff1);
-        load_a(0, av);
-        if (wave < NT) stage_z1(0, zr0, wave, zon0);
-        if (z2w) stage_z1(0, zr1, WV + wave, zon1);
-    }
-#ifdef PETAL_DEBUG_COUNTERS
-    long long ph3[6] = {0, 0, 0, 0, 0, 0};
-    long long tq3 = __builtin_amdgcn_s_memtime();
-#define ATB3_STAMP(i) do { const long long _t = __builtin_amdgcn_s_memtime(); ph3[i] += _t - tq3; tq3 = _t; } while (0)
-#else
-#define ATB3_STAMP(i) do {} while (0)
-#endif
-    for (int st = 0; st < nstage; ++st) {
-        const int buf = st & 1;
-        __syncthreads();  // stage st of B is in sB[buf]; nobody still reads sB[buf ^ 1]
-        ATB3_STAMP(0);
-        bf16x8 ah[MT], am[MT], al[MT];
+    auto split_a = [&](fvecm(&av)[8], bf16x8(&ah)[MT], bf16x8(&am)[MT], bf16x8(&al)[MT]) {
         if (CA) {  // centred in place (a centred COPY would keep 32 more registers alive across the four splits)
 #pragma unroll
             for (int e = 0; e < 8; ++e) av[e] -= ma;
@@ -1532,15 +1504,8 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
             const f32x8 x = f32x8{av[0][t], av[1][t], av[2][t], av[3][t], av[4][t], av[5][t], av[6][t], av[7][t]};
             split3(x, ah[t], am[t], al[t]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        ATB3_STAMP(1);
-        if (st + 1 < nstage) {  // fly under this stage's MFMAs; B first (vmcnt retires in order, see k_xp3)
-            if (wave < NT) load_z1(st + 1, zr0, zon0, zoff0);
-            if (z2w) load_z1(st + 1, zr1, zon1, zoff1);
-            load_a(st + 1, av);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        ATB3_STAMP(2);
+    };
+    auto mfma_stage = [&](int buf, int lane, const bf16x8(&ah)[MT], const bf16x8(&am)[MT], const bf16x8(&al)[MT]) {
         // B fragments one tile ahead of the MFMAs that use them (pinned: hoisting all 15 reads costs 48 more registers)
         bf16x8 bh = sB[buf][0 * 64 + lane], bm = sB[buf][1 * 64 + lane], bl = sB[buf][2 * 64 + lane];
 #pragma unroll
@@ -1562,13 +1527,76 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
             __builtin_amdgcn_sched_barrier(0);
             bh = nh; bm = nm; bl = nl;
         }
+    };
+    fvecm av[8];
+    f32x8 zr0, zr1 = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (nfull > 0) {
+        if (wave < NT) load_z1(0, zr0, zoff0);
+        if (z2w) load_z1(0, zr1, zoff1);
+        load_a(0, av);
+        if (wave < NT) stage_z1(0, zr0, wave, zon0);
+        if (z2w) stage_z1(0, zr1, WV + wave, zon1);
+    }
+#ifdef PETAL_DEBUG_COUNTERS
+    long long ph3[6] = {0, 0, 0, 0, 0, 0};
+    long long tq3 = __builtin_amdgcn_s_memtime();
+#define ATB3_STAMP(i) do { const long long _t = __builtin_amdgcn_s_memtime(); ph3[i] += _t - tq3; tq3 = _t; } while (0)
+#else
+#define ATB3_STAMP(i) do {} while (0)
+#endif
+    for (int st = 0; st < nfull; ++st) {
+        const int buf = st & 1;
+        __syncthreads();  // stage st of B is in sB[buf]; nobody still reads sB[buf ^ 1]
+        ATB3_STAMP(0);
+        bf16x8 ah[MT], am[MT], al[MT];
+        split_a(av, ah, am, al);
+        __builtin_amdgcn_sched_barrier(0);
+        ATB3_STAMP(1);
+        if (st + 1 < nfull) {  // fly under this stage's MFMAs; B first (vmcnt retires in order, see k_xp3)
+            if (wave < NT) load_z1(st + 1, zr0, zoff0);
+            if (z2w) load_z1(st + 1, zr1, zoff1);
+            load_a(st + 1, av);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ATB3_STAMP(2);
+        mfma_stage(buf, lane, ah, am, al);
         __builtin_amdgcn_sched_barrier(0);
         ATB3_STAMP(3);
-        if (st + 1 < nstage) {
+        if (st + 1 < nfull) {
             if (wave < NT) stage_z1(buf ^ 1, zr0, wave, zon0);
             if (z2w) stage_z1(buf ^ 1, zr1, WV + wave, zon1);
         }
         ATB3_STAMP(4);
+    }
+    if (tail > 0) {  // the partial stage (uniform branch; only the last row chunk of a launch has one): nothing is in flight here
+        // Every per-lane quantity of this block is re-derived from a laundered copy of the thread index, so that none of them
+        // is a live range across the pipelined loop above (they cost 4-6 VGPRs there: 132 instead of 128 at <5, *, 8, 2>).
+        int tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const int lane2 = tid2 & 63, wave2 = tid2 >> 6, i2 = lane2 & 15, q2 = lane2 >> 4;
+        const int buf = nfull & 1;   // the buffer the last full stage did NOT read
+        const float* zp = zbase + (int64_t)nfull * 32 * ldb;
+        const float* ap = abase + (int64_t)nfull * 32 * lda + min((bx * WV + wave2) * (16 * MT) + MT * i2, M - MT);
+        auto tail_z = [&](int u) {
+            const int zcol = n0col + 16 * u + i2;
+            f32x8 zr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zr[e] = (8 * q2 + e < tail && zcol < N) ? zp[(int64_t)(8 * q2 + e) * ldb + min(zcol, N - 1)] : 0.f;
+            bf16x8 h, m, l;
+            split3(zr, h, m, l);
+            sB[buf][(u * 3 + 0) * 64 + lane2] = h;
+            sB[buf][(u * 3 + 1) * 64 + lane2] = m;
+            sB[buf][(u * 3 + 2) * 64 + lane2] = l;
+        };
+        if (wave2 < NT) tail_z(wave2);
+        if (Z2 && WV + wave2 < NT) tail_z(WV + wave2);
+        // rows past the end -> the last valid row (finite; their B side is zero)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = *reinterpret_cast<const fvecm*>(ap + (int64_t)min(8 * q2 + e, tail - 1) * lda);
+        bf16x8 ah[MT], am[MT], al[MT];
+        split_a(av, ah, am, al);
+        __syncthreads();
+        mfma_stage(buf, lane2, ah, am, al);
     }
 #ifdef PETAL_DEBUG_COUNTERS
     if (lane == 0) {
@@ -5244,8 +5272,9 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     dev_free(d, part);
 }
 
-__global__ void k_flip_key(const double* __restrict__ t, double* __restrict__ key, int64_t L) {
+__global__ void k_flip_key(const double* __restrict__ t, double* __restrict__ key, int64_t L, const int* __restrict__ flag) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == L && flag) key[L] = *flag != 0 ? 1.0 : 0.0;
     if (j >= L) return;
     const double a = t[j] < 0 ? 0.0 : t[j];
     unsigned long long bits = (unsigned long long)__double_as_longlong(a);
@@ -5255,9 +5284,9 @@ __global__ void k_flip_key(const double* __restrict__ t, double* __restrict__ ke
     bits = (bits & ~((1ull << 29) - 1)) | (t[j] < 0 ? 0ull : payload);
     key[j] = __longlong_as_double((long long)bits);
 }
-void op_flip_key(Dev* d, const double* triple, double* key, int64_t L) {
-    if (L == 0) return;
-    hipLaunchKernelGGL(k_flip_key, dim3(cdiv(L, 256)), dim3(256), 0, d->stream, triple, key, L);
+void op_flip_key(Dev* d, const double* triple, double* key, int64_t L, const int* flag) {
+    if (L == 0 && !flag) return;
+    hipLaunchKernelGGL(k_flip_key, dim3(cdiv(L + 1, 256)), dim3(256), 0, d->stream, triple, key, L, flag);
     launch_check();
 }
 void op_col_absmax(Dev* d, int dt, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* absmax,

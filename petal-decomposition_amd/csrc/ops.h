@@ -100,7 +100,9 @@ void op_col_absmax(Dev*, int dtype, const void* U, int64_t n, int64_t L, int64_t
 // svd_flip across ranks, fp32 data: key[j] = the fp64 image of absmax[j] with (2^28 - 1 - row[j], sign[j] < 0) packed into
 // the 29 low mantissa bits an fp32 magnitude leaves zero (absmax < 0, an empty shard, gives key 0); `triple` is
 // op_col_absmax's [absmax | row | sign] (3 L).  A MAX all-reduce of the keys elects the first element of maximal magnitude.
-void op_flip_key(Dev*, const double* triple, double* key, int64_t L);
+// flag != nullptr: key[L] = (*flag != 0) -- a replicated decision word riding the same MAX all-reduce, so that every rank
+// branches on the agreed value
+void op_flip_key(Dev*, const double* triple, double* key, int64_t L, const int* flag = nullptr);
 // A[i][j] *= s[j] (dtype matrix, f64 scale vector), i < n, j < L
 void op_scale_cols(Dev*, int dtype, void* A, int64_t n, int64_t L, int64_t lda, const double* s);
 // G = tanh(X) elementwise (n x c), gp[j]... logcosh KAT helper: rows are components:
