@@ -3,9 +3,13 @@
 
 A "step" is one fit() -- column means + (2 n_iter + 2) power-iteration GEMM passes + the small-matrix
 tail -- over one synthetic batch that is already resident in HBM.  Workload at N = 1: BASELINE configs[1]
-(RandomizedPca k=64, 5 power iterations, 100000 x 512 fp32).  With N > 1 every rank holds its own
-100000 x 512 row block of one (N * 100000) x 512 matrix (weak scaling, sample-sharded): the only data-path
-exchange is the all-reduce of the small replicated matrices (RCCL through torch.distributed).
+(RandomizedPca k=64, 5 power iterations, 100000 x 512 fp32), the configuration the metric is quoted on.
+With N > 1 (and no --config) the workload is the one north_star scales: BASELINE configs[3], ONE 2000000 x 1024 matrix,
+k = 128, 7 power iterations (the crate's default, src/pca.rs:679-680), its rows split N ways -- STRONG scaling,
+`value` = 2000000 samples / time per fit; `--gpus 1 --config cfg4s` is the same matrix on one GPU (8.2 GB: it fits).
+`--config cfg2 | cfg4 | cfg5 --gpus N` keep the weak-scaling lines (every rank its own block of the per-GPU size).
+The only data-path exchange is the all-reduce of the small replicated matrices (RCCL); the record carries
+`allreduce_calls`, `allreduce_bytes` and the stream time spent in them per fit.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      the dominant power-iteration GEMM kernel: algorithmic bytes (default split-product mode: the kernel
@@ -58,7 +62,23 @@ CONFIGS = {
     "cfg4": dict(model="rpca", n=250000, d=1024, k=128, n_iter=7, label="BASELINE configs[3], one rank's 1/8 share per GPU"),
     # BASELINE.json configs[4]: FastIca n_components = 64 on 4000000 x 512 over 8 GPUs -> 500000 rows per rank, tol 1e-4
     "cfg5": dict(model="ica", n=500000, d=512, k=64, n_iter=0, label="BASELINE configs[4], one rank's 1/8 share per GPU"),
+    # BASELINE.json configs[3] as north_star scales it: ONE 2000000 x 1024 matrix split over the N ranks (strong scaling); `n` is
+    # the TOTAL row count here (rows per GPU = n / N), the data is generated on the device (synth_data.synth_pca_device)
+    "cfg4s": dict(model="rpca", n=2000000, d=1024, k=128, n_iter=7, strong=True, seed=4,
+                  label="BASELINE configs[3]: one 2000000x1024 matrix sample-sharded over the GPUs, strong scaling"),
 }
+
+
+def default_config(gpus: int) -> str:
+    """N = 1: the configuration the metric is quoted on (configs[1]); N > 1: the configuration north_star scales (configs[3], strong)"""
+    return "cfg2" if gpus <= 1 else "cfg4s"
+
+
+def shard_rows(n_total: int, world: int, rank: int):
+    """[begin, end) of rank's row block when n_total rows are split over world ranks (the first n_total % world ranks get one more)"""
+    base, extra = divmod(n_total, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
 
 
 def launch_ranks(n_ranks: int, share_gpu: bool = False) -> int:
@@ -99,10 +119,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
-                    help="per-GPU workload: cfg2 = BASELINE configs[1] (default, the metric's configuration), cfg4 / cfg5 = "
-                         "one rank's share of the 8-GPU configs[3] / configs[4]")
-    ap.add_argument("--n", type=int, default=None, help="rows per GPU (default: the config's)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="default: cfg2 = BASELINE configs[1] at --gpus 1 (the metric's configuration); cfg4s = BASELINE configs[3], "
+                         "one 2000000 x 1024 matrix split over the GPUs (strong scaling), at --gpus N > 1.  cfg2 / cfg4 / cfg5 with "
+                         "--gpus N: per-GPU workloads (weak scaling); cfg4 / cfg5 = one rank's share of the 8-GPU configs[3] / configs[4]")
+    ap.add_argument("--n", type=int, default=None, help="rows per GPU (cfg4s: rows of the whole matrix); default: the config's")
     ap.add_argument("--d", type=int, default=None)
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--n-iter", type=int, default=None)
@@ -124,7 +145,11 @@ def main():
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass "
                          "(default: the committed measurement in profiles/r01_pmc_traffic.json for this workload)")
+    ap.add_argument("--no-strong-baseline", action="store_true",
+                    help="cfg4s at N > 1: skip the single-GPU fit of the whole matrix that rank 0 times after the sharded run")
     args = ap.parse_args()
+    if args.config is None:
+        args.config = default_config(args.gpus)
     cfg = CONFIGS[args.config]
     for key in ("n", "d", "k", "n_iter"):
         if getattr(args, key) is None:
@@ -216,17 +241,27 @@ def main():
             dist.destroy_process_group()
         return
 
-    # synthetic shard: the planted model of BASELINE.md section 3; V and mu are shared by all ranks (seed 2), the iid rows of
-    # each rank's block come from its own seed
-    x_host = synth_pca(n, d, k, seed=2, dtype=np.float32, row_seed=None if world == 1 else 2 + 1000 * rank)
-    x = torch.from_numpy(x_host).to(dev)
+    strong = bool(cfg.get("strong"))
+    n_total = n if strong else world * n
+    if strong:
+        # ONE planted matrix, defined block by block on the device: rank r holds rows [begin, end) of it
+        from synth_data import synth_pca_device
+        row_begin, row_end = shard_rows(n_total, world, rank)
+        x_host = None
+        x = synth_pca_device(n_total, d, k, cfg["seed"], row_begin, row_end, dev)
+        n = row_end - row_begin
+    else:
+        # synthetic shard: the planted model of BASELINE.md section 3; V and mu are shared by all ranks (seed 2), the iid rows of
+        # each rank's block come from its own seed
+        x_host = synth_pca(n, d, k, seed=2, dtype=np.float32, row_seed=None if world == 1 else 2 + 1000 * rank)
+        x = torch.from_numpy(x_host).to(dev)
     omega = np.random.default_rng(3).standard_normal((d, l)).astype(np.float32)
     model = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter)
 
     for _ in range(args.warmup):
         model.fit(x, omega=omega)
     sync_all()
-    acc = {"xp_ms": 0.0, "xp_launches": 0, "atb_ms": 0.0, "atb_launches": 0}
+    acc = {"xp_ms": 0.0, "xp_launches": 0, "atb_ms": 0.0, "atb_launches": 0, "allreduce_ms": 0.0, "allreduce_timed": 0}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.fit(x, omega=omega)
@@ -251,18 +286,20 @@ def main():
         roofline = roofline_entry(dom, per, pass_flops, pass_bytes, args.gemm, args.pmc_traffic, n, d, l)
         out = {
             "metric": "samples/sec for RandomizedPca.fit() on n x d fp32",
-            "value": round(world * n * args.steps / elapsed, 1),
+            "value": round(n_total * args.steps / elapsed, 1),
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"RandomizedPca.fit k={k} n_iter={n_iter} oversample=10 on {n}x{d} fp32 per GPU "
-                                   f"({cfg['label']}), X resident in HBM"
+            "config": {"workload": (f"RandomizedPca.fit k={k} n_iter={n_iter} oversample=10 on ONE {n_total}x{d} fp32 matrix, rows split over "
+                                    f"{world} GPU(s) ({cfg['label']}), X resident in HBM" if strong else
+                                    f"RandomizedPca.fit k={k} n_iter={n_iter} oversample=10 on {n}x{d} fp32 per GPU "
+                                    f"({cfg['label']}), X resident in HBM")
                                    + (" and small enough (%.0f MB) to stay in the 256 MiB Infinity Cache between passes" % (4e-6 * n * d)
                                       if 4 * n * d + 8 * n * l <= INFINITY_CACHE_BYTES else ""),
                        "x_fits_infinity_cache": bool(4 * n * d + 8 * n * l <= INFINITY_CACHE_BYTES),
-                       "rows_per_gpu": n, "features": d, "n_components": k, "n_iter": n_iter,
+                       "rows_per_gpu": n, "rows_total": n_total, "features": d, "n_components": k, "n_iter": n_iter,
                        "gemm_mode": ("bf16x3: fp32 operands split exactly into 3 bf16 pieces, 6 piece products on the bf16 "
                                      "matrix cores, fp32 accumulation (fp32-equivalent)") if args.gemm == "bf16x3"
                                     else "fp32 MFMA (v_mfma_f32_16x16x4_f32)",
@@ -270,35 +307,85 @@ def main():
                        "collective": collective},
             "roofline": roofline,
             "fit_roofline": fit_roofline(n, d, l, n_iter, 4, args.gemm, elapsed / args.steps * 1e3),
+            # what went through the collective per fit (sharded runs; zeros on one GPU).  The stream time is sampled: one
+            # bracketed all-reduce per fit, the index rotating from fit to fit -> average call time x calls per fit
+            "collective": collective_entry(st, acc, args.steps),
         }
 
-        if world == 1:
+        if world == 1 and x_host is not None:
             # host-ndarray-in rate (H2D over PCIe included) -- informational, never `value`
             model.fit(x_host, omega=omega)
             t1 = time.perf_counter()
             reps = 3
             for _ in range(reps):
                 model.fit(x_host, omega=omega)
+            st_h = ctx.stats()
             out["host_in"] = {"value": round(n * reps / (time.perf_counter() - t1), 1), "unit": "samples/s",
-                              "note": "fit() fed a pageable host ndarray: PCIe H2D inside the timed region"}
+                              "row_pitch_bytes": int(st_h["x_row_pitch_bytes"]), "natural_pitch_bytes": 4 * d,
+                              "note": "fit() fed a pageable host ndarray: PCIe H2D inside the timed region; the copy lands with a "
+                                      "padded device row pitch when the natural one is a multiple of 1 KiB (memory-channel spread)"}
 
         if world == 1 and args.gemm == "bf16x3" and not args.no_northstar:
             out["fp32_mfma_mode"] = fp32_mode_extra(petal, ctx, model, x, omega)
 
-        if world == 1 and not args.no_northstar:
+        if world == 1 and not args.no_northstar and not strong:
+            del x
+            torch.cuda.empty_cache()
             out["northstar_gemm"] = northstar(petal, ctx, torch, dev)
             ctx.set_gemm_mode(args.gemm)
+            out["northstar_fit"] = northstar_fit(petal, ctx, torch, dev, args.gemm)
 
-        if world == 1 and not args.no_northstar:
+        if world == 1 and not args.no_northstar and not strong:
             out["fastica_cfg3"] = fastica_cfg3(petal, ctx, torch, dev)
             out["pca_cfg1"] = pca_cfg1(petal, ctx, torch, dev)
 
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and x_host is not None:
             out["cpu_baseline"] = cpu_baseline(x_host, omega, k, n_iter)
+    if strong and world > 1 and not args.no_strong_baseline:
+        # the same matrix on ONE GPU, timed by rank 0 alone after the sharded run (the other ranks wait at the barrier below):
+        # the denominator of the strong-scaling ratio, measured in the same job on the same box
+        del x
+        torch.cuda.empty_cache()
+        if rank == 0:
+            try:
+                out["one_gpu_same_matrix"] = strong_baseline(petal, torch, dev, cfg, n_total, d, k, n_iter, omega, args.gemm,
+                                                             out["ms_per_step"])
+            except Exception as e:  # informational: never loses the line
+                out["one_gpu_same_matrix"] = {"error": repr(e)}
+    if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def collective_entry(st, acc, steps):
+    calls, timed = int(st["allreduce_calls"]), int(acc["allreduce_timed"])
+    avg = acc["allreduce_ms"] / timed if timed else 0.0
+    return {"allreduce_calls_per_fit": calls, "allreduce_bytes_per_fit": float(st["allreduce_bytes"]),
+            "allreduce_avg_call_ms": round(avg, 5), "allreduce_ms_per_fit": round(avg * calls, 4),
+            "timed_calls": timed,
+            "note": "stream time between events around the all-reduce calls (includes waiting for the slowest rank)"}
+
+
+def strong_baseline(petal, torch, dev, cfg, n_total, d, k, n_iter, omega, gemm, sharded_ms, reps=3):
+    from synth_data import synth_pca_device
+    ctx1 = petal.Context(dev.index or 0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    ctx1.set_gemm_mode(gemm)
+    x = synth_pca_device(n_total, d, k, cfg["seed"], 0, n_total, dev)
+    m = petal.RandomizedPca(k, ctx=ctx1, n_iter=n_iter)
+    m.fit(x, omega=omega)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.fit(x, omega=omega)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    del x
+    ctx1.close()
+    return {"ms_per_step": round(ms, 4), "samples_per_s": round(n_total / (ms * 1e-3), 1),
+            "speedup_of_the_sharded_run": round(ms / sharded_ms, 3) if sharded_ms > 0 else None,
+            "note": f"RandomizedPca.fit of the whole {n_total}x{d} matrix on rank 0's GPU alone, {reps} fits after one warm-up"}
 
 
 def pmc_traffic(n, d, l, mode, kind, with_commit=False):
@@ -443,6 +530,39 @@ def northstar(petal, ctx, torch, dev, n=1_000_000, d=512, l=74, reps=5):
                                "hbm_bytes_pmc": pmc_traffic(n, d, l, mode, name)}
     ctx.set_gemm_mode("bf16x3")
     del x, z
+    torch.cuda.empty_cache()
+    return res
+
+
+def northstar_fit(petal, ctx, torch, dev, gemm, n=1_000_000, d=512, k=64, reps=5):
+    """The north-star point as a FIT: RandomizedPca.fit on a planted 1e6 x 512 fp32 matrix (2.05 GB, beyond the Infinity Cache),
+    k = 64, at 5 power iterations (BASELINE configs[1]'s count) and 7 (the crate's default), with the whole-fit roofline
+    fraction: here the serial small-matrix chain is a small share of the time, unlike at 100000 rows."""
+    from synth_data import synth_pca_device
+    l = k + 10
+    x = synth_pca_device(n, d, k, 6, 0, n, dev)
+    omega = np.random.default_rng(3).standard_normal((d, l)).astype(np.float32)
+    res = {"shape": f"{n}x{d} fp32, k={k}", "gemm_mode": gemm}
+    for n_iter in (5, 7):
+        m = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter)
+        for _ in range(2):
+            m.fit(x, omega=omega)
+        torch.cuda.synchronize(dev)
+        acc = {"xp_ms": 0.0, "xp_launches": 0, "atb_ms": 0.0, "atb_launches": 0}
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.fit(x, omega=omega)
+            st = ctx.stats()
+            for key in acc:
+                acc[key] += st[key]
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        res[f"n_iter_{n_iter}"] = {
+            "ms_per_fit": round(ms, 4), "samples_per_s": round(n / (ms * 1e-3), 1),
+            "K1_avg_launch_ms": round(acc["xp_ms"] / max(acc["xp_launches"], 1), 4),
+            "K2_avg_launch_ms": round(acc["atb_ms"] / max(acc["atb_launches"], 1), 4),
+            "fit_roofline": fit_roofline(n, d, l, n_iter, 4, gemm, ms)}
+    del x
     torch.cuda.empty_cache()
     return res
 

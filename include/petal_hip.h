@@ -70,6 +70,14 @@ typedef struct petal_stats {
     /* sample-sharded fits: what went through the collective during the last fit (separates comm from compute) */
     int64_t allreduce_calls;   /* all-reduce calls issued (RandomizedPca: n_iter + 3)                  */
     double  allreduce_bytes;   /* payload bytes summed over those calls                                */
+    double  allreduce_ms;      /* stream time of the all-reduce calls that were bracketed (profiling on: one call per fit at
+                                  level 1, the index rotating from fit to fit; all at level 2)                              */
+    int64_t allreduce_timed;   /* ... and how many were: allreduce_ms / allreduce_timed * allreduce_calls estimates a fit's  */
+    /* how the last fit held X on the device */
+    int64_t x_row_pitch_bytes; /* row pitch of X as the kernels streamed it (a host or strided input is copied with 128 B of
+                                  padding per row when its natural pitch is a multiple of 1 KiB: spreads the rows over the
+                                  memory channels; a device input that is streamed in place keeps the caller's pitch)      */
+    int64_t x_zero_copy;       /* 1: the caller's device buffer was streamed in place                                       */
 } petal_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */

@@ -359,6 +359,8 @@ void finish_stats(petal_ctx& c, const Timer& t) {
     c.stats.atb_launches = kt.launches[TAG_ATB];
     c.stats.ica_step_ms = kt.ms[TAG_ICA];
     c.stats.ica_step_launches = kt.launches[TAG_ICA];
+    c.stats.allreduce_ms = kt.ms[TAG_COMM];
+    c.stats.allreduce_timed = kt.launches[TAG_COMM];
 }
 
 }  // namespace
@@ -366,7 +368,9 @@ void finish_stats(petal_ctx& c, const Timer& t) {
 void allreduce_f64(petal_ctx& c, double* dev_buf, int64_t count, int op) {
     if (!sharded(c) || count == 0) return;
     if (!c.allreduce) device_error("world_size > 1 but no collective hook installed (petal_ctx_set_collective)");
+    void* span = dev_span_begin(c.dev, TAG_COMM);
     int rc = c.allreduce(c.allreduce_user, dev_buf, count, PETAL_F64, op, dev_stream(c.dev));
+    dev_span_end(c.dev, span);
     if (rc != 0) device_error("collective all-reduce failed with code " + std::to_string(rc));
     c.stats.allreduce_calls += 1;
     c.stats.allreduce_bytes += double(sizeof(double)) * double(count);
@@ -387,11 +391,20 @@ DevMat ingest(petal_ctx& c, const petal_matrix& x) {
         (reinterpret_cast<uintptr_t>(x.data) % 16) == 0 && (x.row_stride * esz) % 16 == 0) {
         m.p = x.data;  // zero-copy: already in the layout the kernels stream
         m.ld = x.row_stride;
+        m.zero_copy = true;
+        c.stats.x_row_pitch_bytes = int64_t(size_t(m.ld) * esz);
+        c.stats.x_zero_copy = 1;
         return m;
     }
+    // Row pitch of the copy.  A pitch that is a multiple of 1 KiB (2048 B at d = 512 fp32) puts column chunk c of EVERY row on the
+    // same few memory channels; the matrix is being copied anyway, so the copy lands with 128 more bytes per row (measured with
+    // dev/pitch_probe.py, EXPERIMENTS.md round 3: K1 -5 %, K2 -7 % at 100000 x 512).  The padding is never read.
     m.ld = m.dp;
-    m.owned = DBuf(c.dev, esz * size_t(m.n) * m.dp);
+    if (m.n >= 4096 && (size_t(m.dp) * esz) % 1024 == 0 && getenv("PETAL_NO_ROW_PAD") == nullptr) m.ld = m.dp + int64_t(128 / esz);
+    m.owned = DBuf(c.dev, esz * size_t(m.n) * m.ld);
     m.p = m.owned.p;
+    c.stats.x_row_pitch_bytes = int64_t(size_t(m.ld) * esz);
+    c.stats.x_zero_copy = 0;
     if (x.space == PETAL_DEVICE) {
         op_pack_strided(c.dev, x.dtype, x.data, m.n, m.d, x.row_stride, x.col_stride, m.owned.p, m.ld, m.dp);
         return m;

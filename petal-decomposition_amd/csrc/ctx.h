@@ -71,6 +71,7 @@ struct DevMat {
     int64_t n = 0, d = 0, dp = 0, ld = 0;  // rows, real cols, padded cols, leading dimension (elements)
     int dtype = F32;
     DBuf owned;                             // empty when zero-copy
+    bool zero_copy = false;                 // the caller's device buffer is streamed in place
 };
 
 // host algorithms (algo.cpp)

@@ -314,6 +314,22 @@ struct TagScope {
     }
 };
 
+void* dev_span_begin(Dev* d, int tag) {
+    if (!d->profiling || tag <= 0 || tag >= TAG_COUNT) return nullptr;
+    const int idx = d->tag_seen[tag]++;
+    if (!(d->profiling >= 2 || idx == d->tag_pick[tag])) return nullptr;
+    Dev::Rec* r = new Dev::Rec{tag, get_event(d), get_event(d)};
+    HIP_CHECK(hipEventRecord(r->a, d->stream));
+    return r;
+}
+void dev_span_end(Dev* d, void* token) {
+    if (!token) return;
+    Dev::Rec* r = static_cast<Dev::Rec*>(token);
+    HIP_CHECK(hipEventRecord(r->b, d->stream));
+    d->recs.push_back(*r);
+    delete r;
+}
+
 static inline void launch_check() { HIP_CHECK(hipGetLastError()); }
 static inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -1629,8 +1645,14 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // T = float: the precise Gram of fp32 data; T = double: K2 for fp64 inputs (same kernel, 16-B / 32-B loads).
+// (development knob: the minimum waves per SIMD asked of the compiler for the fp32-data instantiations.  Left alone the kernel
+// takes 132 unified registers = 3 waves per SIMD; asked for 4 it fits 96 -- by serialising load -> convert -> MFMA -- and runs
+// SLOWER: 3244 vs 2760 us at 500000 x 512, 449 vs 323 us at 200000 x 256, round 4, same box)
+#ifndef PETAL_GRAM_MINWAVES
+#define PETAL_GRAM_MINWAVES 1
+#endif
 template <class T, bool CA, bool CB, int NE = 4>
-__global__ __launch_bounds__(256) void k_atb_f64(const T* __restrict__ A, int64_t lda, int M, const T* __restrict__ muA,
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && NE == 4 ? PETAL_GRAM_MINWAVES : 1)) void k_atb_f64(const T* __restrict__ A, int64_t lda, int M, const T* __restrict__ muA,
                                                  const T* __restrict__ B, int64_t ldb, int N, const T* __restrict__ muB,
                                                  int64_t n, int64_t chunk, double* __restrict__ part, int sym) {
     // NE = B tiles per wave: lane i holds the NE consecutive columns n0 + NE i .. (tile e, col j <-> col = n0 + NE j + e).

@@ -19,10 +19,10 @@ inline size_t dtype_size(int dt) { return dt == F64 ? 8 : 4; }
 struct Dev;  // opaque: stream, allocator cache, event pool (hip) / nothing much (cpu sim)
 
 // hot-kernel tags: launches issued while a tag is set are bracketed with events when profiling is on
-enum Tag : int { TAG_NONE = 0, TAG_XP = 1, TAG_ATB = 2, TAG_ICA = 3, TAG_COUNT = 4 };
+enum Tag : int { TAG_NONE = 0, TAG_XP = 1, TAG_ATB = 2, TAG_ICA = 3, TAG_COMM = 4, TAG_COUNT = 5 };
 struct KernelTiming {
-    double ms[TAG_COUNT] = {0, 0, 0, 0};
-    int64_t launches[TAG_COUNT] = {0, 0, 0, 0};
+    double ms[TAG_COUNT] = {0, 0, 0, 0, 0};
+    int64_t launches[TAG_COUNT] = {0, 0, 0, 0, 0};
 };
 
 // ---- lifetime / memory ---------------------------------------------------------------------
@@ -49,6 +49,10 @@ void  dev_abort(Dev*);                     // error path: wait for the stream, d
 void  dev_reset_timing(Dev*);
 void  dev_set_tag(Dev*, int tag);
 KernelTiming dev_timing(Dev*);            // resolves pending events (call after dev_sync)
+// Brackets stream work that is not one of this file's kernels (the collective) with the same event machinery as the tagged
+// kernels: begin returns a token (nullptr when this launch is not sampled), end records the closing event.
+void* dev_span_begin(Dev*, int tag);
+void  dev_span_end(Dev*, void* token);
 
 // ---- O(n) streaming ops --------------------------------------------------------------------
 // dst[i*ld_dst + j] = src[i*rs + j*cs] for j < d, 0 for d <= j < d_pad   (device -> device gather)

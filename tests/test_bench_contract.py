@@ -60,6 +60,25 @@ def test_roofline_bound_is_computed_from_the_shape():
     assert f["passes"] == 12 and 0.2 < f["frac"] < 0.35, f
 
 
+def test_default_workload_per_gpu_count():
+    """N = 1: configs[1], the configuration the metric is quoted on (weak-scaling label as before).  N > 1 without --config:
+    configs[3] as north_star scales it -- ONE 2000000 x 1024 matrix, k = 128, 7 power iterations (src/pca.rs:679-680), its rows
+    split over the ranks: strong scaling, rows_per_gpu = 2000000 / N."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.default_config(1) == "cfg2" and bench.CONFIGS["cfg2"]["n"] == 100000 and not bench.CONFIGS["cfg2"].get("strong")
+    for n_gpus in (2, 4, 8):
+        name = bench.default_config(n_gpus)
+        cfg = bench.CONFIGS[name]
+        assert name == "cfg4s" and cfg["strong"] and (cfg["n"], cfg["d"], cfg["k"], cfg["n_iter"]) == (2000000, 1024, 128, 7)
+        blocks = [bench.shard_rows(cfg["n"], n_gpus, r) for r in range(n_gpus)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == cfg["n"] and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        assert all(e - b == cfg["n"] // n_gpus for b, e in blocks)
+    assert bench.shard_rows(10, 3, 0) == (0, 4) and bench.shard_rows(10, 3, 1) == (4, 7) and bench.shard_rows(10, 3, 2) == (7, 10)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"scaling": "strong" if strong else "weak"' in src and '"northstar_fit"' in src
+
+
 def test_help_runs_without_a_gpu():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and "--gpus" in res.stdout and "--steps" in res.stdout and "--warmup" in res.stdout
@@ -111,3 +130,25 @@ def test_self_launch_two_ranks_sharing_the_gpu():
     before any GPU call), they share GPU 0 and all-reduce over gloo; rank 0 prints the one record with n_gpus = 2."""
     rec = _run("--gpus", "2", "--share-gpu", "--no-cpu-baseline", launcher_env=False, n_gpus=2)
     assert "SHARE GPU 0" in rec["config"]["collective"] and rec["config"]["parallelism"] == "sample-sharded x2"
+    # no --config at N = 2: configs[3] split two ways, strong scaling, total samples per second
+    assert rec["scaling"] == "strong" and rec["config"]["rows_per_gpu"] == 1000000 and rec["config"]["rows_total"] == 2000000
+    assert rec["config"]["n_components"] == 128 and rec["config"]["n_iter"] == 7 and rec["config"]["features"] == 1024
+    assert abs(rec["value"] - 2000000 / (rec["ms_per_step"] * 1e-3)) <= 1e-3 * rec["value"]
+    co = rec["collective"]
+    assert co["allreduce_calls_per_fit"] == 7 + 3 and co["allreduce_bytes_per_fit"] > 0 and co["allreduce_ms_per_fit"] > 0
+    assert rec["one_gpu_same_matrix"]["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_single_gpu_record_has_the_northstar_fit():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rec = json.loads(res.stdout.strip().split("\n")[-1])
+    assert rec["scaling"] == "weak" and rec["config"]["rows_per_gpu"] == 100000
+    nf = rec["northstar_fit"]
+    for key in ("n_iter_5", "n_iter_7"):
+        assert nf[key]["ms_per_fit"] > 0 and 0 < nf[key]["fit_roofline"]["frac"] <= 1.0
+    assert nf["n_iter_7"]["fit_roofline"]["passes"] == 16
+    assert rec["host_in"]["row_pitch_bytes"] == 2048 + 128
