@@ -197,7 +197,8 @@ void op_components_out(Dev*, int dt, const double* Bt, int64_t ldb, const double
         }
     }
 }
-void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz) {
+void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz,
+                 int64_t ndead_cols) {
     if (Lz < L) Lz = L;
     std::vector<double> R(size_t(L) * L, 0.0);
     std::vector<char> dead(L, 0);
@@ -214,7 +215,7 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
             R[j * L + c] = v / rjj;
         }
     }
-    if (ndead) { int c = 0; for (int64_t j = 0; j < L; ++j) c += dead[j]; if (c > *ndead) *ndead = c; }
+    if (ndead) { int c = 0; for (int64_t j = 0; j < (ndead_cols > 0 ? std::min(L, ndead_cols) : L); ++j) c += dead[j]; if (c > *ndead) *ndead = c; }
     // T = R^{-1} by back substitution per column; dead columns -> 0 (and are skipped as rows)
     for (int64_t i = 0; i < Lz; ++i)
         for (int64_t j = 0; j < Lz; ++j) T[i * ldt + j] = 0;
@@ -314,7 +315,7 @@ void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, do
     for (int64_t i = 0; i < L; ++i)
         for (int64_t j = 0; j < L; ++j) V[i * ldv + j] = Vs[i * L + j];
 }
-void op_jacobi_svd_rows(Dev*, double* A, int64_t L, int64_t lda, double* U, int64_t ldu, double* s_inv) {
+void op_jacobi_svd_rows(Dev*, double* A, int64_t L, int64_t lda, double* U, int64_t ldu, double* s_inv, int*) {
     std::vector<double> G(size_t(L) * L, 0.0);
     for (int64_t i = 0; i < L; ++i) G[i * L + i] = 1.0;
     for (int sweep = 0; sweep < 60; ++sweep) {

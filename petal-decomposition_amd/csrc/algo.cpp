@@ -338,7 +338,13 @@ bool accurate_small_svd(petal_ctx& c, const DevMat& X, const void* muT, const do
     op_chol_inv(dv, G2.f64(), d, dp, T2.f64(), dp, 1e-15, nd.as<int>(), dp);
     op_dgemm(dv, false, false, dp, dp, dp, 1.0, T1.f64(), dp, T2.f64(), dp, 0.0, T.f64(), dp);
     if (broke_down()) return false;
-    op_jacobi_svd_rows(dv, T.f64(), d, dp, V, dp, sig);
+    // (into temporaries: a Jacobi run that used up its sweeps raises the same flag, and the caller's Gram-route result stays)
+    DBuf Vt(dv, sizeof(double) * dp * dp), st(dv, sizeof(double) * dp);
+    dev_memset(dv, Vt.p, 0, Vt.bytes);
+    op_jacobi_svd_rows(dv, T.f64(), d, dp, Vt.f64(), dp, st.f64(), nd.as<int>());
+    if (broke_down()) return false;
+    dev_copy2d(dv, V, sizeof(double) * dp, Vt.p, sizeof(double) * dp, sizeof(double) * d, size_t(d), 2);
+    dev_d2d(dv, sig, st.p, sizeof(double) * d);
     return true;
 }
 // (sigma_k / sigma_1 of the Gram route's own eigenvalues below this: its sigma_k is no longer good to 1e-9)
@@ -608,7 +614,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         // breakdowns of the power iterations: the fit is then redone on the robust Cholesky-QR2 path instead of silently
         // dropping a component.  On the planted spectra the pivot ratios r_jj^2 / H_jj stay above 0.9: Pcur's columns come out
         // of a Cholesky-QR ordered like the singular vectors, so Z's columns are nearly orthogonal.)
-        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, ndead, LP);
+        // (only a lost pivot among the first k columns touches an output component: exactly low-rank fp32 data, whose columns beyond
+        // the rank are dropped here with sigma = 0 -- the correct answer -- no longer pays for a second, robust fit)
+        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, ndead, LP, std::max<int64_t>(k, 1));
         Usrc = Z.p; Ubuf = Z1.p;
     } else {
         // Cholesky-QR2: Z1 = Z T1, Q = Z1 T2 with T2 folded into the small side

@@ -921,13 +921,16 @@ __global__ __launch_bounds__(256) void k_pack_p3(const double* __restrict__ P, i
 #define PETAL_XP3_DEPTH 1   // raw X chunks in flight per wave (2 measured slower)
 #define PETAL_XP3_OCC 2     // waves per SIMD the register budget is cut for
 #endif
-template <int RT, int NT, int DEPTH, bool CENTER, int WVK = 4, int OCC = PETAL_XP3_OCC>  // WVK = waves (row tiles of 16 RT rows) per workgroup
+// NPL = planes of P that take part: 3, or 2 when the caller DEFINED P as the sum of its two leading bf16 pieces (the re-based
+// iterate of the power iteration, k_trsm_pack<NB, true>): the product x_h p_l has nothing to multiply then -- five piece products
+// instead of six, and a third less of P to stage through LDS.
+template <int RT, int NT, int DEPTH, bool CENTER, int WVK = 4, int OCC = PETAL_XP3_OCC, int NPL = 3>  // WVK = waves (row tiles of 16 RT rows) per workgroup
 __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
                                                             const float* __restrict__ mu, const bf16x8* __restrict__ Ppk3,
                                                             int NTtot, int nt0, int N, const float* __restrict__ bias,
                                                             float* __restrict__ Z, int64_t ldz, double* __restrict__ amax,
                                                             int64_t am_ld) {
-    constexpr int PITEMS = NT * 192;               // 16-B items of one P chunk (NT tiles x 3 planes x 64 lanes)
+    constexpr int PITEMS = NT * 64 * NPL;          // 16-B items of one P chunk (NT tiles x NPL planes x 64 lanes)
     constexpr int NTHR = 64 * WVK;
     constexpr int PI = (PITEMS + NTHR - 1) / NTHR;  // per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_xp3[];
@@ -950,7 +953,14 @@ __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__
         const int64_t r = row0 + 16 * t + i;
         xrow[t] = X + (r < n ? r : (n - 1)) * ldx + 8 * q;
     }
-    const bf16x8* psrc = Ppk3 + (int64_t)nt0 * 192 + tid;
+    // item j of the LDS image = (tile u, plane pl < NPL, lane): u = j / (64 NPL); in memory the tile keeps three planes
+    const bf16x8* psrc = Ppk3 + (int64_t)nt0 * 192;
+    int poff[PI];
+#pragma unroll
+    for (int it = 0; it < PI; ++it) {
+        const int j = tid + NTHR * it;
+        poff[it] = NPL == 3 ? j : (j / (64 * NPL)) * 192 + (j % (64 * NPL));
+    }
     auto load_a = [&](int c, f32x8(&a)[RT]) {
         const bool in = 32 * c + 8 * q < K;  // K % 32 == 16: the upper half of the last chunk does not exist
 #pragma unroll
@@ -963,7 +973,7 @@ __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__
     auto load_p = [&](int c, bf16x8(&pn)[PI]) {
 #pragma unroll
         for (int it = 0; it < PI; ++it)
-            if (tid + NTHR * it < PITEMS) pn[it] = psrc[(int64_t)c * NTtot * 192 + NTHR * it];
+            if (tid + NTHR * it < PITEMS) pn[it] = psrc[(int64_t)c * NTtot * 192 + poff[it]];
     };
     auto store_p = [&](int buf, const bf16x8(&pn)[PI]) {
 #pragma unroll
@@ -1020,16 +1030,19 @@ __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__
             XP3_STAMP(3);
             // P fragments one tile ahead of the MFMAs that use them (pinned: hoisting all 15 reads costs 48 more registers)
             const bf16x8* sPb = sP + buf * PITEMS + lane;
-            bf16x8 bh = sPb[0], bm = sPb[64], bl = sPb[128];
+            bf16x8 bh = sPb[0], bm = sPb[64], bl = NPL == 3 ? sPb[128] : bm;
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 bf16x8 nh = bh, nm = bm, nl = bl;
-                if (u + 1 < NT) { nh = sPb[(u * 3 + 3) * 64]; nm = sPb[(u * 3 + 4) * 64]; nl = sPb[(u * 3 + 5) * 64]; }
+                if (u + 1 < NT) {
+                    nh = sPb[((u + 1) * NPL) * 64]; nm = sPb[((u + 1) * NPL + 1) * 64];
+                    if (NPL == 3) nl = sPb[((u + 1) * NPL + 2) * 64];
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {  // P fragment as the A operand: the accumulator tile is Z^T (16-B stores below)
                     f32x4 c4 = acc[t][u];
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[t], c4, 0, 0, 0);   // smallest terms first
+                    if (NPL == 3) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[t], c4, 0, 0, 0);   // smallest terms first
                     c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[t], c4, 0, 0, 0);
                     c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[t], c4, 0, 0, 0);
                     c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[t], c4, 0, 0, 0);
@@ -1915,7 +1928,6 @@ __device__ __forceinline__ void ica_write_slab(const f32x4 (&dacc)[NT][NT], cons
     float* out = part + (int64_t)blockIdx.x * SLAB;
     for (int e = threadIdx.x; e < SLAB; e += 256) out[e] = s_slab[e] + s_slab[SLAB + e];
 }
-
 template <int NT>
 __global__ __launch_bounds__(256) void k_ica_mfma(const float* __restrict__ X1T, int64_t n, int64_t ld,
                                                   const float* __restrict__ Wpk, int64_t tiles_per_wave,
@@ -2343,7 +2355,11 @@ __global__ __launch_bounds__(256) void k_dgemm_reduce(const double* __restrict__
 typedef double cf64x4 __attribute__((ext_vector_type(4)));
 constexpr int TRSM_MAXM = 144;
 __host__ __device__ inline size_t trsm_lds_bytes(int M) { return sizeof(double) * 16 * (size_t)(M + 2); }
-template <int NB>   // NB = M / 16 at compile time: straight-line code, so every operand load is issued ahead of the MFMA chain
+// P2: the result is ROUNDED to the sum of its two leading bf16 pieces, P := bf16(p) + bf16(p - bf16(p)) (16 significant bits), in
+// P_out too -- the re-based iterate may be any basis of range(A), so this rounding defines the iterate instead of perturbing a
+// product (numpy model, configs[1] / configs[3] spectra: no change in the 5e-6 / 1.5e-5 component errors), and the next product
+// needs five piece products instead of six (k_xp3<..., NPL = 2>).  The third plane is not written.
+template <int NB, bool P2 = false>   // NB = M / 16 at compile time: straight-line code, so every operand load is issued ahead of the MFMA chain
 __global__ __launch_bounds__(64) void k_trsm_pack(const double* __restrict__ A, int64_t lda, const double* __restrict__ RT, int64_t ldt,
                                                   int64_t K, double* __restrict__ P_out, int64_t ldpo,
                                                   bf16x8* __restrict__ pk3, int NTtot) {
@@ -2389,7 +2405,7 @@ __global__ __launch_bounds__(64) void k_trsm_pack(const double* __restrict__ A, 
         __builtin_amdgcn_sched_barrier(0);   // (keeps the loads of row I + 2 from being hoisted above this row's products)
     }
     __syncthreads();
-    if (P_out)
+    if (P_out && !P2)
         for (int e = lane; e < 16 * M; e += 64) {
             const int r = e / M, c = e - r * M;
             P_out[(i0 + r) * ldpo + c] = sP[r * ldsp + c];
@@ -2406,11 +2422,19 @@ __global__ __launch_bounds__(64) void k_trsm_pack(const double* __restrict__ A, 
             const int ln = (col & 15) + 16 * (int)(((i0 & 31) + 8 * g) >> 3);
             pk3[(tile * 3 + 0) * 64 + ln] = h;
             pk3[(tile * 3 + 1) * 64 + ln] = m;
+            if (P2) {
+                if (P_out) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) P_out[(i0 + 8 * g + e) * ldpo + col] = (double)(float)h[e] + (double)(float)m[e];
+                }
+            } else
             pk3[(tile * 3 + 2) * 64 + ln] = l;
             if ((K & 31) == 16 && i0 + 16 == K) {   // half-empty last chunk: zero operand groups for the rows that do not exist
                 bf16x8 z; for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) pk3[(tile * 3 + pl) * 64 + ln + 32] = z;
+                for (int pl = 0; pl < (P2 ? 2 : 3); ++pl) pk3[(tile * 3 + pl) * 64 + ln + 32] = z;
+                if (P2 && P_out) {   // (those rows do not exist in P_out)
+                }
             }
         }
     }
@@ -2630,10 +2654,11 @@ __host__ __device__ inline size_t chol2_lds_bytes(int L) {
 }
 // gd_ref (nullable): the diagonal the pivots are compared with (rel_tol * gd_ref[j]) when G is a Schur complement of a
 // larger matrix (blocked factorisation of L > 200: the dependence test stays relative to the ORIGINAL diagonal)
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T,
-                                                            int64_t ldt, double rel_tol, int* __restrict__ ndead_out, int Lz,
-                                                            const double* __restrict__ gd_ref, int rt_form) {
-    extern __shared__ __attribute__((aligned(16))) double sm_chol[];
+// The factorisation proper, on a column-packed upper triangle that is already in LDS (Rc filled, Tc zeroed, gd = the reference
+// diagonal).  Collective over the workgroup; starts with a barrier.  (Split from its loader in round 4 for a kernel that fed it
+// from in-launch partial sums -- measured slower than the separate launches, EXPERIMENTS.md -- and kept as the cleaner shape.)
+__device__ __forceinline__ void chol2_body(double* sm_chol, int L, double* __restrict__ T, int64_t ldt, double rel_tol,
+                                           int* __restrict__ ndead_out, int Lz, int rt_form, int ncount) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int np = L * (L + 1) / 2;
     double* Rc = sm_chol;
@@ -2641,26 +2666,6 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
     double* gd = Tc + np;
     double* rinv = gd + L;
     int* dead = reinterpret_cast<int*>(rinv + L);
-    // (loads in batches of four: a runtime-trip loop of load -> LDS-store pairs pays an L2 round trip per pair, eleven in a row
-    // at l = 74)
-    for (int e0 = tid; e0 < L * L; e0 += 4 * nt) {
-        double gv[4];
-        int rr[4], cc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * nt;
-            rr[u] = e / L; cc[u] = e - rr[u] * L;
-            gv[u] = (e < L * L && cc[u] >= rr[u]) ? G[(int64_t)rr[u] * ldg + cc[u]] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (e0 + u * nt < L * L && cc[u] >= rr[u]) {
-                Rc[cp(rr[u], cc[u])] = gv[u];
-                Tc[cp(rr[u], cc[u])] = 0.0;
-                if (cc[u] == rr[u]) gd[rr[u]] = gd_ref ? gd_ref[rr[u]] : gv[u];
-            }
-        }
-    }
     for (int e = tid; e < Lz * Lz; e += nt) {  // zero padding of the output beyond the factored block
         const int r = e / Lz, c = e - r * Lz;
         if (r >= L || c >= L) T[(int64_t)r * ldt + c] = 0.0;
@@ -2805,7 +2810,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
     DBG_T(11);
     if (tid < 64 && ndead_out) {   // (wave 0 counts: a serial loop over L LDS reads by one thread was 2 us)
         int cdead = 0;
-        for (int j = tid; j < L; j += 64) cdead += dead[j];
+        for (int j = tid; j < min(L, ncount); j += 64) cdead += dead[j];   // (ncount: only the columns whose loss the caller minds)
         for (int off = 32; off > 0; off >>= 1) cdead += __shfl_down(cdead, off, 64);
         if (tid == 0 && cdead > *ndead_out) *ndead_out = cdead;
     }
@@ -2875,6 +2880,38 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
         const int r = e / L, c = e - r * L;
         T[(int64_t)r * ldt + c] = c >= r ? Tc[cp(r, c)] : 0.0;
     }
+}
+
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T,
+                                                            int64_t ldt, double rel_tol, int* __restrict__ ndead_out, int Lz,
+                                                            const double* __restrict__ gd_ref, int rt_form, int ncount) {
+    extern __shared__ __attribute__((aligned(16))) double sm_chol[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int np = L * (L + 1) / 2;
+    double* Rc = sm_chol;
+    double* Tc = Rc + np;
+    double* gd = Tc + np;
+    // (loads in batches of four: a runtime-trip loop of load -> LDS-store pairs pays an L2 round trip per pair, eleven in a row
+    // at l = 74)
+    for (int e0 = tid; e0 < L * L; e0 += 4 * nt) {
+        double gv[4];
+        int rr[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * nt;
+            rr[u] = e / L; cc[u] = e - rr[u] * L;
+            gv[u] = (e < L * L && cc[u] >= rr[u]) ? G[(int64_t)rr[u] * ldg + cc[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e0 + u * nt < L * L && cc[u] >= rr[u]) {
+                Rc[cp(rr[u], cc[u])] = gv[u];
+                Tc[cp(rr[u], cc[u])] = 0.0;
+                if (cc[u] == rr[u]) gd[rr[u]] = gd_ref ? gd_ref[rr[u]] : gv[u];
+            }
+        }
+    }
+    chol2_body(sm_chol, L, T, ldt, rel_tol, ndead_out, Lz, rt_form, ncount);
 }
 
 // ---- convergence of a Jacobi sweep, graded matrices included ------------------------------------------------------------
@@ -4911,13 +4948,18 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         // split-product (bf16x3) form: grid of 64-row wave tiles, column panels of <= 5 tiles
         const int64_t nch = (K + 31) / 32, total = nch * NTtot * 64;
         bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
+        // two-plane P (five piece products) where P is the re-based iterate of a power iteration: k_trsm_pack rounds it so
+        static const bool no_p2 = getenv("PETAL_NO_P2") != nullptr;
+        const bool p2 = prod_A && prod_rt && !am && !no_p2;
         if (prod_A) {
             // P = prod_A . P: the fp64 GEMM kernel writes the product (prod_out) AND its operand planes from its epilogue
             if (prod_rt)   // P is R in RT form: blocked triangular solve instead of the product with the explicit inverse
                 switch ((int)(N / 16)) {
 #define PETAL_TRSM_CASE(NB)                                                                                                        \
     case NB:                                                                                                                       \
-        hipLaunchKernelGGL(k_trsm_pack<NB>, dim3(cdiv(K, 16)), dim3(64), trsm_lds_bytes(16 * NB), d->stream, prod_A, prod_lda, P,  \
+        if (p2) hipLaunchKernelGGL((k_trsm_pack<NB, true>), dim3(cdiv(K, 16)), dim3(64), trsm_lds_bytes(16 * NB), d->stream, prod_A, prod_lda, P,  \
+                                   ldp, K, prod_out, prod_ldo, Ppk3, NTtot);                                                       \
+        else hipLaunchKernelGGL((k_trsm_pack<NB, false>), dim3(cdiv(K, 16)), dim3(64), trsm_lds_bytes(16 * NB), d->stream, prod_A, prod_lda, P,  \
                            ldp, K, prod_out, prod_ldo, Ppk3, NTtot);                                                               \
         break
                     PETAL_TRSM_CASE(1); PETAL_TRSM_CASE(2); PETAL_TRSM_CASE(3); PETAL_TRSM_CASE(4); PETAL_TRSM_CASE(5);
@@ -4947,14 +4989,15 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         const int npass = cdiv(NTtot, 9);
         for (int nt0 = 0, pass = 0; nt0 < NTtot; ++pass) {
             const int w = (NTtot - nt0 + (npass - pass) - 1) / (npass - pass);
-            const size_t lds = sizeof(bf16x8) * 2 * w * 192 + sizeof(float) * 32 * nch;
-#define XP3_LAUNCH8(NTv)                                                                                                                  \
+            const size_t lds = sizeof(bf16x8) * 2 * w * 64 * (p2 ? 2 : 3) + sizeof(float) * 32 * nch;
+#define XP3_LAUNCH8P(NTv, NPLv)                                                                                                           \
             do {                                                                                                                            \
                 const int blocksw = cdiv(n, 256);                                                                                           \
-                if (lds > 64 * 1024) set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp3<2, NTv, DPv, true, 8>) : reinterpret_cast<const void*>(k_xp3<2, NTv, DPv, false, 8>)); \
-                if (muf) hipLaunchKernelGGL((k_xp3<2, NTv, DPv, true, 8>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
-                else hipLaunchKernelGGL((k_xp3<2, NTv, DPv, false, 8>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
+                if (lds > 64 * 1024) set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp3<2, NTv, DPv, true, 8, PETAL_XP3_OCC, NPLv>) : reinterpret_cast<const void*>(k_xp3<2, NTv, DPv, false, 8, PETAL_XP3_OCC, NPLv>)); \
+                if (muf) hipLaunchKernelGGL((k_xp3<2, NTv, DPv, true, 8, PETAL_XP3_OCC, NPLv>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
+                else hipLaunchKernelGGL((k_xp3<2, NTv, DPv, false, 8, PETAL_XP3_OCC, NPLv>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
             } while (0)
+#define XP3_LAUNCH8(NTv) do { if (p2) XP3_LAUNCH8P(NTv, 2); else XP3_LAUNCH8P(NTv, 3); } while (0)
             if (w >= 6) {   // eight 32-row waves per workgroup: the P chunk is staged once per 256 rows, as in the 64-row form
                 switch (w) {
                     case 9: XP3_LAUNCH8(9); break;
@@ -4966,13 +5009,14 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
                 nt0 += w;
                 continue;
             }
-#define XP3_LAUNCH(RTw, NTv)                                                                                                               \
+#define XP3_LAUNCHP(RTw, NTv, NPLv)                                                                                                        \
             do {                                                                                                                            \
                 const int blocksw = cdiv(n, 64 * RTw);                                                                                      \
-                if (lds > 64 * 1024) set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp3<RTw, NTv, DPv, true>) : reinterpret_cast<const void*>(k_xp3<RTw, NTv, DPv, false>)); \
-                if (muf) hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, true>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
-                else hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, false>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
+                if (lds > 64 * 1024) set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp3<RTw, NTv, DPv, true, 4, PETAL_XP3_OCC, NPLv>) : reinterpret_cast<const void*>(k_xp3<RTw, NTv, DPv, false, 4, PETAL_XP3_OCC, NPLv>)); \
+                if (muf) hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, true, 4, PETAL_XP3_OCC, NPLv>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
+                else hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, false, 4, PETAL_XP3_OCC, NPLv>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
             } while (0)
+#define XP3_LAUNCH(RTw, NTv) do { if (p2) XP3_LAUNCHP(RTw, NTv, 2); else XP3_LAUNCHP(RTw, NTv, 3); } while (0)
             // LDS-DMA ring form (k_xp4): whole 32-column chunks, mu + rings within the 160 KB of one workgroup per CU
             // (measured slower than k_xp3 -- 68 vs 62 us at 100000 x 512, 594 vs 570 us at 1e6 -- so it is opt-in: DESIGN section 9)
             static const int xp4_env = [] { const char* e = getenv("PETAL_XP4"); return e ? atoi(e) : 0; }();
@@ -5006,6 +5050,8 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
             }
 #undef XP3_LAUNCH
 #undef XP3_LAUNCH8
+#undef XP3_LAUNCHP
+#undef XP3_LAUNCH8P
             launch_check();
             nt0 += w;
         }
@@ -5598,7 +5644,7 @@ static void chol_inv_blocked(Dev* d, const double* G, int64_t L, int64_t ldg, do
         if (j0 > 0)  // block row J of the Schur complement (its diagonal block and everything right of it)
             op_dgemm(d, true, false, bj, L - j0, j0, -1.0, R + j0, L, R + j0, L, 1.0, W + j0 * L + j0, L);
         hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)bj), d->stream, W + j0 * L + j0, (int)bj, L,
-                           T + j0 * ldt + j0, ldt, rel_tol, ndead, (int)bj, (const double*)(gd + j0), 0);
+                           T + j0 * ldt + j0, ldt, rel_tol, ndead, (int)bj, (const double*)(gd + j0), 0, (int)bj);
         launch_check();
         if (rest > 0)
             op_dgemm(d, true, false, bj, rest, bj, 1.0, T + j0 * ldt + j0, ldt, W + j0 * L + j0 + bj, L, 0.0, R + j0 * L + j0 + bj, L);
@@ -5629,12 +5675,13 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
     }
     set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
     hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead,
-                       (int)M, (const double*)nullptr, 1);
+                       (int)M, (const double*)nullptr, 1, (int)L);
     launch_check();
     gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, M, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, true);
 }
 
-void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz) {
+void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz,
+                 int64_t ndead_cols) {
     if (L == 0) return;
     if (Lz < L) Lz = L;
     static const bool force_old = getenv("PETAL_CHOL_OLD") != nullptr;
@@ -5646,7 +5693,7 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
     if (L <= CHOL2_MAXL && !force_old) {
         set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
         hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol,
-                           ndead, (int)Lz, (const double*)nullptr, 0);
+                           ndead, (int)Lz, (const double*)nullptr, 0, (int)(ndead_cols > 0 ? ndead_cols : L));
         launch_check();
         return;
     }
@@ -5793,7 +5840,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
 constexpr int HJ_THREADS = 1024, HJ_GROUP = 32;
 template <bool INLDS>
 __global__ __launch_bounds__(HJ_THREADS) void k_jacobi_svd_rows(double* __restrict__ A, int L, int64_t lda, double* __restrict__ Gg,
-                                                                double* __restrict__ U, int64_t ldu, double* __restrict__ s_inv) {
+                                                                double* __restrict__ U, int64_t ldu, double* __restrict__ s_inv, int* __restrict__ nonconv) {
     extern __shared__ __attribute__((aligned(16))) double sm_hj[];   // [row norms (L) | flag | M, G when INLDS]: all dynamic
     const int tid = threadIdx.x, gl = tid & (HJ_GROUP - 1), grp = tid / HJ_GROUP, ngrp = HJ_THREADS / HJ_GROUP;
     const int ld = INLDS ? (L | 1) : L;
@@ -5810,6 +5857,10 @@ __global__ __launch_bounds__(HJ_THREADS) void k_jacobi_svd_rows(double* __restri
     }
     __syncthreads();
     const int n = (L + 1) & ~1, half = n >> 1;   // round-robin over n players (a dummy when L is odd)
+    // a pair is orthogonal when |p . q| <= tol |p| |q|, tol = 4 eps sqrt(L): the rounding noise of an L-term fp64 dot product
+    // (a fixed 1e-15 sat below it, so the flag rarely cleared and the kernel usually ran all 40 sweeps: ADVICE round 3)
+    const double otol = 8.9e-16 * sqrt((double)L);
+    bool converged = false;
     for (int sweep = 0; sweep < 40; ++sweep) {
         if (tid == 0) s_rot = 0;
         __syncthreads();
@@ -5826,7 +5877,7 @@ __global__ __launch_bounds__(HJ_THREADS) void k_jacobi_svd_rows(double* __restri
                 for (int off = HJ_GROUP / 2; off > 0; off >>= 1) {
                     al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
                 }
-                if (!(fabs(ga) > 1e-15 * sqrt(al * be))) continue;   // (uniform over the 32 lanes of the pair)
+                if (!(fabs(ga) > otol * sqrt(al * be))) continue;   // (uniform over the 32 lanes of the pair)
                 if (gl == 0) s_rot = 1;
                 const double zeta = (be - al) / (2.0 * ga);
                 const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -5844,8 +5895,9 @@ __global__ __launch_bounds__(HJ_THREADS) void k_jacobi_svd_rows(double* __restri
         }
         const int any = s_rot;
         __syncthreads();
-        if (!any) break;
+        if (!any) { converged = true; break; }
     }
+    if (nonconv && tid == 0 && !converged) *nonconv = 1;   // 40 sweeps were not enough: the caller keeps its other result
     // singular values = row norms; ascending order (ties: lower row first), 1 / s out
     for (int i = tid; i < L; i += HJ_THREADS) {
         double a = 0;
@@ -5862,18 +5914,18 @@ __global__ __launch_bounds__(HJ_THREADS) void k_jacobi_svd_rows(double* __restri
     }
 #undef s_rot
 }
-void op_jacobi_svd_rows(Dev* d, double* A, int64_t L, int64_t lda, double* U, int64_t ldu, double* s_inv) {
+void op_jacobi_svd_rows(Dev* d, double* A, int64_t L, int64_t lda, double* U, int64_t ldu, double* s_inv, int* nonconv) {
     if (L == 0) return;
     if (L > 1024) throw std::runtime_error("jacobi_svd_rows: order above 1024");
     const size_t lds = sizeof(double) * (L + 2 + 2 * (size_t)L * (L | 1));
     if (lds <= 150 * 1024) {
         set_max_lds(d, reinterpret_cast<const void*>(k_jacobi_svd_rows<true>));
-        hipLaunchKernelGGL(k_jacobi_svd_rows<true>, dim3(1), dim3(HJ_THREADS), lds, d->stream, A, (int)L, lda, (double*)nullptr, U, ldu, s_inv);
+        hipLaunchKernelGGL(k_jacobi_svd_rows<true>, dim3(1), dim3(HJ_THREADS), lds, d->stream, A, (int)L, lda, (double*)nullptr, U, ldu, s_inv, nonconv);
         launch_check();
         return;
     }
     double* G = (double*)dev_alloc(d, sizeof(double) * L * L);
-    hipLaunchKernelGGL(k_jacobi_svd_rows<false>, dim3(1), dim3(HJ_THREADS), sizeof(double) * (L + 2), d->stream, A, (int)L, lda, G, U, ldu, s_inv);
+    hipLaunchKernelGGL(k_jacobi_svd_rows<false>, dim3(1), dim3(HJ_THREADS), sizeof(double) * (L + 2), d->stream, A, (int)L, lda, G, U, ldu, s_inv, nonconv);
     launch_check();
     dev_free(d, G);
 }

@@ -150,8 +150,10 @@ void op_components_out(Dev*, int dtype, const double* Bt, int64_t ldb, const dou
 // A pivot with r_jj^2 <= rel_tol * G_jj (or G_jj <= 0) marks column j as dependent: T[:, j] = 0.
 // Only the upper triangle of G is read.  ndead (nullable, device int): *ndead = max(*ndead, number of dependent columns).
 // Lz > L: T is additionally zero-filled out to Lz x Lz (the padded extent of the caller's buffers).
+// ndead_cols > 0: only dependent columns j < ndead_cols count towards *ndead (orders the one-workgroup kernel takes; larger
+// orders count them all).
 void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead = nullptr,
-                 int64_t Lz = 0);
+                 int64_t Lz = 0, int64_t ndead_cols = 0);
 // symmetric PSD A (L x L) -> eigenvalues w (descending) and eigenvectors in the COLUMNS of V.  A may be destroyed.
 // tol_rel: off-diagonal elements are annihilated down to |a_pq| <= tol_rel sqrt(a_pp a_qq) (graded matrices keep the
 // relative accuracy of their small eigenvalues) or to the 1e-16 ||diag|| rounding floor; 1e-15 for fp64 data, 1e-8 is
@@ -193,7 +195,8 @@ void op_whiten_k(Dev*, const double* U, int64_t ldu, const double* lam, int64_t 
 //   s_inv (L):      1 / (that singular value)  (descending; 0 where the singular value is 0).
 // (This is the order its one caller wants: A = R^-1 of a thin QR X = Q R, whose left singular vectors are the right
 // singular vectors of X and whose inverse singular values are X's, largest first.)  A is destroyed.
-void op_jacobi_svd_rows(Dev*, double* A, int64_t L, int64_t lda, double* U, int64_t ldu, double* s_inv);
+// nonconv (nullable, device int): set to 1 when 40 sweeps did not orthogonalise the rows (never cleared here).
+void op_jacobi_svd_rows(Dev*, double* A, int64_t L, int64_t lda, double* U, int64_t ldu, double* s_inv, int* nonconv = nullptr);
 // Every column j < cols of Y (rows x cols, ldy) that is exactly zero is replaced by column j of Src (lds): the robust re-basing
 // of RandomizedPca refills the directions its dependence test dropped with fresh (random) ones instead of shrinking the block.
 void op_refill_zero_cols(Dev*, double* Y, int64_t rows, int64_t cols, int64_t ldy, const double* Src, int64_t lds);

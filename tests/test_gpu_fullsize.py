@@ -14,6 +14,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -37,22 +38,28 @@ def _free_port():
 def ranks(tmp_path_factory):
     out = tmp_path_factory.mktemp("fullsize")
     port = _free_port()
-    procs = []
+    procs, logf = [], []
     for r in range(fc.WORLD):   # fresh children, started before this process hands them anything GPU-related
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(fc.WORLD), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # every worker writes to its OWN file: with pipes drained one after another a later rank that fills its 64 KB pipe
+        # (RCCL / HIP warnings, a traceback) blocks mid-collective while the harness waits on rank 0
+        logf.append(open(os.path.join(out, f"rank{r}.log"), "w"))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "fullsize_worker.py"), str(out)],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    logs = []
-    for p in procs:
-        try:
-            logs.append(p.communicate(timeout=1500)[0])
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
+                                      env=env, stdout=logf[-1], stderr=subprocess.STDOUT))
+    deadline = time.monotonic() + 1500
+    try:
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.monotonic()))
+    except subprocess.TimeoutExpired:
+        for q in procs:
+            q.kill()
+        raise
+    finally:
+        for fh in logf:
+            fh.close()
     for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+        assert p.returncode == 0, f"rank {r} failed:\n" + open(os.path.join(out, f"rank{r}.log")).read()[-3000:]
     return [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(fc.WORLD)]
 
 

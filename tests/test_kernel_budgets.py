@@ -20,8 +20,8 @@ BUDGETS = [
     (r"k_atb3<5, (true|false), 8, 4>$", 208, 0, "K2 split-product, long-row form (1e6 x 512)"),
     (r"k_atb3<9, (true|false), 8, 2>$", 170, 0, "K2 split-product, l = 138 (configs[3])"),
     (r"k_atb3<", 256, 0, "every K2 split-product instantiation: no scratch"),
-    (r"k_xp3<4, 5, 1, (true|false), 4, 2>$", 232, 0, "K1 split-product, l = 74"),
-    (r"k_xp3<2, 9, 1, (true|false), 8, 2>$", 180, 0, "K1 split-product, l = 138"),
+    (r"k_xp3<4, 5, 1, (true|false), 4, 2, [23]>$", 232, 0, "K1 split-product, l = 74"),
+    (r"k_xp3<2, 9, 1, (true|false), 8, 2, [23]>$", 180, 0, "K1 split-product, l = 138"),
     (r"k_xp3<", 256, 0, "every K1 split-product instantiation: no scratch"),
     (r"k_ica3<2>$", 128, 0, "FastICA step, 32 components: 4 waves/SIMD"),
     (r"k_ica3<4>$", 256, 0, "FastICA step, 64 components"),
