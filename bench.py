@@ -325,6 +325,9 @@ def main():
                               "note": "fit() fed a pageable host ndarray: PCIe H2D inside the timed region; the copy lands with a "
                                       "padded device row pitch when the natural one is a multiple of 1 KiB (memory-channel spread)"}
 
+        if world == 1 and not strong and not args.no_northstar:
+            out["x_padded_pitch"] = padded_pitch_extra(petal, ctx, torch, model, x, omega)
+
         if world == 1 and args.gemm == "bf16x3" and not args.no_northstar:
             out["fp32_mfma_mode"] = fp32_mode_extra(petal, ctx, model, x, omega)
 
@@ -472,6 +475,27 @@ def fit_roofline(n, d, l, n_iter, esz, mode, ms_per_step):
             "passes": passes, "pass_floor_us": round(b["floor_s"] * 1e6, 2), "pass_pipe": b["pipe"],
             "note": "floor = (2 n_iter + 2) GEMM passes at their binding roofline + the means pass + U = Q.Uh; the serial "
                     "small-matrix steps between the passes have no floor of their own here"}
+
+
+def padded_pitch_extra(petal, ctx, torch, model, x, omega, steps=20, pad_elems=32):
+    """The same fit with X held by the CALLER with a padded row pitch (a strided device view, streamed in place): informational.
+    A row pitch that is a multiple of 1 KiB puts column chunk c of every row on the same few memory channels; 128 B of padding per
+    row spreads them (what the library does by itself for inputs it has to copy)."""
+    n, d = x.shape
+    buf = torch.empty((n, d + pad_elems), dtype=x.dtype, device=x.device)
+    view = buf[:, :d]
+    view.copy_(x)
+    for _ in range(3):
+        model.fit(view, omega=omega)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.fit(view, omega=omega)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    st = ctx.stats()
+    return {"ms_per_step": round(ms, 4), "samples_per_s": round(n / (ms * 1e-3), 1), "row_pitch_bytes": int(st["x_row_pitch_bytes"]),
+            "zero_copy": bool(st["x_zero_copy"]),
+            "note": "X passed as a device view with 128 B of padding per row (the caller's layout, streamed in place); `value` above "
+                    "is measured on the contiguous matrix"}
 
 
 def fp32_mode_extra(petal, ctx, model, x, omega, steps=10):

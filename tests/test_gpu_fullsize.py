@@ -148,6 +148,7 @@ def test_cfg5_full_size_8_shards_against_the_single_process_fit(ranks):
     for corr in [fc.source_match(ys, src)] + [r["cfg5.corr"] for r in ranks]:
         assert corr.max(axis=1).min() > 0.99 and corr.max(axis=0).min() > 0.99
         assert len(set(corr.argmax(axis=1))) == nc
-    # collective budget: prologue + covariance + one (nc^2 + nc) all-reduce per iteration (the flag is read every 4th)
-    assert r0["cfg5.allreduce"][0] <= 2 + 4 * ((it + 3) // 4), r0["cfg5.allreduce"]
+    # collective budget: prologue + covariance + one (nc^2 + nc) all-reduce per iteration (the flag is read every 4th) + the
+    # 8-byte agreement on the optimistic whitening's verdict (every rank redoes the fit, or none: round 4)
+    assert r0["cfg5.allreduce"][0] <= 3 + 4 * ((it + 3) // 4), r0["cfg5.allreduce"]
     ctx.close()

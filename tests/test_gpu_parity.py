@@ -593,6 +593,45 @@ def test_lds_dma_k1_variant_is_bit_identical():
     assert np.array_equal(z0, z1)
 
 
+def test_two_plane_iterate_against_the_three_plane_fit():
+    """The re-based iterate of a power iteration is DEFINED as the sum of its two leading bf16 pieces (k_trsm_pack<NB, true>; the next
+    K1 then needs five piece products, not six).  Any basis of range(Yp) serves the iteration, so the fit must agree with the
+    three-plane fit (PETAL_NO_P2=1, read once per process: a child) far inside the parity bar -- and, being a different rounding
+    of the iterate, must not be bit-identical to it (or the two-plane path did not run).  Both against the oracle at 1e-5."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    import petal_decomposition_amd as petal
+    from oracle import petal_oracle as po
+    n, d, k, n_iter = 20000, 512, 64, 5
+    x = po.synth_pca(n, d, k, seed=11, dtype=np.float32)
+    om = np.random.default_rng(12).standard_normal((d, k + 10))
+    ref = po.RandomizedPcaOracle(k, n_iter=n_iter).fit(x.astype(np.float64), omega=om)
+    ctx = petal.Context(0)
+    m = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter).fit(x, omega=om.astype(np.float32))
+    c2, s2 = m.components().astype(np.float64), m.singular_values().astype(np.float64)
+    ctx.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), x=x, om=om.astype(np.float32))
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); import petal_decomposition_amd as petal; c = petal.Context(0); "
+                "d = np.load(%r); m = petal.RandomizedPca(%d, ctx=c, n_iter=%d).fit(d['x'], omega=d['om']); "
+                "np.savez(%r, c=m.components(), s=m.singular_values())" % (root, os.path.join(tmp, "in.npz"), k, n_iter, os.path.join(tmp, "out.npz")))
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PETAL_NO_P2="1"), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out = np.load(os.path.join(tmp, "out.npz"))
+        c3, s3 = out["c"].astype(np.float64), out["s"].astype(np.float64)
+
+    def rel(a, b):
+        sg = np.sign(np.sum(a * b, axis=1))
+        return (np.linalg.norm(a * sg[:, None] - b, axis=1) / np.linalg.norm(b, axis=1)).max()
+    assert not np.array_equal(c2, c3), "the two-plane path did not run"
+    assert rel(c2, c3) < 1e-5 and np.abs(s2 / s3 - 1).max() < 1e-6, (rel(c2, c3), np.abs(s2 / s3 - 1).max())
+    assert rel(c2, ref.components) < 1e-5 and rel(c3, ref.components) < 1e-5, (rel(c2, ref.components), rel(c3, ref.components))
+    assert np.abs(s2 / ref.singular - 1).max() < 1e-5
+
+
 def test_cfg4_share_against_the_oracle():
     """ONE rank's share of BASELINE configs[3] -- 250000 x 1024 fp32, k = 128 (l = 138), n_iter = 7 (src/pca.rs:680) -- against the
     fp64 LAPACK oracle run from the same Omega (about a minute of host time on the GPU box), both GEMM modes: singular values to
