@@ -662,11 +662,14 @@ def fastica_cfg3(petal, ctx, torch, dev, n=200000, d=256, nc=32):
         m.fit(x, w_init=w0)
     t0 = time.perf_counter()
     reps = 10
+    step_sum, step_cnt = 0.0, 0
     for _ in range(reps):
         m.fit(x, w_init=w0)
+        st = ctx.stats()   # (level-1 profiling samples one launch per fit, the kind rotating: accumulate over the fits)
+        step_sum += st["ica_step_ms"]
+        step_cnt += st["ica_step_launches"]
     fit_ms = (time.perf_counter() - t0) / reps * 1e3
-    st = ctx.stats()
-    step_ms = st["ica_step_ms"] / max(st["ica_step_launches"], 1)
+    step_ms = step_sum / max(step_cnt, 1)
     m200 = petal.FastIca(ctx=ctx, n_components=nc, tol=0.0, max_iter=200)
     m200.fit(x, w_init=w0)
     t0 = time.perf_counter()

@@ -9,7 +9,7 @@ x = torch.randn((n, d), generator=g, device="cuda")
 # planted decay so the spectrum is not flat
 x[:, :256] *= torch.logspace(2, 0, 256, device="cuda")
 om = np.random.default_rng(3).standard_normal((d, k + 10)).astype(np.float32)
-ctx = petal.Context(0); ctx.set_profiling(True)
+ctx = petal.Context(0); ctx.set_profiling(2)
 m = petal.RandomizedPca(k, ctx=ctx, n_iter=7)
 for _ in range(3): m.fit(x, omega=om)
 t0 = time.perf_counter()

@@ -1,0 +1,26 @@
+#!/bin/bash
+# everything round 4's README / profiles quote, in one GPU session (outputs under gpurun_out/final4_*)
+cd "$GRAFT_REPO_ROOT"
+python bench.py > gpurun_out/final4_bench_default.log 2> gpurun_out/final4_bench_default.err; tail -1 gpurun_out/final4_bench_default.log > gpurun_out/final4_bench_default.json
+bash dev/prof_fit.sh final4 > gpurun_out/final4_prof_fit.txt 2>&1
+cp gpurun_out/kt_final4/*/*_kernel_stats.csv gpurun_out/final4_kernel_stats.csv 2>/dev/null
+python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/final4_bench_cfg4.json
+python bench.py --config cfg5 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/final4_bench_cfg5.json
+python bench.py --gemm fp32 --steps 30 --warmup 5 --no-cpu-baseline --no-northstar 2>/dev/null | tail -1 > gpurun_out/final4_bench_fp32.json
+python bench.py --config cfg4s --steps 5 --warmup 2 --no-cpu-baseline --no-northstar 2>/dev/null | tail -1 > gpurun_out/final4_bench_cfg4s_1gpu.json
+python bench.py --gpus 2 --share-gpu --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/final4_bench_cfg4s_share2.json
+bash dev/kt.sh final4_ica "k_ica|k_atb_f64|tridiag|trieig|jacobi|eigh|k_sum|k_xp3|chol|symdecorr|ritz|whiten" dev/ica_bench.py > gpurun_out/final4_ica_bench.txt 2>&1
+bash dev/kt.sh final4_ica5 "k_ica|k_atb_f64|tridiag|trieig|jacobi|eigh|k_sum|k_xp3|chol|symdecorr|ritz|whiten" dev/ica5_bench.py > gpurun_out/final4_ica5_bench.txt 2>&1
+bash dev/tl.sh final4_rp2 dev/rpca_one.py > /dev/null 2>&1
+bash dev/tl.sh final4_rp4 dev/rpca_one.py cfg4 > /dev/null 2>&1
+bash dev/tl.sh final4_ica3 dev/ica_one.py > /dev/null 2>&1
+# PMC passes (counters in their own runs, --kernel-trace only)
+for mode in bf16x3; do for rows in 100000 1000000; do for counter in FETCH_SIZE WRITE_SIZE; do
+  PETAL_GEMM=$mode dev/pmc_pass.sh tr_${mode}_${rows}_${counter} $rows $counter > /dev/null 2>&1
+done; done; done
+PMC_SCRIPT=dev/pmc_ica3.py dev/pmc_pass.sh ica3_j1 200000 GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES > /dev/null 2>&1
+python dev/pmc_table.py gpurun_out/pmc_ica3_j1 > gpurun_out/final4_pmc_ica_200000x32.txt 2>&1
+# keep only the counter CSVs of the traffic passes (small) for dev/pmc_traffic.py to read back in the build container
+find gpurun_out/pmc_tr_* -type f ! -name "*counter_collection.csv" -delete 2>/dev/null
+rm -rf gpurun_out/pmc_ica3_j1 gpurun_out/kt_*
+echo done

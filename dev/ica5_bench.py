@@ -11,7 +11,7 @@ a = torch.randn((nc, d), generator=g, device="cuda", dtype=torch.float32)
 x = src @ a + 0.01 * torch.randn((n, d), generator=g, device="cuda", dtype=torch.float32)
 w0 = np.random.default_rng(7).standard_normal((nc, nc)).astype(np.float32)
 ctx = petal.Context(0)
-ctx.set_profiling(True)
+ctx.set_profiling(2)
 m = petal.FastIca(ctx=ctx, n_components=nc)
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter(); m.fit(x, w_init=w0); dt = time.perf_counter() - t0

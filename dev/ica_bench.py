@@ -9,7 +9,7 @@ x = synth_ica(n, d, nc, seed=5, dtype=np.float32)
 xd = torch.from_numpy(x).cuda()
 w0 = np.random.default_rng(7).standard_normal((nc, nc)).astype(np.float32)
 ctx = petal.Context(0)
-ctx.set_profiling(True)
+ctx.set_profiling(2)
 m = petal.FastIca(ctx=ctx, n_components=nc)
 for rep in range(3):
     t0 = time.perf_counter(); m.fit(xd, w_init=w0); torch.cuda.synchronize(); dt = time.perf_counter() - t0

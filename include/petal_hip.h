@@ -96,8 +96,9 @@ int         petal_ctx_set_collective(petal_ctx* ctx, petal_allreduce_fn fn, void
  * with dlopen at the first call (the copy already loaded in the process wins), error 3 when it cannot be found. */
 int         petal_rccl_unique_id(void* out128);
 int         petal_ctx_init_rccl(petal_ctx* ctx, const void* unique_id128, int rank, int world_size);
-/* profiling: 0 off; 1 = bracket ONE launch of each hot kernel per fit with hipEvents (the launch index rotates from
- * fit to fit, so K fits sample every launch position; keeps the event bubbles out of the fit time); 2 = every launch.
+/* profiling: 0 off; 1 = bracket ONE launch per fit with hipEvents (the kernel kind -- K1, K2, the FastICA step, the all-reduce --
+ * and the launch index within the kind rotate from fit to fit, so K fits sample every launch position of every kind; an event
+ * pair is a ~5 us bubble in the stream); 2 = every launch.
  * petal_stats.*_ms / *_launches count the bracketed launches only. */
 int         petal_ctx_set_profiling(petal_ctx* ctx, int profiling);
 /* How the two X-streaming GEMM kernels of fp32 fits form their products (results agree to fp32 accumulation noise):

@@ -84,6 +84,8 @@ struct Dev {
     int tag_seen[TAG_COUNT] = {};    // tagged launches so far in this fit
     int tag_count[TAG_COUNT] = {};   // tagged launches of the previous fit (period of the rotation)
     int tag_pick[TAG_COUNT] = {};    // index of the launch that is timed in this fit
+    int tag_active = 0;              // level 1: the ONE tag that is sampled in this fit (rotates over the tags the last fit used)
+    int fit_index = 0;
     // pinned staging for small device-to-host results: copies are queued back to back on the stream and handed to the
     // caller's (pageable) buffers at the next dev_sync, instead of one blocking staged copy each
     char* pin = nullptr;
@@ -289,11 +291,19 @@ static void resolve_events(Dev* d) {
 void dev_reset_timing(Dev* d) {
     if (!d->recs.empty()) { (void)hipStreamSynchronize(d->stream); resolve_events(d); }
     d->acc = KernelTiming{};
-    for (int t = 0; t < TAG_COUNT; ++t) {  // next fit times the next launch index of every tag
+    // Level 1 samples ONE launch per fit in all: an event pair is a ~5 us bubble in the stream, and a RandomizedPca fit has two
+    // tagged kinds (three when sharded).  The sampled kind rotates over the kinds the previous fit used, the launch index of a kind
+    // advances each time the kind has had its turn: K fits still visit every launch position of every kind.
+    int used[TAG_COUNT], nused = 0;
+    for (int t = 1; t < TAG_COUNT; ++t) {
         if (d->tag_seen[t] > 0) d->tag_count[t] = d->tag_seen[t];
-        d->tag_pick[t] = d->tag_count[t] > 0 ? (d->tag_pick[t] + 1) % d->tag_count[t] : 0;
+        if (d->tag_count[t] > 0) used[nused++] = t;
         d->tag_seen[t] = 0;
     }
+    if (nused > 0 && d->tag_active > 0 && d->tag_count[d->tag_active] > 0)
+        d->tag_pick[d->tag_active] = (d->tag_pick[d->tag_active] + 1) % d->tag_count[d->tag_active];
+    ++d->fit_index;
+    d->tag_active = nused > 0 ? used[d->fit_index % nused] : 0;   // 0: no history yet -- the first fit samples every kind
 }
 KernelTiming dev_timing(Dev* d) {
     if (!d->recs.empty()) { HIP_CHECK(hipStreamSynchronize(d->stream)); resolve_events(d); }
@@ -305,7 +315,7 @@ struct TagScope {
     explicit TagScope(Dev* dev) : d(dev), on(false) {
         if (d->profiling && d->tag > 0 && d->tag < TAG_COUNT) {
             const int idx = d->tag_seen[d->tag]++;
-            on = d->profiling >= 2 || idx == d->tag_pick[d->tag];
+            on = d->profiling >= 2 || (idx == d->tag_pick[d->tag] && (d->tag_active == 0 || d->tag_active == d->tag));
         }
         if (on) { a = get_event(d); b = get_event(d); HIP_CHECK(hipEventRecord(a, d->stream)); }
     }
@@ -317,7 +327,7 @@ struct TagScope {
 void* dev_span_begin(Dev* d, int tag) {
     if (!d->profiling || tag <= 0 || tag >= TAG_COUNT) return nullptr;
     const int idx = d->tag_seen[tag]++;
-    if (!(d->profiling >= 2 || idx == d->tag_pick[tag])) return nullptr;
+    if (!(d->profiling >= 2 || (idx == d->tag_pick[tag] && (d->tag_active == 0 || d->tag_active == tag)))) return nullptr;
     Dev::Rec* r = new Dev::Rec{tag, get_event(d), get_event(d)};
     HIP_CHECK(hipEventRecord(r->a, d->stream));
     return r;
