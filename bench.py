@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass "
                          "(default: the committed measurement in profiles/r01_pmc_traffic.json for this workload)")
+    ap.add_argument("--clock-ramp-s", type=float, default=0.25,
+                    help="seconds of untimed fits in front of the warm-up steps (brings the GPU clocks up after the host-side data generation)")
     ap.add_argument("--no-strong-baseline", action="store_true",
                     help="cfg4s at N > 1: skip the single-GPU fit of the whole matrix that rank 0 times after the sharded run")
     args = ap.parse_args()
@@ -258,6 +260,12 @@ def main():
     omega = np.random.default_rng(3).standard_normal((d, l)).astype(np.float32)
     model = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter)
 
+    # Clock ramp (untimed, like the W warm-up steps behind it): the seconds of host-side data generation above leave the GPU in its
+    # idle clock state, and W = 5 one-millisecond fits do not bring it back (measured: the first 25 ms after an idle period run
+    # 5-10 % slow).  A quarter of a second of the same fits does; the timed region below is still exactly K steps.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.clock_ramp_s:
+        model.fit(x, omega=omega)
     for _ in range(args.warmup):
         model.fit(x, omega=omega)
     sync_all()
@@ -304,7 +312,7 @@ def main():
                                      "matrix cores, fp32 accumulation (fp32-equivalent)") if args.gemm == "bf16x3"
                                     else "fp32 MFMA (v_mfma_f32_16x16x4_f32)",
                        "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU",
-                       "collective": collective},
+                       "collective": collective, "clock_ramp_s": args.clock_ramp_s},
             "roofline": roofline,
             "fit_roofline": fit_roofline(n, d, l, n_iter, 4, args.gemm, elapsed / args.steps * 1e3),
             # what went through the collective per fit (sharded runs; zeros on one GPU).  The stream time is sampled: one
@@ -362,6 +370,13 @@ def main():
         dist.destroy_process_group()
 
 
+def ramp(fn, seconds=0.25):
+    """untimed repetitions of fn for `seconds`: brings the GPU clocks back up after an idle (host-side) stretch"""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        fn()
+
+
 def collective_entry(st, acc, steps):
     calls, timed = int(st["allreduce_calls"]), int(acc["allreduce_timed"])
     avg = acc["allreduce_ms"] / timed if timed else 0.0
@@ -377,7 +392,7 @@ def strong_baseline(petal, torch, dev, cfg, n_total, d, k, n_iter, omega, gemm, 
     ctx1.set_gemm_mode(gemm)
     x = synth_pca_device(n_total, d, k, cfg["seed"], 0, n_total, dev)
     m = petal.RandomizedPca(k, ctx=ctx1, n_iter=n_iter)
-    m.fit(x, omega=omega)
+    ramp(lambda: m.fit(x, omega=omega), 0.2)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -485,8 +500,7 @@ def padded_pitch_extra(petal, ctx, torch, model, x, omega, steps=20, pad_elems=3
     buf = torch.empty((n, d + pad_elems), dtype=x.dtype, device=x.device)
     view = buf[:, :d]
     view.copy_(x)
-    for _ in range(3):
-        model.fit(view, omega=omega)
+    ramp(lambda: model.fit(view, omega=omega), 0.05)
     t0 = time.perf_counter()
     for _ in range(steps):
         model.fit(view, omega=omega)
@@ -538,7 +552,7 @@ def northstar(petal, ctx, torch, dev, n=1_000_000, d=512, l=74, reps=5):
         res[mode] = {}
         for name, fn, key in (("K1", lambda: petal.gemm_xp(x, p, mu, ctx=ctx), "xp"),
                               ("K2", lambda: petal.gemm_atb(x, z, mu, ctx=ctx), "atb")):
-            fn()
+            ramp(fn, 0.1)
             ms, cnt = 0.0, 0
             for _ in range(reps):
                 fn()
@@ -569,8 +583,7 @@ def northstar_fit(petal, ctx, torch, dev, gemm, n=1_000_000, d=512, k=64, reps=5
     res = {"shape": f"{n}x{d} fp32, k={k}", "gemm_mode": gemm}
     for n_iter in (5, 7):
         m = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter)
-        for _ in range(2):
-            m.fit(x, omega=omega)
+        ramp(lambda: m.fit(x, omega=omega), 0.1)
         torch.cuda.synchronize(dev)
         acc = {"xp_ms": 0.0, "xp_launches": 0, "atb_ms": 0.0, "atb_launches": 0}
         t0 = time.perf_counter()
@@ -599,6 +612,9 @@ def bench_fastica(args, cfg, petal, ctx, torch, dist, dev, rank, world, collecti
     x = torch.from_numpy(synth_ica(n, d, nc, seed=8, dtype=np.float32, row_seed=None if world == 1 else 8 + 1000 * rank)).to(dev)
     w0 = np.random.default_rng(7).standard_normal((nc, nc)).astype(np.float32)
     m = petal.FastIca(ctx=ctx, n_components=nc)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.clock_ramp_s:   # (clock ramp: see main)
+        m.fit(x, w_init=w0)
     for _ in range(args.warmup):
         m.fit(x, w_init=w0)
     sync_all()
@@ -643,11 +659,12 @@ def pca_cfg1(petal, ctx, torch, dev):
         t_w = time.perf_counter()   # (the host-side data generation above idles the GPU: a quarter of a second of fits lets its clocks
         while time.perf_counter() - t_w < 0.25:   #  ramp up again -- five 1-ms fits did not, and the timed ones then ran 2-5 x slow)
             m.fit(x)
-        t0 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
+        times = []
+        for _ in range(20):
+            t0 = time.perf_counter()
             m.fit(x)
-        res[name] = {"fit_ms": round((time.perf_counter() - t0) / reps * 1e3, 4)}
+            times.append(time.perf_counter() - t0)
+        res[name] = {"fit_ms": round(float(np.median(times)) * 1e3, 4), "fit_mean_ms": round(float(np.mean(times)) * 1e3, 4)}
     return res
 
 
@@ -658,17 +675,18 @@ def fastica_cfg3(petal, ctx, torch, dev, n=200000, d=256, nc=32):
     x = torch.from_numpy(synth_ica(n, d, nc, seed=5, dtype=np.float32)).to(dev)
     w0 = np.random.default_rng(7).standard_normal((nc, nc)).astype(np.float32)
     m = petal.FastIca(ctx=ctx, n_components=nc)
-    for _ in range(10):  # the host-side data generation above idles the GPU: let its clocks ramp up again
-        m.fit(x, w_init=w0)
-    t0 = time.perf_counter()
+    ramp(lambda: m.fit(x, w_init=w0), 0.25)  # the host-side data generation above idles the GPU: let its clocks ramp up again
     reps = 10
-    step_sum, step_cnt = 0.0, 0
+    step_sum, step_cnt, times = 0.0, 0, []
     for _ in range(reps):
-        m.fit(x, w_init=w0)
+        t0 = time.perf_counter()
+        m.fit(x, w_init=w0)        # (returns after its own synchronisation)
+        times.append(time.perf_counter() - t0)
         st = ctx.stats()   # (level-1 profiling samples one launch per fit, the kind rotating: accumulate over the fits)
         step_sum += st["ica_step_ms"]
         step_cnt += st["ica_step_launches"]
-    fit_ms = (time.perf_counter() - t0) / reps * 1e3
+    fit_ms = float(np.median(times)) * 1e3   # (median: one host hiccup in ten fits would otherwise own the mean)
+    fit_mean_ms = float(np.mean(times)) * 1e3
     step_ms = step_sum / max(step_cnt, 1)
     m200 = petal.FastIca(ctx=ctx, n_components=nc, tol=0.0, max_iter=200)
     m200.fit(x, w_init=w0)
@@ -687,7 +705,7 @@ def fastica_cfg3(petal, ctx, torch, dev, n=200000, d=256, nc=32):
     for _ in range(reps):
         petal.ica_par(x1t.T, 1e-4, 200, w0, ctx=ctx)
     loop_ms = (time.perf_counter() - t0) / reps * 1e3
-    return {"shape": f"{n}x{d} fp32, n_components={nc}", "fit_ms": round(fit_ms, 3), "n_iter": m.n_iter,
+    return {"shape": f"{n}x{d} fp32, n_components={nc}", "fit_ms": round(fit_ms, 3), "fit_mean_ms": round(fit_mean_ms, 3), "n_iter": m.n_iter,
             "loop_only_on_whitened_ms": round(loop_ms, 3), "loop_only_n_iter": int(it_loop),
             "samples_per_s": round(n / (fit_ms * 1e-3), 1),
             "fit_fixed_200_iter_ms": round(fit200_ms, 3), "ms_per_iteration": round((fit200_ms - fit_ms) / max(200 - m.n_iter, 1), 4),

@@ -88,7 +88,7 @@ void op_colsum(Dev*, int dt, const void* X, int64_t n, int64_t d, int64_t ldx, d
         }
 }
 void op_gemm_xp(Dev*, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P,
-                int64_t N, int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq) {
+                int64_t N, int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, int) {
     std::vector<double> row(K), acc(N);
     double ss = 0;
     for (int64_t i = 0; i < n; ++i) {

@@ -550,7 +550,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     if (robust) dev_memset(c.dev, tvp, 0, sizeof(double) * (2 + LP));  // tv, ndead, lam (only lam[0 .. L) is written below); the first run's were cleared with Omega
     // Z = Xc . Omega (pca.rs:707); total_variance = sum Xc^2 (pca.rs:533) is fused into this product unless tv_from_sq
     dev_set_tag(c.dev, TAG_XP);
-    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv_from_sq ? nullptr : tvp);
+    // (with power iterations behind it the sketch matrix may be ANY matrix: the optimistic run lets the kernel round Omega to two
+    // bf16 planes -- five piece products; n_iter = 0 and the robust redo keep Omega as given)
+    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv_from_sq ? nullptr : tvp, (n_iter > 0 && !robust) ? 2 : 3);
     dev_set_tag(c.dev, TAG_NONE);
 
     double* Pcur = P.f64();  // the orthonormal basis the current Z was formed with

@@ -4850,10 +4850,11 @@ static void launch_xp(Dev* d, const float* X, int64_t n, int K, int64_t ldx, con
 struct AbsmaxReq { int64_t cols, row_offset; double *absmax, *idx, *sign; };
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
-                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am = nullptr);
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am = nullptr,
+                         bool p2_hint = false);
 void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
-                int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq) {
-    gemm_xp_impl(d, dt, X, n, K, ldx, mu, P, N, ldp, bias, Z, ldz, sumsq, nullptr, 0, 0, nullptr, 0, false);
+                int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, int p_planes) {
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, P, N, ldp, bias, Z, ldz, sumsq, nullptr, 0, 0, nullptr, 0, false, nullptr, p_planes == 2);
 }
 void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* A, int64_t M,
                      int64_t lda, const double* T, int64_t N, int64_t ldt, double* P_out, int64_t ldpo, void* Z, int64_t ldz) {
@@ -4889,7 +4890,7 @@ void op_gemm_xp_prod_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K,
 }
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
-                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am) {
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am, bool p2_hint) {
     if (n == 0 || N == 0) return;
     const bool mfma = dt == F32 && K % 16 == 0 && K > 0 && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
                       K < (1 << 24) && N < (1 << 24) && N % 16 == 0 && ldz % 4 == 0 && aligned16(Z) && (!bias || aligned16(bias));
@@ -4960,7 +4961,7 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
         // two-plane P (five piece products) where P is the re-based iterate of a power iteration: k_trsm_pack rounds it so
         static const bool no_p2 = getenv("PETAL_NO_P2") != nullptr;
-        const bool p2 = prod_A && prod_rt && !am && !no_p2;
+        const bool p2 = ((prod_A && prod_rt) || (!prod_A && p2_hint)) && !am && !no_p2;
         if (prod_A) {
             // P = prod_A . P: the fp64 GEMM kernel writes the product (prod_out) AND its operand planes from its epilogue
             if (prod_rt)   // P is R in RT form: blocked triangular solve instead of the product with the explicit inverse

@@ -69,9 +69,11 @@ void op_colmean(Dev*, int dtype, const void* X, int64_t n, int64_t d, int64_t ld
 // Z[n x N] = (X[n x K] - mu) . P[K x N] * 1 + bias        (mu, bias nullable; mu/bias in dtype)
 // P is an f64 small matrix (ldp).  sumsq (nullable, fp64 scalar): += sum_ij (X_ij - mu_j)^2.
 // colscale (nullable, f64[N]): Z[:, j] *= colscale[j].
+// p_planes = 2: the caller accepts P rounded to the sum of its two leading bf16 pieces (a random sketch matrix: any matrix
+// serves) -- the split-product kernel then forms five piece products instead of six; other paths ignore it.
 void op_gemm_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
                 const double* P, int64_t N, int64_t ldp, const void* bias,
-                void* Z, int64_t ldz, double* sumsq);
+                void* Z, int64_t ldz, double* sumsq, int p_planes = 3);
 // op_gemm_xp with P = A . T formed on the fly (A: K x M, lda; T: M x N, ldt; both fp64 small matrices): the re-basing
 // product Y = Yp T of the power iteration goes straight into the GEMM kernel's operand planes instead of through a GEMM
 // launch of its own.  P_out (nullable, K x N fp64, ldpo) also receives the product.
