@@ -48,6 +48,10 @@ void dev_set_gemm_mode(Dev*, int) {}
 int dev_gemm_mode(const Dev*) { return 1; }
 void dev_reset_timing(Dev*) {}
 void dev_set_tag(Dev* d, int tag) { d->tag = tag; }
+void dev_fork(Dev*, bool) {}
+void dev_fork_end(Dev*) {}
+void dev_join(Dev*) {}
+void dev_fork_abort(Dev*) {}
 KernelTiming dev_timing(Dev*) { return KernelTiming{}; }
 void* dev_span_begin(Dev*, int) { return nullptr; }
 void dev_span_end(Dev*, void*) {}

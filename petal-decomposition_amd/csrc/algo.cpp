@@ -521,16 +521,23 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // draw goes up through the pinned ring without a host wait and is widened on the device -- queued BEFORE the column-means
     // pass, whose 35 us then cover the host's copy into the ring and the launches that follow (queued behind it the device sat
     // idle for 20 us waiting for the host); sharded: rank 0's draw came back from the prologue's all-reduce, already fp64.
-    DBuf P(c.dev, sizeof(double) * dp * LP);
+    DBuf P;
+    // The column-means pass is queued FIRST: the device starts on it at once, and the host's copy of Omega into the pinned ring,
+    // its upload, widening and padding run beside it on the side stream (single rank); joined in front of the first product.
+    if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
+    column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq, sharded(c) && centering ? pro.sums : nullptr);
     if (sharded(c)) {
+        P = DBuf(c.dev, sizeof(double) * dp * LP);
         op_pad_to_f64(c.dev, F64, P.f64(), dp, LP, pro.draw, d, L, l_req, tvp, 2 + LP);
     } else {
+        dev_fork(c.dev, false);   // (needs nothing from the means pass: starts at once)
+        P = DBuf(c.dev, sizeof(double) * dp * LP);   // (allocated while forked: a block no main-stream kernel can still be using)
         DBuf raw(c.dev, esz * size_t(d) * l_req);
         dev_h2d_async(c.dev, raw.p, omega, raw.bytes);
         op_pad_to_f64(c.dev, dt, P.f64(), dp, LP, raw.p, d, L, l_req, tvp, 2 + LP);  // (also clears tv, ndead, lam for the first pipeline run)
+        dev_fork_end(c.dev);
     }
-    if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
-    column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq, sharded(c) && centering ? pro.sums : nullptr);
+    dev_join(c.dev);
     DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
     c.stats.pass_flops = 2.0 * double(n) * double(d) * double(l_req);
     c.stats.pass_bytes = double(esz) * (double(n) * d + double(n) * l_req + double(d) * l_req);
@@ -647,7 +654,11 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     if (!robust) op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, false, LP, std::max<int64_t>(k, 1), ndead);
     else op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, true, LP);  // (zero padding of Uh included)
     // rows of V^T: v_j = B^T u_j / sigma_j, sigma_j = sqrt(lam_j) (the host takes the same square roots of lam)
+    // (on the side stream: it only reads what is already there and nothing below reads its output -- it runs beside the product
+    // that forms U; the main stream waits for it in front of the results' copy)
+    dev_fork(c.dev);
     op_components_out(c.dev, dt, Bt.f64(), LP, Uh.f64(), LP, lam, dt == F32 ? 1e-7 : 1e-12, d, L, k, comp_dev.p);
+    dev_fork_end(c.dev);
 
     // U = Q Uh = Usrc (T Uh) (pca.rs:683) and svd_flip (pca.rs:684)
     // (only the k columns svd_flip signs and fit_transform returns: kp = k rounded up to whole 16-column tiles; the small
@@ -666,6 +677,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     double t_q = 0, t_s = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
+        dev_join(c.dev);
         if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip, true, attempt == 0 ? ndead : nullptr);
         dev_d2h(c.dev, hres.data(), tvp, sizeof(double) * hres.size());
         if (k > 0) dev_d2h(c.dev, components, comp_dev.p, esz * size_t(k) * d);
@@ -895,13 +907,23 @@ namespace {
 
 // ica_par (ica.rs:319-361) on a device-resident, sample-major X1T (n x ncp).  W (device f64 nc x nc)
 // holds w_init on entry and the result on exit.  Returns n_iter.
+// The decorrelation of w_init (ica.rs:329) does not depend on the data: fastica_fit runs it on the side stream under the whitening
+// (ica_prepare between dev_fork and dev_fork_end), ica_par right before its loop.  W: w_init in, the decorrelated iterate out;
+// state: the loop's {converged at, iterations done} words, cleared by the same launch.
+struct IcaStart { DBuf W0, state; };
+IcaStart ica_prepare(petal_ctx& c, int64_t nc, DBuf& W, int mode) {
+    // (the caller's buffer holds w_init; the iterate lives in a buffer of this function's and the two are exchanged -- no copy)
+    IcaStart s{DBuf(c.dev, W.bytes), DBuf(c.dev, 2 * sizeof(int))};
+    std::swap(W, s.W0);
+    op_symdecorr(c.dev, nc, s.W0.f64(), W.f64(), mode, s.state.as<int>());
+    return s;
+}
 int64_t ica_loop(petal_ctx& c, int dt, const void* X1T, int64_t n, int64_t nc, int64_t ld, double n_total, DBuf& W,
-                 double tol, int64_t max_iter, int mode) {
-    // (the caller's buffer holds w_init; the iterate lives in a buffer of this function's and the two are exchanged at the end --
-    // no copy; the decorrelation launch also clears the loop state)
-    DBuf W0(c.dev, W.bytes), GX(c.dev, sizeof(double) * (nc * nc + nc)), state(c.dev, 2 * sizeof(int));
-    std::swap(W, W0);
-    op_symdecorr(c.dev, nc, W0.f64(), W.f64(), mode, state.as<int>());  // ica.rs:329
+                 double tol, int64_t max_iter, int mode, IcaStart* prepared = nullptr) {
+    IcaStart own;
+    if (!prepared) { own = ica_prepare(c, nc, W, mode); prepared = &own; }
+    DBuf& state = prepared->state;
+    DBuf GX(c.dev, sizeof(double) * (nc * nc + nc));
     int hstate[2] = {0, 0};
     auto enqueue = [&](int64_t it, int* progress) {
         dev_set_tag(c.dev, TAG_ICA);
@@ -1018,6 +1040,20 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         DBuf C(c.dev, sizeof(double) * dp * dp), U(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp), r3(c.dev, sizeof(double) * 3);
         op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
         allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
+        // w_init and its symmetric decorrelation (ica.rs:210-216, 329) need nothing from the data: they go to the side stream and run
+        // under the whitening (one workgroup, 40 us at 32 components, that the main chain used to wait for); queued BEHIND the
+        // Gram launch on the host side, so that the device is already busy while the host prepares them
+        dev_fork(c.dev, false);   // (nothing of the main stream's queue is needed: the prologue's draw was synchronised with)
+        DBuf W(c.dev, sizeof(double) * nc * nc);   // (allocated while forked: a block no main-stream kernel can still be using)
+        if (sharded(c)) {  // rank 0's draw, from the prologue's all-reduce
+            dev_d2d(c.dev, W.p, pro.draw, W.bytes);
+        } else {
+            std::vector<double> h(size_t(nc) * nc);
+            for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
+            dev_h2d_async(c.dev, W.p, h.data(), W.bytes);  // (staged through the pinned ring: no host wait)
+        }
+        IcaStart start = ica_prepare(c, nc, W, mode);
+        dev_fork_end(c.dev);
         DBuf Ckeep;  // (see pca_fit)
         if (dt == F64) { Ckeep = DBuf(c.dev, C.bytes); dev_d2d(c.dev, Ckeep.p, C.p, C.bytes); }
         const double vtol = dt == F32 ? 1e-12 : 3e-14;
@@ -1042,15 +1078,8 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         op_whiten_k(c.dev, U.f64(), dp, lam.f64(), dp, nc, ncp, std::sqrt(ri.n_total), KT.f64(), KTs.f64());
         op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, KTs.f64(), ncp, ncp, nullptr, X1T.p, ncp, nullptr);
 
-        DBuf W(c.dev, sizeof(double) * nc * nc);
-        if (sharded(c)) {  // rank 0's draw, from the prologue's all-reduce
-            dev_d2d(c.dev, W.p, pro.draw, W.bytes);
-        } else {
-            std::vector<double> h(size_t(nc) * nc);
-            for (int64_t i = 0; i < nc * nc; ++i) h[i] = get_elem(w_init, dt, i);
-            dev_h2d_async(c.dev, W.p, h.data(), W.bytes);  // (staged through the pinned ring: no host wait)
-        }
-        iters = ica_loop(c, dt, X1T.p, n, nc, ncp, ri.n_total, W, tol, max_iter, mode);  // ica.rs:216
+        dev_join(c.dev);   // the decorrelated w_init (side stream) meets the whitened data
+        iters = ica_loop(c, dt, X1T.p, n, nc, ncp, ri.n_total, W, tol, max_iter, mode, &start);  // ica.rs:216
 
         // components = W K (ica.rs:217); everything the host reads comes back behind ONE synchronisation
         DBuf Cm(c.dev, sizeof(double) * nc * dp);

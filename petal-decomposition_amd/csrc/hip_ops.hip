@@ -68,6 +68,11 @@ struct Dev {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // side stream for work that is independent of the main chain (dev_fork .. dev_fork_end .. dev_join)
+    hipStream_t side = nullptr, main_saved = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool forked = false, on_side = false;
+    std::vector<void*> deferred_free;   // blocks released while forked: back to the pool at the join
     int gemm_mode = [] { const char* e = getenv("PETAL_GEMM"); return (e && std::string(e) == "fp32") ? 1 : 0; }();
     // FastICA: W's bf16 planes for the split-product step kernel; the tail kernel refreshes them with the W it writes, so only
     // the first iteration of a fit runs the separate pack kernel
@@ -92,7 +97,11 @@ struct Dev {
     size_t pin_cap = 0, pin_used = 0;
     struct Pend { void* dst; size_t off, bytes; };
     std::vector<Pend> pend;
-    std::multimap<size_t, void*> free_list;
+    // free blocks by size.  `free_list` ("hot"): released since the last synchronisation of the main stream -- their last users may
+    // still be running there, which is fine for the main stream (stream order) and for a side stream that waits for it;
+    // `free_cold`: released before it -- safe for anyone, in particular for a side stream that starts at once.
+    std::multimap<size_t, void*> free_list, free_cold;
+    bool side_nowait = false;
     std::unordered_map<void*, size_t> live;
     std::vector<hipEvent_t> ev_pool;
     struct Rec { int tag; hipEvent_t a, b; };
@@ -138,11 +147,13 @@ void dev_destroy(Dev* d) {
     (void)hipSetDevice(d->device);
     (void)hipStreamSynchronize(d->stream);
     for (auto& kv : d->free_list) (void)hipFree(kv.second);
+    for (auto& kv : d->free_cold) (void)hipFree(kv.second);
     for (auto& kv : d->live) (void)hipFree(kv.first);
     for (auto& r : d->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : d->ev_pool) (void)hipEventDestroy(ev);
     if (d->pin) (void)hipHostFree(d->pin);
     if (d->progress) (void)hipHostFree(d->progress);
+    if (d->side) { (void)hipStreamSynchronize(d->side); (void)hipStreamDestroy(d->side); (void)hipEventDestroy(d->ev_fork); (void)hipEventDestroy(d->ev_join); }
     if (d->own_stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -170,17 +181,25 @@ void dev_pop_current(Dev* d, int prev) {
 
 void* dev_alloc(Dev* d, size_t bytes) {
     const size_t sz = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
-    auto it = d->free_list.find(sz);
     void* p = nullptr;
+    const bool cold_only = d->on_side && d->side_nowait;   // (a side stream that did not wait for the main stream's queue)
+    auto it = cold_only ? d->free_list.end() : d->free_list.find(sz);
+    auto ic = it == d->free_list.end() ? d->free_cold.find(sz) : d->free_cold.end();
     if (it != d->free_list.end()) {
         p = it->second;
         d->free_list.erase(it);
+    } else if (ic != d->free_cold.end()) {
+        p = ic->second;
+        d->free_cold.erase(ic);
     } else {
         hipError_t e = hipMalloc(&p, sz);
         if (e != hipSuccess) {  // drop the cache and retry once
             (void)hipStreamSynchronize(d->stream);
+            if (d->side) (void)hipStreamSynchronize(d->side);
             for (auto& kv : d->free_list) (void)hipFree(kv.second);
+            for (auto& kv : d->free_cold) (void)hipFree(kv.second);
             d->free_list.clear();
+            d->free_cold.clear();
             HIP_CHECK(hipMalloc(&p, sz));
         }
     }
@@ -196,9 +215,57 @@ void dev_free(Dev* d, void* p) {
     if (!p) return;
     auto it = d->live.find(p);
     if (it == d->live.end()) return;
+    if (d->forked) { d->deferred_free.push_back(p); return; }   // two streams in flight: no reuse before they have joined
     // stream-ordered reuse: every consumer of this block was enqueued on d->stream before this call
     d->free_list.emplace(it->second, p);
     d->live.erase(it);
+}
+// Fork / join of a side stream.  Between dev_fork() and dev_fork_end() every launch and copy goes to the side stream, which
+// starts behind everything the main stream holds at the fork; after dev_fork_end() work goes to the main stream again and the
+// two run concurrently until dev_join() makes the main stream wait for the side stream's last operation.  The pool is
+// stream-ordered for ONE stream, so no block released between fork and join is handed out again before the join.
+// after_main = false: the side work needs nothing the main stream still has queued (only buffers whose earlier users have been
+// synchronised with): it starts at once.
+void dev_fork(Dev* d, bool after_main) {
+    if (d->forked) throw std::logic_error("dev_fork: already forked");
+    if (!d->side) {
+        HIP_CHECK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+    }
+    if (after_main) {
+        HIP_CHECK(hipEventRecord(d->ev_fork, d->stream));
+        HIP_CHECK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+    }
+    d->main_saved = d->stream;
+    d->stream = d->side;
+    d->forked = true;
+    d->on_side = true;
+    d->side_nowait = !after_main;
+}
+void dev_fork_end(Dev* d) {
+    if (!d->on_side) return;
+    HIP_CHECK(hipEventRecord(d->ev_join, d->stream));
+    d->stream = d->main_saved;
+    d->on_side = false;
+}
+void dev_join(Dev* d) {
+    if (!d->forked) return;
+    dev_fork_end(d);
+    HIP_CHECK(hipStreamWaitEvent(d->stream, d->ev_join, 0));
+    d->forked = false;
+    for (void* p : d->deferred_free) dev_free(d, p);
+    d->deferred_free.clear();
+}
+// error path: leave the fork whatever state it is in (both streams drained, blocks back in the pool)
+void dev_fork_abort(Dev* d) {
+    if (!d->forked) return;
+    if (d->on_side) { d->stream = d->main_saved; d->on_side = false; }
+    (void)hipStreamSynchronize(d->side);
+    (void)hipStreamSynchronize(d->stream);
+    d->forked = false;
+    for (void* p : d->deferred_free) dev_free(d, p);
+    d->deferred_free.clear();
 }
 
 void dev_memset(Dev* d, void* p, int v, size_t bytes) { if (bytes) HIP_CHECK(hipMemsetAsync(p, v, bytes, d->stream)); }
@@ -244,6 +311,7 @@ void dev_h2d_async(Dev* d, void* dst, const void* src, size_t bytes) {
     const size_t need = (bytes + 63) / 64 * 64;
     if (d->pin_used + need > d->pin_cap) {
         HIP_CHECK(hipStreamSynchronize(d->stream));
+        if (d->forked) { HIP_CHECK(hipStreamSynchronize(d->side)); HIP_CHECK(hipStreamSynchronize(d->main_saved)); }
         drain_pending(d);
     }
     std::memcpy(d->pin + d->pin_used, src, bytes);
@@ -251,6 +319,7 @@ void dev_h2d_async(Dev* d, void* dst, const void* src, size_t bytes) {
     d->pin_used += need;
 }
 void dev_abort(Dev* d) {  // error path: the destinations of queued copies may be gone
+    dev_fork_abort(d);
     (void)hipStreamSynchronize(d->stream);
     d->pend.clear();
     d->pin_used = 0;
@@ -267,6 +336,10 @@ void dev_copy2d(Dev* d, void* dst, size_t dpitch, const void* src, size_t spitch
 void dev_sync(Dev* d) {
     HIP_CHECK(hipStreamSynchronize(d->stream));
     drain_pending(d);
+    if (!d->forked) {   // every block released so far has no user left anywhere
+        for (auto& kv : d->free_list) d->free_cold.emplace(kv.first, kv.second);
+        d->free_list.clear();
+    }
 }
 void dev_set_profiling(Dev* d, int level) { d->profiling = level; }
 void dev_set_gemm_mode(Dev* d, int mode) { d->gemm_mode = mode; }

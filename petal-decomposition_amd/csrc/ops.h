@@ -48,6 +48,13 @@ void  dev_pop_current(Dev*, int prev);      // ... which this restores: every AB
 void  dev_abort(Dev*);                     // error path: wait for the stream, drop queued device-to-host hand-overs
 void  dev_reset_timing(Dev*);
 void  dev_set_tag(Dev*, int tag);
+// side stream for work that does not depend on the main chain: launches between dev_fork and dev_fork_end go to it (behind
+// everything queued so far; at once with after_main = false), dev_join makes the main stream wait for it; dev_fork_abort is the
+// error path
+void  dev_fork(Dev*, bool after_main = true);
+void  dev_fork_end(Dev*);
+void  dev_join(Dev*);
+void  dev_fork_abort(Dev*);
 KernelTiming dev_timing(Dev*);            // resolves pending events (call after dev_sync)
 // Brackets stream work that is not one of this file's kernels (the collective) with the same event machinery as the tagged
 // kernels: begin returns a token (nullptr when this launch is not sampled), end records the closing event.
