@@ -20,6 +20,10 @@ struct petal_ctx {
     int profiling = 0;
     petal_stats stats{};
     void* rccl = nullptr;  // the built-in RCCL communicator (rccl.cpp), when petal_ctx_init_rccl installed it
+    // the fixed pseudo-random start block of the subspace iteration (topk_eigh), kept on the device per shape: generating it on the
+    // host and uploading it cost 20 us of idle device per exact Pca / FastICA fit
+    double* topk_seed = nullptr;
+    int64_t topk_seed_d = 0, topk_seed_dp = 0, topk_seed_p = 0;
 };
 
 namespace petal {

@@ -5671,6 +5671,44 @@ __global__ __launch_bounds__(256) void k_syrk_f64(const double* __restrict__ A, 
     }
 }
 
+// C = A B for small fp64 matrices whose shapes are whole 16 x 16 tiles (A: M x K, B: K x N, both row-major, not transposed): one
+// workgroup per output tile, its four waves take a quarter of K each on the fp64 matrix cores and add through LDS -- ONE launch
+// where the generic kernel needs a split-K launch and a reduce launch (the subspace iteration's C Q products: 256 x 256 x 48)
+// or walks K in 16-deep LDS stages (Yp T: 512 x 80 x 80).  Like k_syrk_f64 the kernel is load latency: a wave's operands of a
+// 64-deep batch are all requested before its 16 MFMAs.
+__global__ __launch_bounds__(256) void k_gemm_nn_f64(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+                                                     int64_t K, double* __restrict__ C, int64_t ldc, int ntn) {
+    __shared__ double red[3][4][64];
+    const int ti = blockIdx.x / ntn, tj = blockIdx.x - ti * ntn;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+    const int64_t kq = ((K + 3) / 4 + 3) / 4 * 4, kbeg = wave * kq, kend = min(K, kbeg + kq);
+    const double* pa = A + (int64_t)(16 * ti + i) * lda;     // A[row][k]
+    const double* pb = B + 16 * tj + i;                        // B[k][col]
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int64_t kb = kbeg; kb < kend; kb += 64) {
+        double a[16], b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int64_t k = kb + 4 * u + q;
+            const bool in = k < kend;
+            a[u] = in ? pa[k] : 0.0;
+            b[u] = in ? pb[k * ldb] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            C[(int64_t)(16 * ti + q + 4 * r) * ldc + 16 * tj + i] = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+    }
+}
+
 void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const double* colscale) {
     if (M == 0 || N == 0) return;
@@ -5680,6 +5718,13 @@ void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double 
             hipLaunchKernelGGL(k_syrk_f64<true>, dim3(nt * (nt + 1) / 2), dim3(256), 0, d->stream, A, lda, B, ldb, (int)M, K, C, ldc);
         else
             hipLaunchKernelGGL(k_syrk_f64<false>, dim3(nt * nt), dim3(256), 0, d->stream, A, lda, B, ldb, (int)M, K, C, ldc);
+        launch_check();
+        return;
+    }
+    static const bool no_nn = getenv("PETAL_NO_GEMM_NN") != nullptr;
+    if (!no_nn && !colscale && !ta && !tb && M % 16 == 0 && N % 16 == 0 && K >= 64 && K <= 4096 && alpha == 1.0 && beta == 0.0 &&
+        (M / 16) * (N / 16) <= 4096) {
+        hipLaunchKernelGGL(k_gemm_nn_f64, dim3((unsigned)((M / 16) * (N / 16))), dim3(256), 0, d->stream, A, lda, B, ldb, K, C, ldc, (int)(N / 16));
         launch_check();
         return;
     }
