@@ -290,7 +290,9 @@ def main():
         kinds = {"K1 (Z = Xc.P)": (acc["xp_ms"], acc["xp_launches"]),
                  "K2 (Y = Xc^T.Z)": (acc["atb_ms"], acc["atb_launches"])}
         per = {kname: (ms / max(cnt, 1)) for kname, (ms, cnt) in kinds.items()}
-        dom = max(kinds, key=lambda kname: kinds[kname][0])
+        # (both kinds run n_iter + 1 times per fit; level-1 profiling samples them alternately, so the SUMS over a few steps
+        # say which kind was sampled more often, not which is slower: the dominant kind is the one with the longer launch)
+        dom = max(per, key=per.get)
         roofline = roofline_entry(dom, per, pass_flops, pass_bytes, args.gemm, args.pmc_traffic, n, d, l)
         out = {
             "metric": "samples/sec for RandomizedPca.fit() on n x d fp32",
