@@ -404,9 +404,14 @@ void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_
     op_dgemm(d, false, false, K, N, M, 1.0, A, lda, T, ldt, 0.0, P, ldp);
     op_gemm_xp(d, dt, X, n, K, ldx, mu, P, N, ldp, nullptr, Z, ldz, nullptr);
 }
+void op_gemm_xp_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
+                       int64_t ldp, void* Z, int64_t ldz, int64_t row_offset, double* absmax, double* idx, double* sign, bool) {
+    op_gemm_xp(d, dt, X, n, K, ldx, mu, P, N, ldp, nullptr, Z, ldz, nullptr);
+    op_col_absmax(d, dt, Z, n, N, ldz, row_offset, absmax, idx, sign);
+}
 void op_gemm_xp_prod_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* A, int64_t M,
                             int64_t lda, const double* T, int64_t N, int64_t ldt, double* P_out, int64_t ldpo, void* Z, int64_t ldz,
-                            int64_t row_offset, double* absmax, double* idx, double* sign) {
+                            int64_t row_offset, double* absmax, double* idx, double* sign, bool) {
     op_gemm_xp_prod(d, dt, X, n, K, ldx, mu, A, M, lda, T, N, ldt, P_out, ldpo, Z, ldz);
     op_col_absmax(d, dt, Z, n, N, ldz, row_offset, absmax, idx, sign);
 }

@@ -669,7 +669,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // product T Uh is formed by the operand-packing kernel of the n x l product)
     if (slot_flip)   // ... and svd_flip's column scan by its epilogue
         op_gemm_xp_prod_absmax(c.dev, dt, Usrc, n, LP, LP, nullptr, T.f64(), LP, LP, Uh.f64(), kp, LP, M2.f64(), LP, Ubuf, LP,
-                               ri.row_offset, flip, flip + kp, flip + 2 * kp);
+                               ri.row_offset, flip, flip + kp, flip + 2 * kp, /*store_product=*/y_out != nullptr);
     else
         op_gemm_xp_prod(c.dev, dt, Usrc, n, LP, LP, nullptr, T.f64(), LP, LP, Uh.f64(), kp, LP, M2.f64(), LP, Ubuf, LP);
     Uout = Ubuf;
@@ -771,7 +771,7 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
 
     DBuf C(c.dev, sizeof(double) * dp * dp), V(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp);
     DBuf sig(c.dev, sizeof(double) * dp), inv(c.dev, sizeof(double) * dp), diag(c.dev, sizeof(double) * dp), r3(c.dev, sizeof(double) * 3);
-    DBuf compd(c.dev, esz * size_t(std::max<int64_t>(k, 1)) * d), U;
+    DBuf compd(c.dev, esz * size_t(std::max<int64_t>(k, 1)) * d), U, fslot;
     const bool slot_flip = !sharded(c) || dt == F32;  // (sharded fp64 decides the signs in three dependent all-reduce rounds)
     std::vector<double> hdiag(dp), hs(dp), hmu(dp), deferred, sg;
     int64_t r = 0, rp = 16;
@@ -821,9 +821,19 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     DBuf Pm(c.dev, sizeof(double) * dp * rp);
     op_scale_pad_cols(c.dev, V.f64(), dp, inv.f64(), dp, std::min(r, dp), rp, Pm.f64());
     U = DBuf(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * rp);
-    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Pm.f64(), rp, rp, nullptr, U.p, rp, nullptr);
-    if (slot_flip) flip_signs(c, dt, U.p, n, r, rp, ri.row_offset, &deferred);  // pca.rs:223 (decision data queued, decoded below)
-    else sg = flip_signs(c, dt, U.p, n, r, rp, ri.row_offset);
+    if (slot_flip) {
+        // pca.rs:223: svd_flip's scan comes out of the product kernel's accumulators (no second pass over U; U itself is only
+        // stored for fit_transform); decision data queued, decoded below
+        fslot = DBuf(c.dev, sizeof(double) * (4 * rp + 1));
+        op_gemm_xp_absmax(c.dev, dt, X.p, n, dp, X.ld, muT.p, Pm.f64(), rp, rp, U.p, rp, ri.row_offset, fslot.f64(), fslot.f64() + rp,
+                          fslot.f64() + 2 * rp, /*store_product=*/y_out != nullptr);
+        flip_signs_to_slot(c, dt, U.p, n, rp, rp, ri.row_offset, fslot.f64(), true);
+        deferred.assign(size_t(4 * rp), 0.0);
+        dev_d2h(c.dev, deferred.data(), fslot.p, sizeof(double) * 4 * rp);
+    } else {
+        op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Pm.f64(), rp, rp, nullptr, U.p, rp, nullptr);
+        sg = flip_signs(c, dt, U.p, n, r, rp, ri.row_offset);
+    }
     op_transpose_out(c.dev, dt, V.f64(), dp, d, k, compd.p);
 
     double h3[3] = {0, 1, 0};
@@ -836,7 +846,9 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     return !(partial && optimistic) || topk_verdict_ok(h3, vtol);
     };  // pipeline
     pipeline(false);
-    if (slot_flip) sg = signs_from_triple(deferred, r);
+    if (slot_flip)   // (sharded fp32: the all-reduced keys behind the triple; else the triple itself)
+        sg = flip_slot_keys(c, dt) ? signs_from_triple(std::vector<double>(deferred.begin() + 3 * rp, deferred.begin() + 4 * rp), rp)
+                                   : signs_from_triple(std::vector<double>(deferred.begin(), deferred.begin() + 3 * rp), rp);
     double tvar = 0;
     for (int64_t j = 0; j < d; ++j) tvar += hdiag[j];
     for (int64_t j = 0; j < k; ++j) {   // svd_flip's sign on row j of the components (already in place)

@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             const int64_t row = row0 + 16 * t + i;
-            if (row < n) *reinterpret_cast<f32x4*>(Z + row * ldz + col) = acc[t][u] + bv;
+            if (Z && row < n) *reinterpret_cast<f32x4*>(Z + row * ldz + col) = acc[t][u] + bv;   // (Z == nullptr: only the scan below is wanted)
         }
     }
     if (amax) {
@@ -4827,12 +4827,9 @@ void op_unpack_strided(Dev* d, int dt, const void* src, int64_t n, int64_t dd, i
     launch_check();
 }
 
-void op_colsum(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx, double* out, bool with_sq) {
-    if (dd == 0) return;
-    const int64_t w = with_sq ? 2 * dd : dd;
-    if (n == 0) { dev_memset(d, out, 0, sizeof(double) * w); return; }
-    const int64_t rows = scan_rows_per_block(n), nparts = cdiv(n, rows);
-    double* part = (double*)dev_alloc(d, sizeof(double) * nparts * w);
+// first stage of the column sums (a 16-byte-per-lane form measured the same: EXPERIMENTS.md round 4)
+static void launch_colsum_parts(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx, int64_t rows, int64_t nparts,
+                                double* part, bool with_sq) {
     const dim3 grid((unsigned)nparts, cdiv(dd, 64));
     if (with_sq) {
         DISPATCH_T(dt, hipLaunchKernelGGL((k_colsum_part2<T, true>), grid, dim3(256), 0, d->stream, (const T*)X, n, dd, ldx, rows, part));
@@ -4840,6 +4837,14 @@ void op_colsum(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx
         DISPATCH_T(dt, hipLaunchKernelGGL((k_colsum_part2<T, false>), grid, dim3(256), 0, d->stream, (const T*)X, n, dd, ldx, rows, part));
     }
     launch_check();
+}
+void op_colsum(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx, double* out, bool with_sq) {
+    if (dd == 0) return;
+    const int64_t w = with_sq ? 2 * dd : dd;
+    if (n == 0) { dev_memset(d, out, 0, sizeof(double) * w); return; }
+    const int64_t rows = scan_rows_per_block(n), nparts = cdiv(n, rows);
+    double* part = (double*)dev_alloc(d, sizeof(double) * nparts * w);
+    launch_colsum_parts(d, dt, X, n, dd, ldx, rows, nparts, part, with_sq);
     hipLaunchKernelGGL(k_sum_parts2<double>, dim3(cdiv(w, 32)), dim3(256), 0, d->stream, part, nparts, w, out, w, w, false);
     launch_check();
     dev_free(d, part);
@@ -4851,13 +4856,7 @@ void op_colmean(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ld
     if (n == 0) { dev_memset(d, mu64, 0, sizeof(double) * w); dev_memset(d, muT, 0, dtype_size(dt) * dd); return; }
     const int64_t rows = scan_rows_per_block(n), nparts = cdiv(n, rows);
     double* part = (double*)dev_alloc(d, sizeof(double) * nparts * w);
-    const dim3 grid((unsigned)nparts, cdiv(dd, 64));
-    if (with_sq) {
-        DISPATCH_T(dt, hipLaunchKernelGGL((k_colsum_part2<T, true>), grid, dim3(256), 0, d->stream, (const T*)X, n, dd, ldx, rows, part));
-    } else {
-        DISPATCH_T(dt, hipLaunchKernelGGL((k_colsum_part2<T, false>), grid, dim3(256), 0, d->stream, (const T*)X, n, dd, ldx, rows, part));
-    }
-    launch_check();
+    launch_colsum_parts(d, dt, X, n, dd, ldx, rows, nparts, part, with_sq);
     DISPATCH_T(dt, hipLaunchKernelGGL(k_colmean_final<T>, dim3(cdiv(w, 8)), dim3(256), 0, d->stream, part, nparts, w, dd, 1.0 / n_total, mu64, (T*)muT));
     launch_check();
     dev_free(d, part);
@@ -4949,7 +4948,7 @@ void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_
 }
 void op_gemm_xp_prod_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* A, int64_t M,
                             int64_t lda, const double* T, int64_t N, int64_t ldt, double* P_out, int64_t ldpo, void* Z, int64_t ldz,
-                            int64_t row_offset, double* absmax, double* idx, double* sign) {
+                            int64_t row_offset, double* absmax, double* idx, double* sign, bool store_product) {
     const bool fused = dt == F32 && gemm_split_product(d) && n >= 64 && K % 16 == 0 && K > 0 && N % 16 == 0 && N > 0 && ldx % 4 == 0 &&
                        aligned16(X) && (!mu || aligned16(mu)) && ldz % 4 == 0 && aligned16(Z) && K < (1 << 24) && N < (1 << 24) &&
                        n < (int64_t(1) << 31) && P_out != nullptr;
@@ -4959,7 +4958,24 @@ void op_gemm_xp_prod_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K,
         return;
     }
     const AbsmaxReq am{N, row_offset, absmax, idx, sign};
-    gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, N, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, false, &am);
+    // (store_product = false: the caller only wants svd_flip's scan -- the product stays in the accumulators, 26 MB less to write at
+    // configs[1])
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, N, ldt, nullptr, store_product ? Z : nullptr, ldz, nullptr, A, M, lda, P_out, ldpo, false, &am);
+}
+// Z = (X - mu) P with svd_flip's column scan (first row of largest |z| per column, its sign) taken from the product kernel's
+// accumulators where that kernel runs -- no second pass over Z, and no store of Z at all when store_product is false.
+void op_gemm_xp_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
+                       int64_t ldp, void* Z, int64_t ldz, int64_t row_offset, double* absmax, double* idx, double* sign, bool store_product) {
+    const bool fused = dt == F32 && gemm_split_product(d) && n >= 64 && K % 16 == 0 && K > 0 && N % 16 == 0 && N > 0 && ldx % 4 == 0 &&
+                       aligned16(X) && (!mu || aligned16(mu)) && ldz % 4 == 0 && aligned16(Z) && K < (1 << 24) && N < (1 << 24) &&
+                       n < (int64_t(1) << 31);
+    if (!fused) {
+        op_gemm_xp(d, dt, X, n, K, ldx, mu, P, N, ldp, nullptr, Z, ldz, nullptr);
+        op_col_absmax(d, dt, Z, n, N, ldz, row_offset, absmax, idx, sign);
+        return;
+    }
+    const AbsmaxReq am{N, row_offset, absmax, idx, sign};
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, P, N, ldp, nullptr, store_product ? Z : nullptr, ldz, nullptr, nullptr, 0, 0, nullptr, 0, false, &am);
 }
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,

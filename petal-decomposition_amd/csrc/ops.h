@@ -92,7 +92,12 @@ void op_gemm_xp_prod(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64
 void op_gemm_xp_prod_absmax(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
                             const double* A, int64_t M, int64_t lda, const double* T, int64_t N, int64_t ldt,
                             double* P_out, int64_t ldpo, void* Z, int64_t ldz,
-                            int64_t row_offset, double* absmax, double* idx, double* sign);
+                            int64_t row_offset, double* absmax, double* idx, double* sign, bool store_product = true);
+// (store_product = false: Z may be left unwritten where the scan comes out of the product kernel's accumulators)
+// op_gemm_xp with the same scan (absmax / idx / sign: N doubles each, as op_col_absmax delivers them over the leading N columns)
+void op_gemm_xp_absmax(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
+                       int64_t ldp, void* Z, int64_t ldz, int64_t row_offset, double* absmax, double* idx, double* sign,
+                       bool store_product = true);
 // One re-basing step of the power iteration: G (L x L, ldg) = R^T R, P_out (K x M fp64, ldpo) = A R^-1 (A: K x M, lda; columns
 // L .. M of the result are zero), Z = (X - mu) . P_out.  Same results contract as op_chol_inv(G -> T, Lz = M) followed by
 // op_gemm_xp_prod(A, T); T (M x M, ldt) is SCRATCH here -- it may hold R^-1 or a factored form of it, callers must not read it.
