@@ -593,6 +593,41 @@ def test_lds_dma_k1_variant_is_bit_identical():
     assert np.array_equal(z0, z1)
 
 
+def test_alternating_fits_on_one_ctx_match_a_fresh_ctx():
+    """RandomizedPca / FastIca / exact Pca fits alternating on ONE ctx with changing shapes: every result is bit-identical to the
+    same fit on a fresh ctx.  Exercises the side stream's fork / join (w_init's decorrelation under the Gram kernel, the components'
+    write-out beside the U product, Omega beside the means pass) and the pool's hot / cold free lists under block reuse."""
+    import torch
+    import petal_decomposition_amd as petal
+    from synth_data import synth_pca, synth_ica
+    rng = np.random.default_rng(5)
+    ctx = petal.Context(0)
+    for rep in range(15):
+        kind = rep % 3
+        n = int(rng.choice([4096, 20000, 50001])); d = int(rng.choice([64, 256, 512])); k = int(rng.choice([8, 16, 32]))
+        fresh = petal.Context(0)
+        if kind == 0:
+            x = torch.from_numpy(synth_pca(n, d, k, seed=rep, dtype=np.float32)).cuda()
+            om = rng.standard_normal((d, k + 10)).astype(np.float32)
+            a = petal.RandomizedPca(k, ctx=ctx, n_iter=4).fit(x, omega=om)
+            b = petal.RandomizedPca(k, ctx=fresh, n_iter=4).fit(x, omega=om)
+            same = np.array_equal(a.components(), b.components()) and np.array_equal(a.singular_values(), b.singular_values())
+        elif kind == 1:
+            x = torch.from_numpy(synth_ica(n, d, k, seed=rep, dtype=np.float32)).cuda()
+            w0 = rng.standard_normal((k, k)).astype(np.float32)
+            a = petal.FastIca(ctx=ctx, n_components=k).fit(x, w_init=w0)
+            b = petal.FastIca(ctx=fresh, n_components=k).fit(x, w_init=w0)
+            same = np.array_equal(a.components, b.components) and a.n_iter == b.n_iter
+        else:
+            x = torch.from_numpy(synth_pca(n, d, k, seed=rep, dtype=np.float32)).cuda()
+            a = petal.Pca(k, ctx=ctx).fit(x)
+            b = petal.Pca(k, ctx=fresh).fit(x)
+            same = np.array_equal(a.components(), b.components()) and np.array_equal(a.singular_values(), b.singular_values())
+        fresh.close()
+        assert same, (rep, kind, n, d, k)
+    ctx.close()
+
+
 def test_two_plane_iterate_against_the_three_plane_fit():
     """The re-based iterate of a power iteration is DEFINED as the sum of its two leading bf16 pieces (k_trsm_pack<NB, true>; the next
     K1 then needs five piece products, not six).  Any basis of range(Yp) serves the iteration, so the fit must agree with the
