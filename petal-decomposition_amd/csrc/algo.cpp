@@ -521,10 +521,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     double* const mu64 = res.f64() + o_mu;
     double* const flip = res.f64() + o_flip;
     DBuf muT;
-    // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64.  Single rank: the raw
-    // draw goes up through the pinned ring without a host wait and is widened on the device -- queued BEFORE the column-means
-    // pass, whose 35 us then cover the host's copy into the ring and the launches that follow (queued behind it the device sat
-    // idle for 20 us waiting for the host); sharded: rank 0's draw came back from the prologue's all-reduce, already fp64.
+    // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64.  Single rank: the raw draw
+    // goes up through the pinned ring without a host wait and is widened on the device; sharded: rank 0's draw came back from the
+    // prologue's all-reduce, already fp64.
     DBuf P;
     // The column-means pass is queued FIRST: the device starts on it at once, and the host's copy of Omega into the pinned ring,
     // its upload, widening and padding run beside it on the side stream (single rank); joined in front of the first product.
