@@ -16,7 +16,7 @@ for rep in range(200): m.fit(xd, omega=om)
 ws, cs = [], []
 for rep in range(20):
     t0 = time.perf_counter(); m.fit(xd, omega=om); dt = time.perf_counter() - t0
-    ws.append(dt * 1e6); cs.append(ctx.stats().fit_ms * 1e3)
+    ws.append(dt * 1e6); cs.append(ctx.stats()["fit_ms"] * 1e3)
 print(f"python wall median {np.median(ws):.1f} us, library fit_ms median {np.median(cs):.1f} us", flush=True)
 # pieces of the wrapper
 def tm(f, reps=200):

@@ -512,8 +512,10 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // and the components leave in their own k x d buffer, already in the caller's layout and type (op_components_out): 128 KB at
     // configs[1] instead of the 320 KB fp64 d x l matrix V, and nothing for the host to transpose.
     const int64_t o_tv = dp * LP, o_dead = o_tv + 1, o_lam = o_dead + 1, o_mu = o_lam + LP, o_flip = o_mu + 2 * dp, res_len = o_flip + 4 * LP + 1;  // (+ 1: the agreed redo verdict of a sharded fp32 fit)
-    DBuf comp_dev(c.dev, esz * size_t(std::max<int64_t>(k, 1)) * d);
-    DBuf res(c.dev, sizeof(double) * res_len);
+    // (the components sit right behind the block: both leave in one copy)
+    const size_t comp_bytes = esz * size_t(k) * d;
+    DBuf res(c.dev, sizeof(double) * res_len + std::max<size_t>(comp_bytes, 8));
+    void* const comp_dev = res.f64() + res_len;
     double* const Yp = res.f64();
     double* const tvp = res.f64() + o_tv;
     int* const ndead = reinterpret_cast<int*>(res.f64() + o_dead);
@@ -660,7 +662,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // (on the side stream: it only reads what is already there and nothing below reads its output -- it runs beside the product
     // that forms U; the main stream waits for it in front of the results' copy)
     dev_fork(c.dev);
-    op_components_out(c.dev, dt, Bt.f64(), LP, Uh.f64(), LP, lam, dt == F32 ? 1e-7 : 1e-12, d, L, k, comp_dev.p);
+    op_components_out(c.dev, dt, Bt.f64(), LP, Uh.f64(), LP, lam, dt == F32 ? 1e-7 : 1e-12, d, L, k, comp_dev);
     dev_fork_end(c.dev);
 
     // U = Q Uh = Usrc (T Uh) (pca.rs:683) and svd_flip (pca.rs:684)
@@ -674,50 +676,69 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     Uout = Ubuf;
     };  // pipeline
 
-    // results (pca.rs:543-547): one copy queued behind the pipeline, ONE synchronisation
-    std::vector<double> hres(size_t(res_len - o_tv)), sg;
+    // results (pca.rs:543-547): ONE small copy queued behind the pipeline, ONE synchronisation; the host reads it where it
+    // lands (the pinned ring) and writes the caller's arrays in one pass, svd_flip's sign applied on the way
+    const size_t hres_len = size_t(res_len - o_tv);
+    const double* hres = nullptr;
+    const void* hcomp = nullptr;
+    std::vector<double> sg, keep;
+    std::vector<char> comp_keep;
     static const bool host_tl = getenv("PETAL_HOST_TIMELINE") != nullptr;
     double t_q = 0, t_s = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
         dev_join(c.dev);
         if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip, true, attempt == 0 ? ndead : nullptr);
-        dev_d2h(c.dev, hres.data(), tvp, sizeof(double) * hres.size());
-        if (k > 0) dev_d2h(c.dev, components, comp_dev.p, esz * size_t(k) * d);
+        hres = static_cast<const double*>(dev_d2h_view(c.dev, tvp, sizeof(double) * hres_len + comp_bytes));
+        hcomp = hres + hres_len;
         t_q = timer.ms();
         dev_sync(c.dev);
         t_s = timer.ms();
+        // (the sharded fp64 path queues more copies through the ring below -- agree_any(), flip_signs(): it takes everything out
+        // first; the small block is copied on every path)
+        keep.assign(hres, hres + hres_len);
+        if (sharded(c) && !flip_slot_keys(c, dt)) {
+            comp_keep.assign(static_cast<const char*>(hcomp), static_cast<const char*>(hcomp) + comp_bytes);
+            hcomp = comp_keep.data();
+        }
         if (attempt == 1) break;
         int hdead = 0;
-        std::memcpy(&hdead, &hres[o_dead - o_tv], sizeof(int));
+        std::memcpy(&hdead, &keep[o_dead - o_tv], sizeof(int));
         bool redo = hdead != 0;
-        if (sharded(c)) redo = flip_slot_keys(c, dt) ? hres[o_flip - o_tv + 4 * kp] != 0.0 : agree_any(c, redo);  // the agreed verdict
+        if (sharded(c)) redo = flip_slot_keys(c, dt) ? keep[o_flip - o_tv + 4 * kp] != 0.0 : agree_any(c, redo);  // the agreed verdict
         if (!redo) break;
     }
     if (slot_flip) {
-        const double* hf = &hres[o_flip - o_tv];
+        const double* hf = &keep[o_flip - o_tv];
         sg = flip_slot_keys(c, dt) ? signs_from_triple(std::vector<double>(hf + 3 * kp, hf + 4 * kp), kp)
                                    : signs_from_triple(std::vector<double>(hf, hf + 3 * kp), kp);
-    } else {
-        sg = flip_signs(c, dt, Uout, n, kp, LP, ri.row_offset);
     }
-    const double* hlam = &hres[o_lam - o_tv];
+    if (!slot_flip) sg = flip_signs(c, dt, Uout, n, kp, LP, ri.row_offset);   // (sharded fp64: three more dependent rounds)
+    const double* hlam = &keep[o_lam - o_tv];
     std::vector<double> hs(size_t(std::max<int64_t>(k, 1)), 0.0);
     for (int64_t j = 0; j < k; ++j) hs[j] = std::sqrt(std::max(hlam[j], 0.0));
-    const double* hmu = &hres[o_mu - o_tv];
-    double htv = hres[0];
+    const double* hmu = &keep[o_mu - o_tv];
+    double htv = keep[0];
     if (tv_from_sq) {  // sum (x - mu)^2 = sum x^2 - n mu^2 per column, in fp64
         htv = 0;
         for (int64_t j = 0; j < d; ++j) htv += std::max(0.0, hmu[dp + j] - ri.n_total * hmu[j] * hmu[j]);
     }
-    for (int64_t j = 0; j < k; ++j) {   // svd_flip's sign on row j of the components (already in place, pca.rs:684)
-        if (sg[j] < 0) {
-            if (dt == F32) { float* r = static_cast<float*>(components) + j * d; for (int64_t i = 0; i < d; ++i) r[i] = -r[i]; }
-            else { double* r = static_cast<double*>(components) + j * d; for (int64_t i = 0; i < d; ++i) r[i] = -r[i]; }
+    for (int64_t j = 0; j < k; ++j) {   // the components leave the ring with svd_flip's sign on row j (pca.rs:684)
+        if (dt == F32) {
+            const float* src = static_cast<const float*>(hcomp) + j * d;
+            float* r = static_cast<float*>(components) + j * d;
+            if (sg[j] < 0) for (int64_t i = 0; i < d; ++i) r[i] = -src[i];
+            else std::memcpy(r, src, sizeof(float) * size_t(d));
+        } else {
+            const double* src = static_cast<const double*>(hcomp) + j * d;
+            double* r = static_cast<double*>(components) + j * d;
+            if (sg[j] < 0) for (int64_t i = 0; i < d; ++i) r[i] = -src[i];
+            else std::memcpy(r, src, sizeof(double) * size_t(d));
         }
         put_elem(singular, dt, j, hs[j]);
     }
-    for (int64_t i = 0; i < d; ++i) put_elem(means, dt, i, hmu[i]);
+    if (dt == F32) { float* m = static_cast<float*>(means); for (int64_t i = 0; i < d; ++i) m[i] = float(hmu[i]); }
+    else std::memcpy(means, hmu, sizeof(double) * size_t(d));
     put_elem(total_variance, dt, 0, htv);
     if (y_out) {  // fit_transform: U[:, :k] * sigma (transform_with_u, pca.rs:758-779)
         std::vector<double> sc(LP, 0.0);
@@ -827,8 +848,7 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
         op_gemm_xp_absmax(c.dev, dt, X.p, n, dp, X.ld, muT.p, Pm.f64(), rp, rp, U.p, rp, ri.row_offset, fslot.f64(), fslot.f64() + rp,
                           fslot.f64() + 2 * rp, /*store_product=*/y_out != nullptr);
         flip_signs_to_slot(c, dt, U.p, n, rp, rp, ri.row_offset, fslot.f64(), true);
-        deferred.assign(size_t(4 * rp), 0.0);
-        dev_d2h(c.dev, deferred.data(), fslot.p, sizeof(double) * 4 * rp);
+        deferred.assign(size_t(4 * rp), 0.0);   // (leaves with the other results below)
     } else {
         op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, Pm.f64(), rp, rp, nullptr, U.p, rp, nullptr);
         sg = flip_signs(c, dt, U.p, n, r, rp, ri.row_offset);
@@ -836,11 +856,13 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     op_transpose_out(c.dev, dt, V.f64(), dp, d, k, compd.p);
 
     double h3[3] = {0, 1, 0};
-    dev_d2h(c.dev, hdiag.data(), diag.p, diag.bytes);
-    dev_d2h(c.dev, hs.data(), sig.p, sig.bytes);
-    dev_d2h(c.dev, hmu.data(), mu64.p, sizeof(double) * dp);
-    if (k > 0) dev_d2h(c.dev, components, compd.p, esz * size_t(k) * d);
-    if (partial && optimistic) dev_d2h(c.dev, h3, r3.p, sizeof(h3));
+    {   // every result in one launch
+        void* dsts[6] = {hdiag.data(), hs.data(), hmu.data(), components, h3, deferred.data()};
+        const void* srcs[6] = {diag.p, sig.p, mu64.p, compd.p, r3.p, fslot.p};
+        const size_t lens[6] = {diag.bytes, sig.bytes, sizeof(double) * size_t(dp), k > 0 ? esz * size_t(k) * d : 0,
+                                (partial && optimistic) ? sizeof(h3) : 0, slot_flip ? sizeof(double) * size_t(4 * rp) : 0};
+        dev_d2h_multi(c.dev, 6, dsts, srcs, lens);
+    }
     dev_sync(c.dev);
     return !(partial && optimistic) || topk_verdict_ok(h3, vtol);
     };  // pipeline
@@ -1100,9 +1122,12 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         DBuf Cm(c.dev, sizeof(double) * nc * dp);
         op_dgemm(c.dev, false, true, nc, dp, nc, 1.0, W.f64(), nc, KT.f64(), ncp, 0.0, Cm.f64(), dp);
         double h3[3] = {0, 1, 0};
-        dev_d2h(c.dev, hC.data(), Cm.p, Cm.bytes);
-        dev_d2h(c.dev, hmu.data(), mu64.p, sizeof(double) * dp);
-        if (topk && optimistic) dev_d2h(c.dev, h3, r3.p, sizeof(h3));
+        {
+            void* dsts[3] = {hC.data(), hmu.data(), h3};
+            const void* srcs[3] = {Cm.p, mu64.p, r3.p};
+            const size_t lens[3] = {Cm.bytes, sizeof(double) * size_t(dp), (topk && optimistic) ? sizeof(h3) : 0};
+            dev_d2h_multi(c.dev, 3, dsts, srcs, lens);
+        }
         dev_sync(c.dev);
         return !agree_any(c, (topk && optimistic) && !topk_verdict_ok(h3, vtol));   // every rank redoes, or none
     };

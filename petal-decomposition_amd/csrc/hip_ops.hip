@@ -94,6 +94,8 @@ struct Dev {
     // pinned staging for small device-to-host results: copies are queued back to back on the stream and handed to the
     // caller's (pageable) buffers at the next dev_sync, instead of one blocking staged copy each
     char* pin = nullptr;
+    char* pin_dev = nullptr;         // the ring's address as the device sees it
+    bool d2h_kernel = getenv("PETAL_D2H_MEMCPY") == nullptr;   // small results leave through a copy kernel (default) or hipMemcpyAsync
     size_t pin_cap = 0, pin_used = 0;
     struct Pend { void* dst; size_t off, bytes; };
     std::vector<Pend> pend;
@@ -280,43 +282,122 @@ static void drain_pending(Dev* d) {
     d->pin_used = 0;
 }
 constexpr size_t PIN_MAX_COPY = size_t(8) << 20, PIN_RING = size_t(32) << 20;
+// Small results leave through a KERNEL that stores them straight into the pinned ring (device-visible host memory, posted writes over
+// the link) instead of hipMemcpyAsync: a device-to-host copy is a blit kernel of 3-4 us behind a 6-12 us gap of runtime work (two
+// of them close every RandomizedPca fit, four every Pca fit: profiles/r04_timeline_*), this one starts like any other launch.
+template <class V>
+__global__ __launch_bounds__(256) void k_copy_out(const V* __restrict__ src, V* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+static void ensure_pin(Dev* d) {
+    if (d->pin) return;
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->pin), PIN_RING, hipHostMallocDefault));
+    d->pin_cap = PIN_RING;
+    void* dp = nullptr;   // (the same address on this platform; asked for rather than assumed)
+    d->pin_dev = (hipHostGetDevicePointer(&dp, d->pin, 0) == hipSuccess && dp) ? static_cast<char*>(dp) : nullptr;
+}
+static void copy_to_pin(Dev* d, size_t off, const void* src, size_t bytes) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(src);
+    if (!d->d2h_kernel || !d->pin_dev || (bytes & 3) || (a & 3)) {
+        HIP_CHECK(hipMemcpyAsync(d->pin + off, src, bytes, hipMemcpyDeviceToHost, d->stream));
+        return;
+    }
+    char* dst = d->pin_dev + off;   // (64-byte aligned slots)
+    if (!((bytes | a) & 15)) {
+        const size_t n = bytes / 16;
+        hipLaunchKernelGGL(k_copy_out<uint4>, dim3((unsigned)std::min<size_t>(64, (n + 255) / 256)), dim3(256), 0, d->stream,
+                           static_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n);
+    } else if (!((bytes | a) & 7)) {
+        const size_t n = bytes / 8;
+        hipLaunchKernelGGL(k_copy_out<uint2>, dim3((unsigned)std::min<size_t>(64, (n + 255) / 256)), dim3(256), 0, d->stream,
+                           static_cast<const uint2*>(src), reinterpret_cast<uint2*>(dst), n);
+    } else {
+        const size_t n = bytes / 4;
+        hipLaunchKernelGGL(k_copy_out<unsigned>, dim3((unsigned)std::min<size_t>(64, (n + 255) / 256)), dim3(256), 0, d->stream,
+                           static_cast<const unsigned*>(src), reinterpret_cast<unsigned*>(dst), n);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+static void pin_make_room(Dev* d, size_t need) {
+    ensure_pin(d);
+    if (d->pin_used + need > d->pin_cap) {  // ring full: finish what is queued, hand it over, start again
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        if (d->forked) { HIP_CHECK(hipStreamSynchronize(d->side)); HIP_CHECK(hipStreamSynchronize(d->main_saved)); }
+        drain_pending(d);
+    }
+}
+static size_t pin_reserve(Dev* d, size_t bytes) {
+    const size_t need = (bytes + 63) / 64 * 64;
+    pin_make_room(d, need);
+    const size_t off = d->pin_used;
+    d->pin_used += need;
+    return off;
+}
 void dev_d2h(Dev* d, void* dst, const void* src, size_t bytes) {
     if (!bytes) return;
     if (bytes > PIN_MAX_COPY) {  // large results go straight to the caller's buffer
         HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
         return;
     }
-    if (!d->pin) {
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->pin), PIN_RING, hipHostMallocDefault));
-        d->pin_cap = PIN_RING;
+    const size_t off = pin_reserve(d, bytes);
+    copy_to_pin(d, off, src, bytes);
+    d->pend.push_back({dst, off, bytes});
+}
+// Several small results in ONE launch (a fit that ends with five separate copies pays five launches)
+struct CopySegs { const unsigned* src[8]; unsigned* dst[8]; unsigned n[8]; };
+__global__ __launch_bounds__(256) void k_copy_out_multi(CopySegs s) {
+    const int seg = blockIdx.y;
+    const unsigned* __restrict__ src = s.src[seg];
+    unsigned* __restrict__ dst = s.dst[seg];
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < s.n[seg]; i += gridDim.x * 256) dst[i] = src[i];
+}
+void dev_d2h_multi(Dev* d, int nseg, void* const* dst, const void* const* src, const size_t* bytes) {
+    ensure_pin(d);
+    bool ok = d->d2h_kernel && d->pin_dev && nseg <= 8;
+    size_t total = 0;
+    for (int i = 0; i < nseg; ++i) {
+        ok = ok && !(bytes[i] & 3) && !(reinterpret_cast<uintptr_t>(src[i]) & 3) && bytes[i] <= PIN_MAX_COPY;
+        total += (bytes[i] + 63) / 64 * 64;
     }
-    const size_t need = (bytes + 63) / 64 * 64;
-    if (d->pin_used + need > d->pin_cap) {  // ring full: finish what is queued, hand it over, start again
-        HIP_CHECK(hipStreamSynchronize(d->stream));
-        drain_pending(d);
+    if (!ok || total > PIN_MAX_COPY) {
+        for (int i = 0; i < nseg; ++i) dev_d2h(d, dst[i], src[i], bytes[i]);
+        return;
     }
-    HIP_CHECK(hipMemcpyAsync(d->pin + d->pin_used, src, bytes, hipMemcpyDeviceToHost, d->stream));
-    d->pend.push_back({dst, d->pin_used, bytes});
-    d->pin_used += need;
+    pin_make_room(d, total);   // (all segments in one stretch of the ring)
+    CopySegs cs{};
+    int m = 0;
+    unsigned nmax = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (!bytes[i]) continue;
+        const size_t off = pin_reserve(d, bytes[i]);
+        cs.src[m] = static_cast<const unsigned*>(src[i]);
+        cs.dst[m] = reinterpret_cast<unsigned*>(d->pin_dev + off);
+        cs.n[m] = (unsigned)(bytes[i] / 4);
+        nmax = std::max(nmax, cs.n[m]);
+        d->pend.push_back({dst[i], off, bytes[i]});
+        ++m;
+    }
+    if (!m) return;
+    hipLaunchKernelGGL(k_copy_out_multi, dim3(std::min<unsigned>(32, (nmax + 255) / 256), m), dim3(256), 0, d->stream, cs);
+    HIP_CHECK(hipGetLastError());
+}
+// The same without a destination: the caller reads the result IN the pinned ring after its dev_sync (valid until the next copy is
+// queued on this Dev) -- no hand-over copy, and a caller that has to transform the data on its way out does it in one pass.
+const void* dev_d2h_view(Dev* d, const void* src, size_t bytes) {
+    if (!bytes) return nullptr;
+    if (bytes > PIN_MAX_COPY) throw std::logic_error("dev_d2h_view: larger than a ring slot");
+    const size_t off = pin_reserve(d, bytes);
+    copy_to_pin(d, off, src, bytes);
+    return d->pin + off;
 }
 // Host-to-device without blocking the host: the bytes are copied into the pinned ring now (so the caller's buffer may be
 // a short-lived pageable one) and the transfer is queued on the stream; the slot is recycled at the next dev_sync.
 void dev_h2d_async(Dev* d, void* dst, const void* src, size_t bytes) {
     if (!bytes) return;
     if (bytes > PIN_MAX_COPY) { dev_h2d(d, dst, src, bytes); return; }
-    if (!d->pin) {
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->pin), PIN_RING, hipHostMallocDefault));
-        d->pin_cap = PIN_RING;
-    }
-    const size_t need = (bytes + 63) / 64 * 64;
-    if (d->pin_used + need > d->pin_cap) {
-        HIP_CHECK(hipStreamSynchronize(d->stream));
-        if (d->forked) { HIP_CHECK(hipStreamSynchronize(d->side)); HIP_CHECK(hipStreamSynchronize(d->main_saved)); }
-        drain_pending(d);
-    }
-    std::memcpy(d->pin + d->pin_used, src, bytes);
-    HIP_CHECK(hipMemcpyAsync(dst, d->pin + d->pin_used, bytes, hipMemcpyHostToDevice, d->stream));
-    d->pin_used += need;
+    const size_t off = pin_reserve(d, bytes);
+    std::memcpy(d->pin + off, src, bytes);
+    HIP_CHECK(hipMemcpyAsync(dst, d->pin + off, bytes, hipMemcpyHostToDevice, d->stream));
 }
 void dev_abort(Dev* d) {  // error path: the destinations of queued copies may be gone
     dev_fork_abort(d);
