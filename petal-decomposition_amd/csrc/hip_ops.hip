@@ -3987,7 +3987,14 @@ __device__ __forceinline__ void tri_ladder(double* __restrict__ W, int ld, int L
     for (const int kend = min(L - 2, L - 1 - 8 * (T - STEP)); k < kend; ++k) tri_step<T>(W, ld, L, k, sv, sp, _t0);
     if constexpr (T - STEP > 0) tri_ladder<T - STEP, STEP>(W, ld, L, k, sv, sp, _t0);
 }
-__host__ __device__ constexpr int tri_ld(int L, int step) { return step == 1 ? L + 8 : ((L + 8 * step) | 1); }
+// row pitch of the working copy: at least L + PAD, and 8 or 24 (mod 32) doubles where the LDS has room -- the four rows that a
+// 32-lane half reads (8 lanes each, 8 consecutive doubles) then fall on four different quarters of the bank row (ds_read_b64
+// banks: (a / 4) mod 64); an odd pitch, the round-3 choice, leaves two of them overlapping: 85.4 -> 80.5 us at l = 74
+__host__ __device__ constexpr int tri_ld(int L, int step) {
+    const int lo = L + 8 * step, r = lo % 32;
+    const int v = r <= 8 ? lo + (8 - r) : (r <= 24 ? lo + (24 - r) : lo + (40 - r));
+    return (size_t)8 * ((size_t)L * v + 288) <= 160 * 1024 ? v : (step == 1 ? L + 8 : (lo | 1));
+}
 __host__ __device__ constexpr int tri_sp_len(int tmax) { return 8 * tmax; }
 template <int TMAX, int STEP>  // L <= 8 TMAX; PAD = 8 STEP zero columns
 __global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restrict__ A, int L, int64_t lda, double* __restrict__ dd,
@@ -4042,265 +4049,6 @@ __global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restr
             for (int c = kk + 1 + (tid & 7); c < L; c += 8) acc += W[c * ld + kk] * W[c * ld + kk - 1];
         acc = oct_sum_f64(acc);
         if ((tid & 7) == 0) gg[kk] = acc;
-    }
-}
-
-// ---- the same reduction with a LOOK-AHEAD (round 4).  Phase stamps of k_tridiag_r at l = 74: 42 % of a step is the chain that
-// turns row k into the reflector (LDS read -> squares -> 8-lane sum -> reciprocal square root and reciprocal with their Newton
-// steps -> scale), run by every wave while nothing else can.  Here lane `sub` owns the ABSOLUTE columns c = sub (mod 8), so its
-// slots mean the same columns in every step and the next row's entries -- row k + 1 after the rank-2 update -- are formed in
-// registers from values the lane already holds (the same two FMAs the update applies, bit for bit) as soon as w is known.  The
-// next reflector's chain then runs BESIDE the rank-2 update, on a wave of its own: the last wave forms reflector k + 1 while the
-// other seven update the trailing block (a first form that had every wave do both, in opposite orders on the two waves of a
-// SIMD, was slower than k_tridiag_r: a wave still ran chain + update back to back).  v, tau, beta live in two alternating LDS
-// buffers and every wave reads them at the top of a step; a reflector is parked in the dead part of the working copy one step
-// after it was formed.
-template <int TMAX>
-__device__ __forceinline__ void tri_la_reflector(double (&x)[TMAX], int a0, double alpha, int kk, int sub, int off, double& tk_out,
-                                                 double& beta_out) {
-    // in: x[a] = entry of row kk at column c(a) = sub + 8 a - off (junk where c <= kk + 1); out: v (1 at kk + 1, 0 below)
-    double sq0 = 0, sq1 = 0;
-#pragma unroll
-    for (int a = 0; a < TMAX; ++a) {
-        if (a < a0) continue;
-        const int c = sub + 8 * a - off;
-        const double xa = c > kk + 1 ? x[a] : 0.0;
-        x[a] = xa;
-        if (a & 1) sq1 = fma(xa, xa, sq1); else sq0 = fma(xa, xa, sq0);
-    }
-    const double sigma = oct_sum_f64(sq0 + sq1);
-    double beta = alpha, tk = 0.0, scale = 0.0;
-    if (sigma > 0.0) {                                            // (uniform: every thread holds the same bits)
-        const double n2 = fma(alpha, alpha, sigma);
-        double rs = __builtin_amdgcn_rsq(n2);
-        double rc = __builtin_amdgcn_rcp(fma(n2, rs, fabs(alpha)));   // ~ 1 / (|alpha| + ||x||), refined below
-        rs = rs * fma(-0.5 * n2 * rs, rs, 1.5);
-        rs = rs * fma(-0.5 * n2 * rs, rs, 1.5);
-        const double nrm = n2 * rs;
-        beta = -copysign(nrm, alpha);
-        const double den = fabs(alpha) + nrm;                     // |alpha - beta|
-        rc = fma(fma(-den, rc, 1.0), rc, rc);
-        rc = fma(fma(-den, rc, 1.0), rc, rc);
-        scale = copysign(rc, alpha);
-        tk = den * rs;                                            // (beta - alpha) / beta
-    }
-#pragma unroll
-    for (int a = 0; a < TMAX; ++a) {
-        if (a < a0) continue;
-        const int c = sub + 8 * a - off;
-        x[a] = c == kk + 1 ? 1.0 : x[a] * scale;
-    }
-    tk_out = tk;
-    beta_out = beta;
-}
-// reflector kk leaves its chain (the chain wave's first group): v, tau, beta and v_kk . v_{kk-1} to the LDS buffer of the next step
-template <int TMAX>
-__device__ __forceinline__ void tri_la_emit(const double (&v)[TMAX], const double (&vprev)[TMAX], int a0, int sub, bool writer, double tk,
-                                            double beta, double* __restrict__ sv) {
-    double acc = 0;
-#pragma unroll
-    for (int a = 0; a < TMAX; ++a)
-        if (a >= a0) acc = fma(v[a], vprev[a], acc);
-    acc = oct_sum_f64(acc);
-    if (writer) {
-#pragma unroll
-        for (int a = 0; a < TMAX; ++a) sv[sub + 8 * a] = a >= a0 ? v[a] : 0.0;
-        if (sub == 0) { sv[8 * TMAX] = tk; sv[8 * TMAX + 1] = beta; sv[8 * TMAX + 2] = acc; }
-    }
-}
-// ... and is PARKED one step later, when column kk and row kk of the working copy are dead (no global-memory traffic inside the
-// loop: a barrier waits for outstanding stores): v_c in W[c][kk], beta / tau / v_kk . v_{kk-1} in W[kk][kk+1 .. kk+3]
-template <int TMAX>
-__device__ __forceinline__ void tri_la_park(double* __restrict__ W, int ld, int L, const double (&v)[TMAX], int a0, int kk, int sub, int g,
-                                            int off, const double* __restrict__ sc) {
-    if (g == 8) {
-#pragma unroll
-        for (int a = 0; a < TMAX; ++a) {
-            const int c = sub + 8 * a - off;
-            if (a >= a0 && c > kk && c < L) W[c * ld + kk] = v[a];
-        }
-    } else if (g == 16 && sub == 0) {
-        double* r = W + kk * ld + kk;
-        r[1] = sc[1]; r[2] = sc[0]; r[3] = sc[2];
-    }
-}
-constexpr int TLA_UG = TRR_THREADS / 8 - 8;                       // row groups of the update: every wave but the last
-#ifdef PETAL_DEBUG_COUNTERS
-struct TlaStamps { long long t0, st[6]; };
-#define TLA_STAMP(i) do { const long long _t = clock64(); stamps.st[i] += _t - stamps.t0; stamps.t0 = _t; } while (0)
-#else
-struct TlaStamps {};
-#define TLA_STAMP(i) do {} while (0)
-#endif
-template <int TMAX, int T, int STEP>
-__device__ __forceinline__ void tri_la_step(double* __restrict__ W, int ld, int L, int off, int k, const double* __restrict__ sv_cur,
-                                            double* __restrict__ sv_nxt, double* __restrict__ sp, TlaStamps& stamps) {
-    constexpr int NG = TRR_THREADS / 8;
-    constexpr int RB = (8 * T + NG - 1) / NG, RBU = (8 * T + TLA_UG - 1) / TLA_UG;
-    constexpr int A0 = TMAX - T;
-    const int tid = threadIdx.x, g = tid >> 3, sub = tid & 7;
-    const bool chain_wave = g >= TLA_UG;
-    int cc[TMAX];                                                 // my columns (clamped for the address; phantom slots are dead)
-    double xv[TMAX];
-#pragma unroll
-    for (int a = A0; a < TMAX; ++a) { cc[a] = max(sub + 8 * a - off, 0); xv[a] = sv_cur[sub + 8 * a]; }
-    const double tk = sv_cur[8 * TMAX];
-    TLA_STAMP(0);
-    // ---- p = tau A22 v; the chain wave also takes row k + 1 as it stands (the look-ahead's input) ----
-    double nx[TMAX];
-    double a12 = 0;
-    if (chain_wave) {
-        const double* rk1 = W + (k + 1) * ld;
-#pragma unroll
-        for (int a = A0; a < TMAX; ++a) nx[a] = rk1[cc[a]];
-        a12 = rk1[k + 2];
-    }
-    tri_la_park<TMAX>(W, ld, L, xv, A0, k, sub, g, off, sv_cur + 8 * TMAX);   // reflector k: its column and row are dead now
-    {
-        double acc[RB][2];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int i = k + 1 + g + NG * r;
-            const double* row = W + min(i, L - 1) * ld;
-            acc[r][0] = 0; acc[r][1] = 0;
-#pragma unroll
-            for (int a = A0; a < TMAX; ++a) acc[r][a & 1] = fma(row[cc[a]], xv[a], acc[r][a & 1]);
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int i = k + 1 + g + NG * r;
-            const double s = oct_sum_f64(acc[r][0] + acc[r][1]);
-            if (sub == 0 && i < L) sp[i + off] = tk * s;
-        }
-    }
-    TLA_STAMP(1);
-    __syncthreads();
-    TLA_STAMP(2);
-    // ---- w = p + K v ----
-    double wj[TMAX];
-    double pv0 = 0, pv1 = 0;
-#pragma unroll
-    for (int a = A0; a < TMAX; ++a) {
-        const int c = sub + 8 * a - off;
-        const double pj = sp[sub + 8 * a];
-        wj[a] = (a >= A0 + STEP || c > k) ? pj : 0.0;           // (entries of p from rows that have left the trailing block are stale)
-        if (a & 1) pv1 = fma(wj[a], xv[a], pv1); else pv0 = fma(wj[a], xv[a], pv0);
-    }
-    const double K = -0.5 * tk * oct_sum_f64(pv0 + pv1);
-#pragma unroll
-    for (int a = A0; a < TMAX; ++a) wj[a] = fma(K, xv[a], wj[a]);
-    TLA_STAMP(3);
-    if (chain_wave) {
-        if (k + 3 < L) {                                          // (the last step has no successor)
-            const double p1 = sp[k + 1 + off], p2 = sp[k + 2 + off], v2 = sv_cur[k + 2 + off];
-            const double w0 = fma(K, 1.0, p1);                    // w at row k + 1 (v there is exactly 1)
-            // row k + 1 after the update, at my columns: the update's own two FMAs with v_{k+1} = 1
-#pragma unroll
-            for (int a = A0; a < TMAX; ++a) nx[a] = fma(-1.0, wj[a], fma(-w0, xv[a], nx[a]));
-            const double alpha_n = fma(-1.0, fma(K, v2, p2), fma(-w0, v2, a12));
-            double tk_n = 0, beta_n = 0;
-            tri_la_reflector<TMAX>(nx, A0, alpha_n, k + 1, sub, off, tk_n, beta_n);
-            tri_la_emit<TMAX>(nx, xv, A0, sub, g == TLA_UG, tk_n, beta_n, sv_nxt);
-        }
-    } else {                                                      // A22 -= v w^T + w v^T
-#pragma unroll
-        for (int r = 0; r < RBU; ++r) {
-            const int i = k + 1 + g + TLA_UG * r;
-            if (i < L) {
-                const double vi = sv_cur[i + off], wi = fma(K, vi, sp[i + off]);
-                double* row = W + i * ld;
-#pragma unroll
-                for (int a = A0; a < TMAX; ++a) {
-                    const int c = sub + 8 * a - off;
-                    const double nv = fma(-vi, wj[a], fma(-wi, xv[a], row[cc[a]]));
-                    if (a >= A0 + STEP || c > k) row[cc[a]] = nv;
-                }
-            }
-        }
-    }
-    TLA_STAMP(4);
-    __syncthreads();
-    TLA_STAMP(5);
-}
-template <int TMAX, int T, int STEP>
-__device__ __forceinline__ void tri_la_ladder(double* __restrict__ W, int ld, int L, int S, int off, int& k, double* __restrict__ sv,
-                                              double* __restrict__ sp, TlaStamps& stamps) {
-    // this rung while the leading live slot (k + 1) / 8 lies within its first STEP slots (slots S - T ...); skipped when S < T - STEP + 1
-    if (T - STEP <= 0 || S > T - STEP) {
-        const int kend = (T - STEP > 0) ? min(L - 2, 8 * (S - T + STEP) - 1) : L - 2;
-        for (; k < kend; ++k) {
-            double* cur = sv + (k & 1) * (8 * TMAX + 8);
-            double* nxt = sv + ((k + 1) & 1) * (8 * TMAX + 8);
-            tri_la_step<TMAX, T, STEP>(W, ld, L, off, k, cur, nxt, sp, stamps);
-        }
-    }
-    if constexpr (T - STEP > 0) tri_la_ladder<TMAX, T - STEP, STEP>(W, ld, L, S, off, k, sv, sp, stamps);
-}
-// row pitch: every slot of a row addressable (8 S); 8 or 24 (mod 32) doubles where the LDS has room -- the four rows that a
-// 32-lane half reads (8 lanes each, 8 consecutive doubles) then fall on four different quarters of the bank row -- else odd
-__host__ __device__ constexpr int tri_la_doubles(int tmax) { return 24 * tmax + 16; }
-__host__ __device__ inline int tri_la_ld(int L, int tmax) {
-    const int s8 = 8 * ((L + 7) / 8);
-    const int want = (s8 % 32 == 8 || s8 % 32 == 24) ? s8 : s8 + 8;
-    return sizeof(double) * ((size_t)L * want + tri_la_doubles(tmax)) <= 160 * 1024 ? want : (s8 | 1);
-}
-template <int TMAX, int STEP>  // L <= 8 TMAX
-__global__ __launch_bounds__(TRR_THREADS) void k_tridiag_la(const double* __restrict__ A, int L, int64_t lda, double* __restrict__ dd,
-                                                            double* __restrict__ ee, double* __restrict__ HV,
-                                                            double* __restrict__ tau, double* __restrict__ gg,
-                                                            int* __restrict__ flag, double* __restrict__ V, int64_t ldv, int Lz, int reset_flag) {
-    extern __shared__ __attribute__((aligned(16))) double sm_tri[];
-    const int tid = threadIdx.x, g = tid >> 3, sub = tid & 7;
-    const int S = (L + 7) >> 3, off = 8 * (TMAX - S);
-    const int ld = tri_la_ld(L, TMAX);
-    for (int e = tid; e < Lz * Lz; e += TRR_THREADS) {           // the caller's zero padding of V (rows / columns L .. Lz - 1)
-        const int r = e / Lz, c = e - r * Lz;
-        if (r >= L || c >= L) V[(int64_t)r * ldv + c] = 0.0;
-    }
-    double* W = sm_tri;
-    double* sv = W + (size_t)L * ld;                              // two buffers of 8 TMAX + 8 entries: v | tau, beta, v . v_prev
-    double* sp = sv + 2 * (8 * TMAX + 8);                         // 8 TMAX entries
-    for (int e0 = tid; e0 < L * ld; e0 += 8 * TRR_THREADS) {
-        double t8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * TRR_THREADS, r = e / ld, c = e - r * ld;
-            t8[u] = (e < L * ld && c < L) ? A[(int64_t)r * lda + c] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = e0 + u * TRR_THREADS; if (e < L * ld) W[e] = t8[u]; }
-    }
-    for (int e = tid; e < tri_la_doubles(TMAX); e += TRR_THREADS) sv[e] = 0.0;   // v buffers and p
-    if (tid == 0 && reset_flag) *flag = 0;   // (a caller-owned verdict word accumulates: it is not reset here)
-    __syncthreads();
-    if (g == 0) {                                                 // reflector 0 from row 0
-        double xv[TMAX], vz[TMAX];
-#pragma unroll
-        for (int a = 0; a < TMAX; ++a) { xv[a] = W[max(sub + 8 * a - off, 0)]; vz[a] = 0.0; }
-        double tk = 0, beta = 0;
-        tri_la_reflector<TMAX>(xv, 0, W[1], 0, sub, off, tk, beta);
-        tri_la_emit<TMAX>(xv, vz, 0, sub, true, tk, beta, sv);
-    }
-    __syncthreads();
-    int k = 0;
-    TlaStamps stamps{};
-#ifdef PETAL_DEBUG_COUNTERS
-    stamps.t0 = clock64();
-#endif
-    tri_la_ladder<TMAX, TMAX, STEP>(W, ld, L, S, off, k, sv, sp, stamps);
-#ifdef PETAL_DEBUG_COUNTERS
-    if (tid == 0) for (int i = 0; i < 6; ++i) g_cyc[i] += stamps.st[i];
-    if (tid == 8 * TLA_UG) for (int i = 0; i < 6; ++i) g_cyc[26 + i] += stamps.st[i];
-#endif
-    for (int e = tid; e < (L - 2) * L; e += TRR_THREADS) {       // reflector k: row k of HV, entries k + 1 .. L - 1
-        const int kk = e / L, c = e - kk * L;
-        HV[e] = c > kk ? W[c * ld + kk] : 0.0;
-    }
-    for (int kk = tid; kk < L; kk += TRR_THREADS) {
-        dd[kk] = W[kk * ld + kk];
-        ee[kk] = kk + 2 < L ? W[kk * ld + kk + 1] : (kk + 2 == L ? W[(L - 1) * ld + L - 2] : 0.0);
-        tau[kk] = kk + 2 < L ? W[kk * ld + kk + 2] : 0.0;
-        gg[kk] = (kk >= 1 && kk + 2 < L) ? W[kk * ld + kk + 3] : 0.0;
     }
 }
 
@@ -6236,21 +5984,10 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         set_max_lds(d, reinterpret_cast<const void*>(k_tridiag_r<TM, ST>));                                                        \
         hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag, V, ldv, (int)(pad_done ? 0 : Lz), (ext_verdict && !verdict_fresh) ? 0 : 1); \
     } while (0)
-#define PETAL_TRI_LA_LAUNCH(TM, ST)                                                                                                \
-    do {                                                                                                                           \
-        const size_t lds_r = sizeof(double) * ((size_t)L * tri_la_ld((int)L, TM) + tri_la_doubles(TM));                             \
-        set_max_lds(d, reinterpret_cast<const void*>(k_tridiag_la<TM, ST>));                                                       \
-        hipLaunchKernelGGL((k_tridiag_la<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag, V, ldv, (int)(pad_done ? 0 : Lz), (ext_verdict && !verdict_fresh) ? 0 : 1); \
-    } while (0)
-            static const bool tri_old = getenv("PETAL_TRIDIAG_OLD") != nullptr;
-            if (!tri_old) {
-                if (L <= 80) PETAL_TRI_LA_LAUNCH(10, 2);
-                else PETAL_TRI_LA_LAUNCH(18, 2);
-            } else if (L <= 80) PETAL_TRI_LAUNCH(10, 2);
+            if (L <= 80) PETAL_TRI_LAUNCH(10, 2);
             else if (L <= 132) PETAL_TRI_LAUNCH(18, 2);
             else PETAL_TRI_LAUNCH(18, 1);
 #undef PETAL_TRI_LAUNCH
-#undef PETAL_TRI_LA_LAUNCH
             launch_check();
             const int hv_rows = (int)std::min<int64_t>(L - 2, (96 * 1024) / (8 * L));
             const size_t lds_e = sizeof(double) * (23 * (((L + 7) & ~7) + 8) + (size_t)hv_rows * L);
