@@ -628,6 +628,43 @@ def test_alternating_fits_on_one_ctx_match_a_fresh_ctx():
     ctx.close()
 
 
+def test_results_through_the_copy_kernel_match_the_memcpy_path():
+    """Small results leave through a copy kernel that stores into the pinned ring (dev_d2h / dev_d2h_multi / dev_d2h_view); a ctx
+    created under PETAL_D2H_MEMCPY=1 uses hipMemcpyAsync instead.  Same bytes either way: fit, fit_transform and transform of all
+    three models, fp32 and fp64, bit for bit -- and the copy-kernel ctx is the default."""
+    import os
+    import torch
+    import petal_decomposition_amd as petal
+    from synth_data import synth_pca, synth_ica
+    os.environ["PETAL_D2H_MEMCPY"] = "1"
+    try:
+        ctx_m = petal.Context(0)
+    finally:
+        os.environ.pop("PETAL_D2H_MEMCPY", None)
+    ctx_k = petal.Context(0)
+    rng = np.random.default_rng(11)
+    for dtype in (np.float32, np.float64):
+        n, d, k = 30011, 200, 24
+        x = torch.from_numpy(synth_pca(n, d, k, seed=3, dtype=dtype)).cuda()
+        om = rng.standard_normal((d, k + 10)).astype(dtype)
+        outs = []
+        for c in (ctx_k, ctx_m):
+            m = petal.RandomizedPca(k, ctx=c, n_iter=3)
+            y = m.fit_transform(x, omega=om)
+            p = petal.Pca(k, ctx=c)
+            yp = p.fit_transform(x)
+            outs.append([m.components(), m.singular_values(), m.mean(), np.asarray(y.cpu()), m.explained_variance_ratio(),
+                         p.components(), p.singular_values(), p.mean(), np.asarray(yp.cpu()), np.asarray(p.transform(x).cpu())])
+        for a, b in zip(*outs):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+        xs = torch.from_numpy(synth_ica(n, 64, 8, seed=4, dtype=dtype)).cuda()
+        w0 = rng.standard_normal((8, 8)).astype(dtype)
+        fa = petal.FastIca(ctx=ctx_k, n_components=8).fit(xs, w_init=w0)
+        fb = petal.FastIca(ctx=ctx_m, n_components=8).fit(xs, w_init=w0)
+        assert np.array_equal(fa.components, fb.components) and np.array_equal(fa.means, fb.means) and fa.n_iter == fb.n_iter
+    ctx_k.close(); ctx_m.close()
+
+
 def test_two_plane_iterate_against_the_three_plane_fit():
     """The re-based iterate of a power iteration is DEFINED as the sum of its two leading bf16 pieces (k_trsm_pack<NB, true>; the next
     K1 then needs five piece products, not six).  Any basis of range(Yp) serves the iteration, so the fit must agree with the
