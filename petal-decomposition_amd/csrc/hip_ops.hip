@@ -4635,7 +4635,9 @@ template <int MB>
 __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_total, double* W, const double* GX_gp, int mode,
                                                                double tol, int* state, int iter, double* scratch,
                                                                bf16x8* __restrict__ wpk3, double ortho_tol2, int* progress) {
-    if (state[0]) return;
+    // (the loop's "converged" word is only LOOKED AT in front of the first write: its load, a memory round trip, travels with the
+    // operands' instead of in front of them; a launch queued behind the converging one computes for nothing and leaves no trace)
+    const int done = __builtin_nontemporal_load(state);
     constexpr bool use_lds = MB > 0;
     extern __shared__ __attribute__((aligned(16))) double sm_tail[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -4692,14 +4694,15 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
             lim = fmax(lim, fabs(fabs(dot) - 1.0));
         }
     }
-    ws.red[tid] = lim;
+    // max over the workgroup: inside each wave by shuffles, across the waves through LDS (one barrier pair; a tree over the 512
+    // threads was nine)
+    for (int off = 32; off > 0; off >>= 1) lim = fmax(lim, __shfl_xor(lim, off, 64));
+    __syncthreads();                                              // (ws.red's last readers are done)
+    if ((tid & 63) == 0) ws.red[tid >> 6] = lim;
     __syncthreads();
-    for (int st = nt / 2; st > 0; st >>= 1) {
-        if (tid < st) ws.red[tid] = fmax(ws.red[tid], ws.red[tid + st]);
-        __syncthreads();
-    }
-    const double tl = ws.red[0];
-    __syncthreads();
+    double tl = 0;
+    for (int w = 0; w < (nt >> 6); ++w) tl = fmax(tl, ws.red[w]);
+    if (done) return;                                             // (uniform)
     if (res) { for (int e = tid; e < nc * nc; e += nt) W[e] = res[(e / nc) * ldl + (e % nc)]; }
     else { for (int e = tid; e < nc * nc; e += nt) W[e] = W1[e]; }
     if (wpk3) {  // the next step kernel's operand planes (k_pack_w3's layout), straight from the new W
