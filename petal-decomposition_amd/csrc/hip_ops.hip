@@ -4052,6 +4052,208 @@ __global__ __launch_bounds__(TRR_THREADS) void k_tridiag_r(const double* __restr
     }
 }
 
+// ---- the same reduction on 16-byte LDS accesses (round 4).  With two waves per SIMD the LDS hands out 8-byte reads at a fraction
+// of its rate (MI355X_MICROARCH.md, LDS: ds_read_b64 needs ~4 waves per SIMD, ds_read_b128 one), and a step of k_tridiag_r is paced
+// by the number of LDS instructions between its two barriers (measured with the look-ahead experiment, EXPERIMENTS.md round 4).
+// Here lane `sub` owns the ABSOLUTE column pairs {2 sub, 2 sub + 1} (mod 16): its slots mean the same columns in every step and
+// start on 16-byte boundaries, so every row access is one ds_read_b128 / ds_write_b128 per 16 columns -- half the LDS
+// instructions of the 8-byte form.  Columns that have left the trailing block keep v = w = 0: the update writes their old
+// values back unchanged, so nothing needs a guard; reflector k is parked in ROW k (dead once the step has read it), contiguous,
+// with beta in the slot of its unit entry and tau in the dead column k below it.
+template <int TM, int T>
+__device__ __forceinline__ void triw_step(double* __restrict__ W, int ld, int L, int off, int k, double* __restrict__ sv,
+                                          double* __restrict__ sp) {
+    constexpr int NG = TRR_THREADS / 8;
+    constexpr int RB = (16 * T + NG - 1) / NG;
+    constexpr int A0 = TM - T;
+    const int tid = threadIdx.x, g = tid >> 3, sub = tid & 7;
+    const int c0 = 2 * sub - off;                                 // column of element 0 of slot a: c0 + 16 a
+    // ---- reflector k from row k ----
+    const double* rowk = W + k * ld;
+    const double alpha = rowk[k + 1];
+    f64x2 x[TM];
+    double sq0 = 0, sq1 = 0;
+#pragma unroll
+    for (int a = A0; a < TM; ++a) {
+        const int c = c0 + 16 * a;
+        x[a] = *reinterpret_cast<const f64x2*>(rowk + c);
+        if (a == A0) {                                            // (only the rung's leading slot holds columns that have left the block)
+            x[a].x = c > k + 1 ? x[a].x : 0.0;
+            x[a].y = c + 1 > k + 1 ? x[a].y : 0.0;
+        }
+        sq0 = fma(x[a].x, x[a].x, sq0);
+        sq1 = fma(x[a].y, x[a].y, sq1);
+    }
+    const double sigma = oct_sum_f64(sq0 + sq1);
+    double beta = alpha, tk = 0.0, scale = 0.0;
+    if (sigma > 0.0) {                                            // (uniform: every thread holds the same bits)
+        const double n2 = fma(alpha, alpha, sigma);
+        double rs = __builtin_amdgcn_rsq(n2);
+        double rc = __builtin_amdgcn_rcp(fma(n2, rs, fabs(alpha)));
+        rs = rs * fma(-0.5 * n2 * rs, rs, 1.5);
+        rs = rs * fma(-0.5 * n2 * rs, rs, 1.5);
+        const double nrm = n2 * rs;
+        beta = -copysign(nrm, alpha);
+        const double den = fabs(alpha) + nrm;
+        rc = fma(fma(-den, rc, 1.0), rc, rc);
+        rc = fma(fma(-den, rc, 1.0), rc, rc);
+        scale = copysign(rc, alpha);
+        tk = den * rs;
+    }
+#pragma unroll
+    for (int a = A0; a < TM; ++a) {
+        const int c = c0 + 16 * a;
+        x[a].x = (a == A0 && c == k + 1) ? 1.0 : x[a].x * scale;
+        x[a].y = (a == A0 && c + 1 == k + 1) ? 1.0 : x[a].y * scale;
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int a = A0; a < TM; ++a) *reinterpret_cast<f64x2*>(sv + 2 * sub + 16 * a) = x[a];
+        // tau is parked in the dead column k of the row below -- BEFORE the barrier: the update behind it writes the old values
+        // of dead columns back, so it has to find tau there (the product in front of it multiplies it by v = 0 either way)
+        if (sub == 0) W[(k + 1) * ld + k] = tk;
+    }
+    if (tk != 0.0) {                                              // (uniform)
+        // ---- p = tau A22 v ----
+        double acc[RB][2];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int i = k + 1 + g + NG * r;
+            const double* row = W + min(i, L - 1) * ld + c0;
+            acc[r][0] = 0; acc[r][1] = 0;
+#pragma unroll
+            for (int a = A0; a < TM; ++a) {
+                const f64x2 rv = *reinterpret_cast<const f64x2*>(row + 16 * a);
+                acc[r][0] = fma(rv.x, x[a].x, acc[r][0]);
+                acc[r][1] = fma(rv.y, x[a].y, acc[r][1]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int i = k + 1 + g + NG * r;
+            const double s = oct_sum_f64(acc[r][0] + acc[r][1]);
+            if (sub == 0 && i < L) sp[i + off] = tk * s;
+        }
+    }
+    __syncthreads();
+    // reflector k is parked now that every group has read row k (no update touches row k): v, with beta where its unit entry sits
+    // (by a group of the second wave: the first has the most rows to update)
+    if (g == 8) {
+        double* rk = W + k * ld;
+#pragma unroll
+        for (int a = A0; a < TM; ++a) {
+            const int c = c0 + 16 * a;
+            if (c + 1 > k) {
+                f64x2 pv = x[a];
+                if (c == k + 1) pv.x = beta;
+                if (c + 1 == k + 1) pv.y = beta;
+                if (c == k) pv.x = rk[k];                          // (the diagonal entry stays)
+                *reinterpret_cast<f64x2*>(rk + c) = pv;
+            }
+        }
+    }
+    if (tk != 0.0) {
+        f64x2 w[TM];
+        double pv0 = 0, pv1 = 0;
+#pragma unroll
+        for (int a = A0; a < TM; ++a) {
+            const int c = c0 + 16 * a;
+            w[a] = *reinterpret_cast<const f64x2*>(sp + 2 * sub + 16 * a);
+            if (a == A0) {                                        // (entries of p from rows that have left the block are stale)
+                w[a].x = c > k ? w[a].x : 0.0;
+                w[a].y = c + 1 > k ? w[a].y : 0.0;
+            }
+            pv0 = fma(w[a].x, x[a].x, pv0);
+            pv1 = fma(w[a].y, x[a].y, pv1);
+        }
+        const double K = -0.5 * tk * oct_sum_f64(pv0 + pv1);
+#pragma unroll
+        for (int a = A0; a < TM; ++a) { w[a].x = fma(K, x[a].x, w[a].x); w[a].y = fma(K, x[a].y, w[a].y); }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {                            // A22 -= v w^T + w v^T
+            const int i = k + 1 + g + NG * r;
+            if (i < L) {
+                const double vi = sv[i + off], wi = fma(K, vi, sp[i + off]);
+                double* row = W + i * ld + c0;
+#pragma unroll
+                for (int a = A0; a < TM; ++a) {
+                    f64x2 rv = *reinterpret_cast<const f64x2*>(row + 16 * a);
+                    rv.x = fma(-vi, w[a].x, fma(-wi, x[a].x, rv.x));
+                    rv.y = fma(-vi, w[a].y, fma(-wi, x[a].y, rv.y));
+                    *reinterpret_cast<f64x2*>(row + 16 * a) = rv;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+template <int TM, int T>
+__device__ __forceinline__ void triw_ladder(double* __restrict__ W, int ld, int L, int S2, int off, int& k, double* __restrict__ sv,
+                                            double* __restrict__ sp) {
+    if (S2 >= T) {                                                // (a rung with more slots than the matrix has is skipped)
+        const int kend = T > 1 ? min(L - 2, 16 * (S2 - T + 1) - 1) : L - 2;
+        for (; k < kend; ++k) triw_step<TM, T>(W, ld, L, off, k, sv, sp);
+    }
+    if constexpr (T > 1) triw_ladder<TM, T - 1>(W, ld, L, S2, off, k, sv, sp);
+}
+// row pitch: every 16-column slot addressable; 16 (mod 32) doubles where the LDS has room -- the four 8-double pieces of a
+// ds_read_b128 lane group (two rows x two half slots) then fall on four different quarters of the bank row
+__host__ __device__ inline int triw_ld(int L, int tm) {
+    const int s16 = 16 * ((L + 15) / 16);
+    const int want = (s16 % 32 == 16) ? s16 : s16 + 16;
+    return sizeof(double) * ((size_t)L * want + 32 * tm) <= 160 * 1024 ? want : s16;
+}
+template <int TM>  // L <= 16 TM
+__global__ __launch_bounds__(TRR_THREADS) void k_tridiag_w(const double* __restrict__ A, int L, int64_t lda, double* __restrict__ dd,
+                                                           double* __restrict__ ee, double* __restrict__ HV,
+                                                           double* __restrict__ tau, double* __restrict__ gg,
+                                                           int* __restrict__ flag, double* __restrict__ V, int64_t ldv, int Lz, int reset_flag) {
+    extern __shared__ __attribute__((aligned(16))) double sm_tri[];
+    const int tid = threadIdx.x;
+    const int S2 = (L + 15) >> 4, off = 16 * (TM - S2);
+    const int ld = triw_ld(L, TM);
+    for (int e = tid; e < Lz * Lz; e += TRR_THREADS) {           // the caller's zero padding of V (rows / columns L .. Lz - 1)
+        const int r = e / Lz, c = e - r * Lz;
+        if (r >= L || c >= L) V[(int64_t)r * ldv + c] = 0.0;
+    }
+    double* W = sm_tri;
+    double* sv = W + (size_t)L * ld;                              // 16 TM entries, indexed by column + off
+    double* sp = sv + 16 * TM;                                    // 16 TM entries
+    for (int e0 = tid; e0 < L * ld; e0 += 8 * TRR_THREADS) {
+        double t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * TRR_THREADS, r = e / ld, c = e - r * ld;
+            t8[u] = (e < L * ld && c < L) ? A[(int64_t)r * lda + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * TRR_THREADS; if (e < L * ld) W[e] = t8[u]; }
+    }
+    for (int e = tid; e < 32 * TM; e += TRR_THREADS) sv[e] = 0.0;
+    if (tid == 0 && reset_flag) *flag = 0;   // (a caller-owned verdict word accumulates: it is not reset here)
+    __syncthreads();
+    int k = 0;
+    triw_ladder<TM, TM>(W, ld, L, S2, off, k, sv, sp);
+    for (int e = tid; e < (L - 2) * L; e += TRR_THREADS) {       // reflector k: row k of HV, entries k + 1 .. L - 1
+        const int kk = e / L, c = e - kk * L;
+        HV[e] = c > kk + 1 ? W[kk * ld + c] : (c == kk + 1 ? 1.0 : 0.0);
+    }
+    for (int kk = tid; kk < L; kk += TRR_THREADS) {
+        dd[kk] = W[kk * ld + kk];
+        ee[kk] = kk + 2 < L ? W[kk * ld + kk + 1] : (kk + 2 == L ? W[(L - 1) * ld + L - 2] : 0.0);
+        tau[kk] = kk + 2 < L ? W[(kk + 1) * ld + kk] : 0.0;
+    }
+    // gg[k] = v_k . v_{k-1} (lets the back-transformation apply two reflectors per reduction round), eight lanes per k: v_k is row k
+    // from column k + 2 on and 1 at column k + 1
+    for (int kk = tid >> 3; kk < L; kk += TRR_THREADS / 8) {
+        double acc = 0;
+        if (kk >= 1 && kk + 2 < L)
+            for (int c = kk + 1 + (tid & 7); c < L; c += 8) acc += (c == kk + 1 ? 1.0 : W[kk * ld + c]) * W[(kk - 1) * ld + c];
+        acc = oct_sum_f64(acc);
+        if ((tid & 7) == 0) gg[kk] = acc;
+    }
+}
+
 // one wave per eigenpair.  The Sturm count runs on the three-term recurrence of the leading minors, renormalised by their
 // exponent every step (v_frexp_mant / v_ldexp: no division on the chain); d and e^2 are fetched eight at a time so the LDS
 // latency is paid once per eight steps.  The twisted factorisation keeps both recurrences in one instruction stream
@@ -5987,10 +6189,18 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         set_max_lds(d, reinterpret_cast<const void*>(k_tridiag_r<TM, ST>));                                                        \
         hipLaunchKernelGGL((k_tridiag_r<TM, ST>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag, V, ldv, (int)(pad_done ? 0 : Lz), (ext_verdict && !verdict_fresh) ? 0 : 1); \
     } while (0)
+#define PETAL_TRIW_LAUNCH(TM)                                                                                                      \
+    do {                                                                                                                           \
+        const size_t lds_r = sizeof(double) * ((size_t)L * triw_ld((int)L, TM) + 32 * TM);                                         \
+        set_max_lds(d, reinterpret_cast<const void*>(k_tridiag_w<TM>));                                                            \
+        hipLaunchKernelGGL((k_tridiag_w<TM>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag, V, ldv, (int)(pad_done ? 0 : Lz), (ext_verdict && !verdict_fresh) ? 0 : 1); \
+    } while (0)
+            // l <= 80: the 8-byte form (78.5 us at l = 74, where a step is a chain of latencies and the 16-byte form measures 83.6);
+            // above: the 16-byte form (238 us at l = 138 against 290)
             if (L <= 80) PETAL_TRI_LAUNCH(10, 2);
-            else if (L <= 132) PETAL_TRI_LAUNCH(18, 2);
-            else PETAL_TRI_LAUNCH(18, 1);
+            else PETAL_TRIW_LAUNCH(9);
 #undef PETAL_TRI_LAUNCH
+#undef PETAL_TRIW_LAUNCH
             launch_check();
             const int hv_rows = (int)std::min<int64_t>(L - 2, (96 * 1024) / (8 * L));
             const size_t lds_e = sizeof(double) * (23 * (((L + 7) & ~7) + 8) + (size_t)hv_rows * L);

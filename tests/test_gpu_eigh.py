@@ -2,7 +2,8 @@
 Jacobi solver as the fallback for eigenvalues it flags as too close), driven through the product API on a real MI355X:
 Pca with k = d eigen-decomposes the d x d covariance, so d walks the solver's kernel boundaries
 
-    d <= 80 / <= 132 / <= 138   the three register-resident tridiagonalisation kernels (k_tridiag_r<10,2>, <18,2>, <18,1>)
+    d <= 80 / <= 138            the two register-resident tridiagonalisation kernels (k_tridiag_r<10,2>: 8-byte LDS accesses;
+                                k_tridiag_w<9>: absolute column pairs, 16-byte accesses, one rung per 16 columns)
     d  = 139 .. 141             working copy in LDS (k_tridiag<true>),  d >= 142: in global memory (k_tridiag<false>)
     d <= 128 / > 128            two / three 64-lane slices of an eigenvector per wave (k_trieig_r<4,2>, <4,3>)
 
