@@ -34,6 +34,7 @@ void dev_h2d(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, 
 void dev_h2d_async(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
 void dev_d2h(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
 const void* dev_d2h_view(Dev*, const void* src, size_t) { return src; }
+const void* dev_h2d_view(Dev*, const void* src, size_t) { return src; }
 void dev_d2h_multi(Dev*, int nseg, void* const* dst, const void* const* src, const size_t* bytes) { for (int i = 0; i < nseg; ++i) if (bytes[i]) std::memcpy(dst[i], src[i], bytes[i]); }
 void dev_d2d(Dev*, void* dst, const void* src, size_t bytes) { std::memmove(dst, src, bytes); }
 void dev_copy2d(Dev*, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int) {

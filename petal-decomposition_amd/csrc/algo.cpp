@@ -524,25 +524,31 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     double* const flip = res.f64() + o_flip;
     DBuf muT;
     // Omega (pca.rs:701-705): d x l_req row-major host draw -> first L columns, padded to dp x LP, f64.  Single rank: the raw draw
-    // goes up through the pinned ring without a host wait and is widened on the device; sharded: rank 0's draw came back from the
+    // is staged in the pinned ring without a host wait and widened on the device; sharded: rank 0's draw came back from the
     // prologue's all-reduce, already fp64.
     DBuf P;
-    // The column-means pass is queued FIRST: the device starts on it at once, and the host's copy of Omega into the pinned ring,
-    // its upload, widening and padding run beside it on the side stream (single rank); joined in front of the first product.
+    // The column-means pass is queued FIRST: the device starts on it at once, and the host's copy of Omega into the pinned ring
+    // runs beside it.
     if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
     column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq, sharded(c) && centering ? pro.sums : nullptr);
     if (sharded(c)) {
         P = DBuf(c.dev, sizeof(double) * dp * LP);
         op_pad_to_f64(c.dev, F64, P.f64(), dp, LP, pro.draw, d, L, l_req, tvp, 2 + LP);
     } else {
-        dev_fork(c.dev, false);   // (needs nothing from the means pass: starts at once)
-        P = DBuf(c.dev, sizeof(double) * dp * LP);   // (allocated while forked: a block no main-stream kernel can still be using)
-        DBuf raw(c.dev, esz * size_t(d) * l_req);
-        dev_h2d_async(c.dev, raw.p, omega, raw.bytes);
-        op_pad_to_f64(c.dev, dt, P.f64(), dp, LP, raw.p, d, L, l_req, tvp, 2 + LP);  // (also clears tv, ndead, lam for the first pipeline run)
-        dev_fork_end(c.dev);
+        // (queued behind the means pass, so the host's copy into the ring runs beside it.  No transfer of its own: the widening
+        // kernel reads the draw from the pinned ring over the link.  A side stream for this, joined in front of the first product,
+        // measured the same; one for the components' write-out further down COST 46 us a fit -- an event recorded on the main
+        // stream and the wait for the join are bubbles of their own, far longer than the kernel trace shows: EXPERIMENTS.md)
+        P = DBuf(c.dev, sizeof(double) * dp * LP);
+        const void* view = dev_h2d_view(c.dev, omega, esz * size_t(d) * l_req);
+        if (view) {
+            op_pad_to_f64(c.dev, dt, P.f64(), dp, LP, view, d, L, l_req, tvp, 2 + LP);  // (also clears tv, ndead, lam for the first pipeline run)
+        } else {   // a draw beyond a ring slot
+            DBuf raw(c.dev, esz * size_t(d) * l_req);
+            dev_h2d_async(c.dev, raw.p, omega, raw.bytes);
+            op_pad_to_f64(c.dev, dt, P.f64(), dp, LP, raw.p, d, L, l_req, tvp, 2 + LP);
+        }
     }
-    dev_join(c.dev);
     DBuf Z(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP), Z1(c.dev, esz * size_t(std::max<int64_t>(n, 1)) * LP);
     c.stats.pass_flops = 2.0 * double(n) * double(d) * double(l_req);
     c.stats.pass_bytes = double(esz) * (double(n) * d + double(n) * l_req + double(d) * l_req);
@@ -659,11 +665,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     if (!robust) op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, false, LP, std::max<int64_t>(k, 1), ndead);
     else op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, true, LP);  // (zero padding of Uh included)
     // rows of V^T: v_j = B^T u_j / sigma_j, sigma_j = sqrt(lam_j) (the host takes the same square roots of lam)
-    // (on the side stream: it only reads what is already there and nothing below reads its output -- it runs beside the product
-    // that forms U; the main stream waits for it in front of the results' copy)
-    dev_fork(c.dev);
     op_components_out(c.dev, dt, Bt.f64(), LP, Uh.f64(), LP, lam, dt == F32 ? 1e-7 : 1e-12, d, L, k, comp_dev);
-    dev_fork_end(c.dev);
 
     // U = Q Uh = Usrc (T Uh) (pca.rs:683) and svd_flip (pca.rs:684)
     // (only the k columns svd_flip signs and fit_transform returns: kp = k rounded up to whole 16-column tiles; the small
@@ -687,7 +689,6 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     double t_q = 0, t_s = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
-        dev_join(c.dev);
         if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip, true, attempt == 0 ? ndead : nullptr);
         hres = static_cast<const double*>(dev_d2h_view(c.dev, tvp, sizeof(double) * hres_len + comp_bytes));
         hcomp = hres + hres_len;

@@ -399,6 +399,16 @@ void dev_h2d_async(Dev* d, void* dst, const void* src, size_t bytes) {
     std::memcpy(d->pin + off, src, bytes);
     HIP_CHECK(hipMemcpyAsync(dst, d->pin + off, bytes, hipMemcpyHostToDevice, d->stream));
 }
+// The same without the transfer: the bytes are copied into the pinned ring and the ring's DEVICE-visible address is returned -- a
+// kernel that reads its (small) operand once may as well read it over the link itself (valid until the next dev_sync).
+const void* dev_h2d_view(Dev* d, const void* src, size_t bytes) {
+    if (!bytes) return nullptr;
+    ensure_pin(d);
+    if (bytes > PIN_MAX_COPY || !d->pin_dev) return nullptr;
+    const size_t off = pin_reserve(d, bytes);
+    std::memcpy(d->pin + off, src, bytes);
+    return d->pin_dev + off;
+}
 void dev_abort(Dev* d) {  // error path: the destinations of queued copies may be gone
     dev_fork_abort(d);
     (void)hipStreamSynchronize(d->stream);

@@ -36,6 +36,7 @@ void  dev_h2d(Dev*, void* dst, const void* src, size_t bytes);
 void  dev_h2d_async(Dev*, void* dst, const void* src, size_t bytes);  // src is consumed before the call returns; no host wait
 void  dev_d2h(Dev*, void* dst, const void* src, size_t bytes);  // dst is valid after the next dev_sync
 void  dev_d2h_multi(Dev*, int nseg, void* const* dst, const void* const* src, const size_t* bytes);   // several dev_d2h in one launch (nseg <= 8)
+const void* dev_h2d_view(Dev*, const void* src, size_t bytes);   // host bytes staged in the pinned ring; returns its device-visible address (nullptr: too large), valid until the next dev_sync
 const void* dev_d2h_view(Dev*, const void* src, size_t bytes);   // the result where the copy lands (pinned ring): readable after the next dev_sync, until the next copy is queued
 void  dev_d2d(Dev*, void* dst, const void* src, size_t bytes);
 // pitched copies (bytes); kind: 0 h2d, 1 d2h, 2 d2d
