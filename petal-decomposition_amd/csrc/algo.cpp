@@ -801,7 +801,7 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     // Pca whose spectrum needs four products instead of two then pays the whole pipeline twice, 1.10 -> 1.74 ms) and, for fp64
     // data, the spectrum that chooses the accurate route -- and one synchronisation at the end delivers the results.  The
     // components leave in the caller's layout and type.
-    auto pipeline = [&](bool optimistic) -> bool {
+    auto pipeline = [&](bool optimistic, bool route_check) -> bool {
     op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
     allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
     // total_variance = sigma . sigma over ALL singular values (pca.rs:224) = trace of the Gram matrix: its diagonal is set aside
@@ -822,8 +822,11 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     if (!partial) op_eigh(c.dev, C.f64(), d, dp, V.f64(), dp, lam.f64(), dt == F32 ? 1e-8 : 1e-15, false, 0, std::max<int64_t>(k, 1));
     // fp64 data with wanted singular values below 10^-3.5 sigma_1 (by the Gram route's own estimate): the QR + one-sided
     // Jacobi route keeps them to eps sigma_1 / sigma_k like the crate's gesvd (linalg.rs:70-91); two more passes over X
+    // (the check needs the spectrum on the host: the first run skips it and the caller looks at the singular values that come back
+    // with the results -- a fit that does need the route, rare, is run again with the check in place; every fp64 fit used to pay
+    // a host round trip in the middle of its queue for it)
     bool accurate = false;
-    if (dt == F64 && k > 0) {
+    if (dt == F64 && k > 0 && route_check) {
         std::vector<double> hl(k);
         dev_d2h(c.dev, hl.data(), lam.p, sizeof(double) * k);
         dev_sync(c.dev);
@@ -867,7 +870,11 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
     dev_sync(c.dev);
     return !(partial && optimistic) || topk_verdict_ok(h3, vtol);
     };  // pipeline
-    pipeline(false);
+    pipeline(false, false);
+    if (dt == F64 && k > 0) {
+        const bool low = hs[0] > 0 && hs[k - 1] > 0 && n_total >= d && hs[k - 1] / hs[0] < GRAM_ROUTE_FLOOR;
+        if (agree_any(c, low)) pipeline(false, true);
+    }
     if (slot_flip)   // (sharded fp32: the all-reduced keys behind the triple; else the triple itself)
         sg = flip_slot_keys(c, dt) ? signs_from_triple(std::vector<double>(deferred.begin() + 3 * rp, deferred.begin() + 4 * rp), rp)
                                    : signs_from_triple(std::vector<double>(deferred.begin(), deferred.begin() + 3 * rp), rp);
