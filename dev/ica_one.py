@@ -6,6 +6,7 @@ import petal_decomposition_amd as petal
 from synth_data import synth_ica
 big = len(sys.argv) > 1 and sys.argv[1] == "cfg5"
 n, d, nc = (500000, 512, 64) if big else (200000, 256, 32)
+if len(sys.argv) > 1 and sys.argv[1] == "small": n, d, nc = 20000, 256, 32
 xd = torch.from_numpy(synth_ica(n, d, nc, seed=8 if big else 5, dtype=np.float32)).cuda()
 w0 = np.random.default_rng(7).standard_normal((nc, nc)).astype(np.float32)
 ctx = petal.Context(0)

@@ -5588,23 +5588,28 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
             active = cdiv(tiles, 4);
         }
         // row split: workgroups are dealt round-robin to the 256 CUs (up to three resident on each: the kernel's register
-        // budget), so the launch takes ceil(active * ns / 256) / ns of the single-split time; pick the ns that minimises it
-        // (ties: fewer fp64 slabs), as long as the slabs stay a fraction of the input traffic
-        const int64_t slab_cap = std::max<int64_t>(1, (int64_t)(0.4 * double(n) * double(M + (sym ? 0 : N)) * dtype_size(dt) / (double(M) * N * 8.0)));
-        const int64_t ns_max = std::min<int64_t>(std::min<int64_t>(128, slab_cap), std::max<int64_t>(1, n / 256));
+        // budget), so the launch takes ceil(active * ns / 256) / ns of the single-split time t1 -- one workgroup's four 32 x 64
+        // tiles over all n rows, ~0.1 us a row (20000 x 256 in 15 splits: 119 us) -- plus what the ns fp64 slabs cost to write and
+        // to combine (M N 16 bytes each at ~4 TB/s); pick the ns that minimises the sum.  (Round 4: a hard cap "slabs <= 40 % of
+        // the input traffic" stood here and left 20000 x 256 on 75 workgroups: 119 us where 250 take half that.)
+        const int64_t ns_max = std::min<int64_t>(128, std::max<int64_t>(1, n / 64));
+        const double t1 = 0.1 * double(n), slab_us = double(M) * double(N) * 16.0 / 4.0e6;
+        auto launch_us = [&](int64_t ns) { return t1 * double((active * ns + 255) / 256) / double(ns) * (active * ns <= 256 ? 1.25 : 1.0); };
+        // (a single workgroup per CU leaves one wave per SIMD and the load latency exposed: measured 312 vs 265 us)
         int64_t nsplit = 1;
         double best = 1e30;
         for (int64_t ns = 1; ns <= ns_max; ++ns) {
-            // (a single workgroup per CU leaves one wave per SIMD and the load latency exposed: measured 312 vs 265 us)
-            const double cost = double((active * ns + 255) / 256) / double(ns) * (active * ns <= 256 ? 1.25 : 1.0);
+            const double cost = launch_us(ns) + slab_us * double(ns);
             if (cost < best * 0.97) { best = cost; nsplit = ns; }
         }
         // among the splits that tie with the best one, the finest up to 96: whole "rounds" of workgroups cost the same in this
         // model, but a finer split keeps three workgroups on a CU and shortens the tail of the launch (500000 x 512: 2909 us at
-        // 28 splits, 2863 at 42, 2837 at 56, 2757 at 84 -- against 0.4 us of k_sum_parts2 per extra slab)
-        for (int64_t ns = nsplit + 1; ns <= std::min<int64_t>(ns_max, 96); ++ns) {
-            const double cost = double((active * ns + 255) / 256) / double(ns) * (active * ns <= 256 ? 1.25 : 1.0);
-            if (cost <= best * 1.005) nsplit = ns;
+        // 28 splits, 2863 at 42, 2837 at 56, 2757 at 84 -- against 0.4 us of k_sum_parts2 per extra slab) -- while the slabs stay
+        // small change (3 % of the launch)
+        {
+            const double base = launch_us(nsplit);
+            for (int64_t ns = nsplit + 1; ns <= std::min<int64_t>(ns_max, 96); ++ns)
+                if (launch_us(ns) <= base * 1.005 && slab_us * double(ns) <= 0.03 * base) nsplit = ns;
         }
         (void)mslices;
         static const int ns_env = [] { const char* e = getenv("PETAL_GRAM_NS"); return e ? atoi(e) : 0; }();   // (development knob)
