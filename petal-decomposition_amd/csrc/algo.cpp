@@ -292,7 +292,7 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
         op_ritz_residual(dv, R.f64(), p, V, dp, dp, nc, th.f64(), resid3 ? vf.as<int>() : nullptr, out3, w);
     };
     auto deliver = [&] {};
-    double h3[3];
+    double h3[3], prev_rel = -1.0;
     for (int it = 0; it < 40; ++it) {
         if (it == 0) op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, seed, p, 0.0, Y.f64(), p);   // (the start block is read-only)
         orth(Y, Q, it % 2 == 1 ? 2 : 1);   // (the Rayleigh-Ritz step of the odd iterations needs the orthonormal basis)
@@ -307,6 +307,18 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
             dev_d2h(dv, h3, r3.p, sizeof(h3));
             dev_sync(dv);
             if (topk_verdict_ok(h3, verdict_tol)) { deliver(); return true; }
+            // No gap behind the wanted pairs (a smoothly decaying spectrum): the residual falls by (lambda_{p+1} / lambda_nc)^2 per
+            // check and would need hundreds of them.  Give up as soon as the measured rate says the remaining budget cannot get
+            // there -- the caller's full eigen-solve costs about eight checks at d = 512 -- instead of running all twenty
+            // (20000 x 512 without a gap: 6 of the fit's 10 ms were these products).
+            const double rel = (std::isfinite(h3[0]) && h3[1] > 0) ? std::sqrt(std::max(h3[0], 0.0)) / h3[1] : -1.0;
+            if (rel < 0) return false;
+            if (prev_rel > 0) {
+                const double rate = rel / prev_rel;
+                if (!(rate < 1.0)) return false;
+                if (std::log(verdict_tol / rel) / std::log(rate) > 8.0) return false;
+            }
+            prev_rel = rel;
         }
     }
     return false;

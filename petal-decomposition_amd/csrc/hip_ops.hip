@@ -3678,6 +3678,107 @@ __global__ __launch_bounds__(TRI_THREADS) void k_tridiag(const double* __restric
     }
 }
 
+// ---- the same reduction for orders beyond the LDS (139 ... 2048), ONE LAUNCH PER STEP on the whole chip (round 4).  k_tridiag
+// walks such a matrix with one workgroup and its working copy in global memory: 29 ms at order 512, which is where an exact Pca of
+// data without a spectral gap behind its k components ends up (the subspace iteration cannot converge there and the d x d
+// covariance is eigen-decomposed in full).  Launch k applies the PENDING rank-2 update of step k - 1 to the rows below row k and, in
+// the same pass over each row, forms that row's entry of p_k = tau_k A22 v_k: one pass over the trailing block per step.  Every
+// workgroup first rebuilds, redundantly and bit-identically, what the pass needs -- w_{k-1} = p_{k-1} + K v_{k-1} from the vectors
+// the previous launch left in global memory, row k as the pending update leaves it, and from it reflector k -- so nothing but
+// a launch boundary orders the steps.  Vectors are indexed by absolute column (zeros outside their range).
+constexpr int TMW_NV = 8;                                          // orders up to 256 * TMW_NV
+__global__ __launch_bounds__(256) void k_tridiag_mw(double* __restrict__ W, int64_t ld, int L, int k, const double* __restrict__ vp_prev,
+                                                    double* __restrict__ vp_cur, double* __restrict__ dd, double* __restrict__ ee,
+                                                    double* __restrict__ HV, double* __restrict__ tau) {
+    extern __shared__ __attribute__((aligned(16))) double sm_mw[];
+    double* svp = sm_mw;            // v_{k-1}
+    double* swp = svp + L;          // w_{k-1}
+    double* svn = swp + L;          // v_k
+    double* s_red = svn + L;        // 2 x 4 partial sums
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int red_slot = 0;
+    auto block_sum = [&](double a) {                               // to every thread; alternating slots: one barrier per sum
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        double* slot = s_red + 4 * red_slot;
+        red_slot ^= 1;
+        if (lane == 0) slot[wv] = a;
+        __syncthreads();
+        return (slot[0] + slot[1]) + (slot[2] + slot[3]);
+    };
+    // (a) w_{k-1} = p_{k-1} + K v_{k-1}, K = -tau_{k-1} (p^T v) / 2
+    double vq[TMW_NV], pq[TMW_NV];
+    double pv = 0;
+#pragma unroll
+    for (int t = 0; t < TMW_NV; ++t) {
+        const int j = tid + 256 * t;
+        vq[t] = (k > 0 && j < L) ? vp_prev[j] : 0.0;
+        pq[t] = (k > 0 && j < L) ? vp_prev[L + j] : 0.0;
+        pv = fma(pq[t], vq[t], pv);
+    }
+    const double tkp = k > 0 ? tau[k - 1] : 0.0;
+    const double Kp = -0.5 * tkp * block_sum(pv);
+#pragma unroll
+    for (int t = 0; t < TMW_NV; ++t) {
+        const int j = tid + 256 * t;
+        pq[t] = fma(Kp, vq[t], pq[t]);                            // w_{k-1}
+        if (j < L) { svp[j] = vq[t]; swp[j] = pq[t]; }
+    }
+    __syncthreads();
+    // (b) row k as the pending update leaves it (v_{k-1}[k] = 1), and reflector k from it
+    const double wk = k > 0 ? swp[k] : 0.0, vk = k > 0 ? svp[k] : 0.0;
+    double rq[TMW_NV];
+    double sq = 0;
+#pragma unroll
+    for (int t = 0; t < TMW_NV; ++t) {
+        const int j = tid + 256 * t;
+        rq[t] = (j >= k && j < L) ? fma(-vk, pq[t], fma(-wk, vq[t], W[(size_t)k * ld + j])) : 0.0;
+        sq = fma(j >= k + 2 ? rq[t] : 0.0, j >= k + 2 ? rq[t] : 0.0, sq);
+    }
+    // (row k's own entries k and k + 1 sit in whichever thread owns those columns: they travel through LDS)
+#pragma unroll
+    for (int t = 0; t < TMW_NV; ++t) {
+        const int j = tid + 256 * t;
+        if (j == k) s_red[8] = rq[t];
+        if (j == k + 1) s_red[9] = rq[t];
+    }
+    const double sigma = block_sum(sq);                           // (its barrier also publishes s_red[8 .. 9])
+    const double dk = s_red[8], alpha = k + 1 < L ? s_red[9] : 0.0;
+    double beta = alpha, tk = 0.0, scale = 0.0;
+    if (k + 2 < L && sigma > 0.0) {
+        beta = -copysign(sqrt(fma(alpha, alpha, sigma)), alpha);
+        tk = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    const bool refl = k + 2 < L;
+#pragma unroll
+    for (int t = 0; t < TMW_NV; ++t) {
+        const int j = tid + 256 * t;
+        const double vj = !refl ? 0.0 : (j == k + 1 ? 1.0 : (j >= k + 2 ? rq[t] * scale : 0.0));
+        if (j < L) {
+            svn[j] = vj;
+            if (blockIdx.x == 0) {
+                vp_cur[j] = vj;
+                if (refl) HV[(size_t)k * L + j] = vj;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) { dd[k] = dk; ee[k] = k + 1 < L ? beta : 0.0; tau[k] = tk; }
+    __syncthreads();
+    // (c) rows below k: the pending update, and p_k = tau_k A22 v_k from the updated row -- one wave per row
+    for (int i = k + 1 + blockIdx.x * 4 + wv; i < L; i += 4 * gridDim.x) {
+        double* row = W + (size_t)i * ld;
+        const double vi = svp[i], wi = swp[i];
+        double acc = 0;
+        for (int j = k + 1 + lane; j < L; j += 64) {
+            const double nv = fma(-vi, swp[j], fma(-wi, svp[j], row[j]));
+            if (k > 0) row[j] = nv;
+            acc = fma(nv, svn[j], acc);
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) vp_cur[L + i] = tk * acc;
+    }
+}
+
 // one wave per eigenpair j (descending): lambda_j, z_j, v_j.  d, e in LDS; q+ / q- / z per wave in LDS.
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_trieig(const double* __restrict__ dd, const double* __restrict__ ee,
@@ -6228,7 +6329,25 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
             }
             launch_check();
         } else {
-            if (inlds) {
+            static const bool tri_one_wg = getenv("PETAL_TRIDIAG_ONE_WG") != nullptr;   // (the round-2 kernels: A/B switch)
+            if (!tri_one_wg && L <= 256 * TMW_NV) {
+                // one launch per Householder step, the whole chip per launch (k_tridiag_mw): 29 -> ~5 ms at order 512
+                const int64_t ldm = L | 1;
+                double* mw = (double*)dev_alloc(d, sizeof(double) * ((size_t)L * ldm + 4 * L));
+                double* vp = mw + (size_t)L * ldm;
+                HIP_CHECK(hipMemcpy2DAsync(mw, ldm * sizeof(double), A, lda * sizeof(double), L * sizeof(double), L, hipMemcpyDeviceToDevice, d->stream));
+                HIP_CHECK(hipMemsetAsync(vp, 0, sizeof(double) * 4 * L, d->stream));
+                HIP_CHECK(hipMemsetAsync(HV, 0, sizeof(double) * L * L, d->stream));
+                const size_t lds_mw = sizeof(double) * (3 * L + 16);
+                for (int64_t k = 0; k < L; ++k) {
+                    const int64_t m = L - k - 1;
+                    const unsigned grid = (unsigned)std::min<int64_t>(512, std::max<int64_t>(1, (m + 3) / 4));
+                    hipLaunchKernelGGL(k_tridiag_mw, dim3(grid), dim3(256), lds_mw, d->stream, mw, ldm, (int)L, (int)k, vp + ((k + 1) & 1) * 2 * L,
+                                       vp + (k & 1) * 2 * L, dd, ee, HV, tau);
+                }
+                launch_check();
+                dev_free(d, mw);
+            } else if (inlds) {
                 set_max_lds(d, reinterpret_cast<const void*>(k_tridiag<true>));
                 hipLaunchKernelGGL(k_tridiag<true>, dim3(1), dim3(TRI_THREADS), lds_in, d->stream, A, (int)L, lda, Wg, dd, ee, HV, tau);
             } else {
