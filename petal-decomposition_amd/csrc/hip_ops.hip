@@ -531,7 +531,13 @@ __global__ void k_unpack_strided(const T* __restrict__ src, int64_t n, int64_t d
 // Column scans over a tall row-major matrix, first stage: block = 64 column lanes x 4 row lanes over `rows` rows (the
 // loads of a thread are independent: many in flight), row lanes combined through LDS in fixed order.
 constexpr int SCAN_RY = 4;
-__host__ inline int64_t scan_rows_per_block(int64_t n) { return std::max<int64_t>(256, (cdiv64(n, 256) + 3) / 4 * 4); }
+// rows per block of the column scans: ~256 row parts for wide matrices; a narrow one (few 64-column blocks) gets more parts so that
+// the launch still puts ~2048 workgroups on the chip (1e6 x 64 on 256 workgroups streamed at 2.1 TB/s)
+__host__ inline int64_t scan_rows_per_block(int64_t n, int64_t cols = 512) {
+    const int64_t col_blocks = std::max<int64_t>(1, (cols + 63) / 64);
+    const int64_t parts = std::min<int64_t>(1024, std::max<int64_t>(256, 2048 / col_blocks));   // (more parts cost the final combine more than they save)
+    return std::max<int64_t>(256, (cdiv64(n, parts) + 3) / 4 * 4);
+}
 template <class T, bool SQ>  // SQ: also the column sums of squares, part = [nparts][2 d] = [sums | sums of squares]
 __global__ __launch_bounds__(256) void k_colsum_part2(const T* __restrict__ X, int64_t n, int64_t d, int64_t ldx, int64_t rows,
                                                       double* __restrict__ part) {
@@ -5246,7 +5252,7 @@ void op_colsum(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ldx
     if (dd == 0) return;
     const int64_t w = with_sq ? 2 * dd : dd;
     if (n == 0) { dev_memset(d, out, 0, sizeof(double) * w); return; }
-    const int64_t rows = scan_rows_per_block(n), nparts = cdiv(n, rows);
+    const int64_t rows = scan_rows_per_block(n, dd), nparts = cdiv(n, rows);
     double* part = (double*)dev_alloc(d, sizeof(double) * nparts * w);
     launch_colsum_parts(d, dt, X, n, dd, ldx, rows, nparts, part, with_sq);
     hipLaunchKernelGGL(k_sum_parts2<double>, dim3(cdiv(w, 32)), dim3(256), 0, d->stream, part, nparts, w, out, w, w, false);
@@ -5258,7 +5264,7 @@ void op_colmean(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ld
     if (dd == 0) return;
     const int64_t w = with_sq ? 2 * dd : dd;
     if (n == 0) { dev_memset(d, mu64, 0, sizeof(double) * w); dev_memset(d, muT, 0, dtype_size(dt) * dd); return; }
-    const int64_t rows = scan_rows_per_block(n), nparts = cdiv(n, rows);
+    const int64_t rows = scan_rows_per_block(n, dd), nparts = cdiv(n, rows);
     double* part = (double*)dev_alloc(d, sizeof(double) * nparts * w);
     launch_colsum_parts(d, dt, X, n, dd, ldx, rows, nparts, part, with_sq);
     DISPATCH_T(dt, hipLaunchKernelGGL(k_colmean_final<T>, dim3(cdiv(w, 8)), dim3(256), 0, d->stream, part, nparts, w, dd, 1.0 / n_total, mu64, (T*)muT));
@@ -5869,7 +5875,7 @@ void op_flip_key(Dev* d, const double* triple, double* key, int64_t L, const int
 void op_col_absmax(Dev* d, int dt, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* absmax,
                    double* idx, double* sign) {
     if (L == 0) return;
-    const int64_t rows = scan_rows_per_block(n), nparts = std::max<int64_t>(1, cdiv(n, rows));
+    const int64_t rows = scan_rows_per_block(n, L), nparts = std::max<int64_t>(1, cdiv(n, rows));
     double* part = (double*)dev_alloc(d, sizeof(double) * 3 * nparts * L);
     double *pm = part, *pi = part + nparts * L, *ps = part + 2 * nparts * L;
     if (n == 0) {
