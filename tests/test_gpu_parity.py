@@ -108,6 +108,27 @@ def test_pca_parity(ctx):
     pc.pca_parity(ctx, 5000, 64, 8, seed=2, dtype=np.float32, tol=2e-5)
 
 
+@pytest.mark.parametrize("n,d,k,dtype", [(6000, 256, 16, np.float64), (8000, 512, 32, np.float64), (6000, 160, 24, np.float32)])
+def test_exact_pca_without_a_spectral_gap(ctx, n, d, k, dtype):
+    """Exact Pca with k < d on data whose singular values decay smoothly (no gap behind the k wanted ones): the subspace iteration
+    cannot converge, gives up from its measured rate, and the d x d covariance is eigen-decomposed in full -- orders beyond 138 by
+    the one-launch-per-step tridiagonalisation (k_tridiag_mw).  Against numpy's SVD of the centred data: singular values, and the
+    components up to sign (neighbours are ~1 % apart, so fp64 vectors are good to ~1e-10, fp32 ones to ~1e-4)."""
+    import petal_decomposition_amd as petal
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal((n, d)) * np.linspace(3.0, 0.3, d)).astype(dtype)
+    xc = x.astype(np.float64) - x.astype(np.float64).mean(axis=0)
+    _, s_ref, vt_ref = np.linalg.svd(xc, full_matrices=False)
+    m = petal.Pca.new(k, ctx)
+    m.fit(x)
+    tol_s, tol_v = (1e-10, 1e-7) if dtype == np.float64 else (2e-5, 2e-3)
+    assert np.abs(m.singular_values() - s_ref[:k]).max() <= tol_s * s_ref[0]
+    c = np.asarray(m.components(), dtype=np.float64)
+    dots = np.abs(np.sum(c * vt_ref[:k], axis=1))
+    assert (1.0 - dots).max() <= tol_v, (1.0 - dots).max()
+    assert np.abs(c @ c.T - np.eye(k)).max() <= (1e-10 if dtype == np.float64 else 2e-5)
+
+
 def test_ica_parity(ctx):
     pc.ica_par_parity(ctx, 20000, 8, seed=8, dtype=np.float32, tol=1e-4)   # MFMA fused step
     pc.ica_par_parity(ctx, 3000, 5, seed=9, dtype=np.float64, tol=1e-8)    # generic fp64 step
