@@ -917,13 +917,27 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
 // May the product kernel write its n x cols result straight into the caller's matrix?  A device matrix of the same type with unit
 // column stride, no padding columns to drop (cols a multiple of 16) and 16-byte aligned rows: then there is no staging buffer and
 // no copy-out pass (1e6 x 64 floats: 0.15 ms of a 0.9 ms transform).  The shape / type checks of emit() are made here as well.
-static bool writes_in_place(const petal_matrix& out, int dtype, int64_t n, int64_t cols) {
+static bool writes_in_place(const petal_matrix& out, int dtype, int64_t n, int64_t cols, const petal_matrix& in) {
     check_matrix(out, "output");
     if (out.dtype != dtype) invalid_input("output dtype differs from input dtype");
     if (out.rows != n || out.cols != cols) invalid_input("output has the wrong shape");
     const size_t esz = dtype_size(dtype);
-    return out.space == PETAL_DEVICE && n > 0 && cols > 0 && cols % 16 == 0 && out.col_stride == 1 && out.row_stride >= cols &&
-           (size_t(out.row_stride) * esz) % 16 == 0 && (reinterpret_cast<uintptr_t>(out.data) & 15) == 0;
+    if (!(out.space == PETAL_DEVICE && n > 0 && cols > 0 && cols % 16 == 0 && out.col_stride == 1 && out.row_stride >= cols &&
+          (size_t(out.row_stride) * esz) % 16 == 0 && (reinterpret_cast<uintptr_t>(out.data) & 15) == 0))
+        return false;
+    // (an output that overlaps the input keeps the staged form: the product would read rows it has already overwritten)
+    if (in.space == PETAL_DEVICE && in.rows > 0 && in.cols > 0) {
+        const auto span = [&](const petal_matrix& m, uintptr_t& lo, uintptr_t& hi) {
+            const int64_t last = (m.rows - 1) * std::abs(m.row_stride) + (m.cols - 1) * std::abs(m.col_stride) + 1;
+            const uintptr_t p0 = reinterpret_cast<uintptr_t>(m.data), ext = size_t(last) * dtype_size(m.dtype);
+            lo = (m.row_stride < 0 || m.col_stride < 0) ? p0 - std::min<uintptr_t>(p0, ext) : p0;   // (a reversed view reaches below its base)
+            hi = p0 + ext;
+        };
+        uintptr_t alo, ahi, blo, bhi;
+        span(in, alo, ahi); span(out, blo, bhi);
+        if (alo < bhi && blo < ahi) return false;
+    }
+    return true;
 }
 // k x d components (the caller's type, row-major) -> the fp64 operand the product kernels take: P[i][j] = comp[j][i] (transposed = true,
 // dp x kp) or P[j][i] = comp[j][i] (kp x dp), zero padded
@@ -944,7 +958,7 @@ void transform(petal_ctx& c, const petal_matrix& x, const void* components, cons
     if (x.rows == 0 || k == 0) { emit(c, dt, nullptr, x.rows, k, 0, y_out); return; }
     DevMat X = ingest(c, x);
     const int64_t dp = X.dp, kp = round_up(k, 16);
-    const bool in_place = writes_in_place(y_out, dt, X.n, k);
+    const bool in_place = writes_in_place(y_out, dt, X.n, k, x);
     // (operands through the pinned ring, queued: no host wait in front of the product)
     const std::vector<double> hP = components_operand(components, dt, k, d, dp, kp, true);
     DBuf P(c.dev, sizeof(double) * dp * kp), muT(c.dev, dtype_size(dt) * dp);
@@ -969,7 +983,7 @@ void inverse_transform(petal_ctx& c, const petal_matrix& y, const void* componen
     if (y.rows == 0 || d == 0) { emit(c, dt, nullptr, y.rows, d, 0, x_out); return; }
     DevMat Y = ingest(c, y);  // n x kp
     const int64_t kp = Y.dp, dp = round_up(d, 16);
-    const bool in_place = writes_in_place(x_out, dt, Y.n, d);
+    const bool in_place = writes_in_place(x_out, dt, Y.n, d, y);
     const std::vector<double> hP = components_operand(components, dt, k, d, kp, dp, false);
     DBuf P(c.dev, sizeof(double) * kp * dp), muT(c.dev, dtype_size(dt) * dp);
     dev_h2d_async(c.dev, P.p, hP.data(), P.bytes);

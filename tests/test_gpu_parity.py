@@ -788,3 +788,32 @@ def test_no_kernel_reads_uninitialised_workspace():
                           "kats or gemm_kernels_exact or rpca_parity or ica_parity or edge_cases or rank_deficient or cfg5"],
                          capture_output=True, text=True, env=env, timeout=1500)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+
+
+def test_transform_into_a_view_that_overlaps_its_input(ctx):
+    """transform writes straight into the caller's device matrix when its layout allows (a multiple of 16 columns, aligned rows) --
+    unless that matrix overlaps the input: then the staged form runs, and the result equals the non-overlapping call's."""
+    import torch
+    import petal_decomposition_amd as petal
+    from synth_data import synth_pca
+    n, d, k = 4096, 64, 16
+    x = torch.from_numpy(synth_pca(n, d, k, seed=9, dtype=np.float32)).cuda()
+    m = petal.RandomizedPcaBuilder.new(k).seed(3).context(ctx).build()
+    m.fit(x)
+    ref = m.transform(x).cpu().numpy()
+    lib, h = ctx.lib, ctx._h
+    import ctypes as C
+    buf = torch.empty(n * d + n * k, dtype=torch.float32, device="cuda")
+    xin = buf[: n * d].view(n, d); xin.copy_(x)
+    comp = np.ascontiguousarray(m.components(), dtype=np.float32); mu = np.ascontiguousarray(m.mean(), dtype=np.float32)
+    for start in (n * d, n * d - 64):          # behind the input; overlapping its last rows
+        y = buf[start: start + n * k].view(n, k)
+        keep = []
+        mx, my = petal.describe(xin, keep), petal.describe(y, keep)
+        ctx.check(lib.petal_transform(h, C.byref(mx), comp.ctypes.data, mu.ctypes.data, k, d, 1, C.byref(my)))
+        out = y.cpu().numpy()
+        if start == n * d:
+            assert np.array_equal(out, ref)
+        else:                                   # the input was partly overwritten by the copy-out, AFTER the product had read it
+            assert np.array_equal(out, ref)
+            xin.copy_(x)
