@@ -81,9 +81,9 @@ void op_pack_strided(Dev*, int dt, const void* src, int64_t n, int64_t d, int64_
         for (int64_t j = 0; j < d_pad; ++j) st(dst, dt, i * ld_dst + j, j < d ? ld(src, dt, i * rs + j * cs) : 0.0);
 }
 void op_unpack_strided(Dev*, int dt, const void* src, int64_t n, int64_t d, int64_t ld_src, void* dst, int64_t rs,
-                       int64_t cs) {
+                       int64_t cs, const double* scale) {
     for (int64_t i = 0; i < n; ++i)
-        for (int64_t j = 0; j < d; ++j) st(dst, dt, i * rs + j * cs, ld(src, dt, i * ld_src + j));
+        for (int64_t j = 0; j < d; ++j) st(dst, dt, i * rs + j * cs, ld(src, dt, i * ld_src + j) * (scale ? scale[j] : 1.0));
 }
 void op_colsum(Dev*, int dt, const void* X, int64_t n, int64_t d, int64_t ldx, double* out, bool with_sq) {
     for (int64_t j = 0; j < (with_sq ? 2 * d : d); ++j) out[j] = 0;

@@ -446,16 +446,17 @@ DevMat ingest(petal_ctx& c, const petal_matrix& x) {
     return m;
 }
 
-void emit(petal_ctx& c, int dtype, const void* src, int64_t n, int64_t cols, int64_t ld, const petal_matrix& out) {
+void emit(petal_ctx& c, int dtype, const void* src, int64_t n, int64_t cols, int64_t ld, const petal_matrix& out, const double* scale) {
     check_matrix(out, "output");
     if (out.dtype != dtype) invalid_input("output dtype differs from input dtype");
     if (out.rows != n || out.cols != cols) invalid_input("output has the wrong shape");
     if (n == 0 || cols == 0) return;
     const size_t esz = dtype_size(dtype);
-    if (out.space == PETAL_DEVICE) {
-        op_unpack_strided(c.dev, dtype, src, n, cols, ld, out.data, out.row_stride, out.col_stride);
+    if (out.space == PETAL_DEVICE) {   // (scale: a per-column factor applied on the way out, device array of `cols` doubles)
+        op_unpack_strided(c.dev, dtype, src, n, cols, ld, out.data, out.row_stride, out.col_stride, scale);
         return;
     }
+    if (scale) op_scale_cols(c.dev, dtype, const_cast<void*>(src), n, cols, ld, scale);
     if ((out.col_stride == 1 || cols == 1) && out.row_stride >= cols) {
         dev_copy2d(c.dev, out.data, size_t(out.row_stride) * esz, src, size_t(ld) * esz, size_t(cols) * esz, size_t(n), 1);
         dev_sync(c.dev);
@@ -758,8 +759,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         for (int64_t j = 0; j < k; ++j) sc[j] = sg[j] * hs[j];
         DBuf dsc(c.dev, sizeof(double) * LP);
         dev_h2d(c.dev, dsc.p, sc.data(), dsc.bytes);
-        op_scale_cols(c.dev, dt, Uout, n, k, LP, dsc.f64());
-        emit(c, dt, Uout, n, k, LP, *y_out);
+        emit(c, dt, Uout, n, k, LP, *y_out, dsc.f64());
     }
     if (host_tl) std::fprintf(stderr, "rpca_fit host: queued %.1f us, synced %.1f us, done %.1f us\n", t_q * 1e3, t_s * 1e3, timer.ms() * 1e3);
     finish_stats(c, timer);
@@ -906,8 +906,7 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
         for (int64_t j = 0; j < k; ++j) sc[j] = sg[j] * hs[j];
         DBuf dsc(c.dev, sizeof(double) * rp);
         dev_h2d(c.dev, dsc.p, sc.data(), dsc.bytes);
-        op_scale_cols(c.dev, dt, U.p, n, k, rp, dsc.f64());
-        emit(c, dt, U.p, n, k, rp, *y_out);
+        emit(c, dt, U.p, n, k, rp, *y_out, dsc.f64());
     }
     finish_stats(c, timer);
 }

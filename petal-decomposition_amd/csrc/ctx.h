@@ -80,7 +80,7 @@ struct DevMat {
 
 // host algorithms (algo.cpp)
 DevMat ingest(petal_ctx& c, const petal_matrix& x);
-void   emit(petal_ctx& c, int dtype, const void* src, int64_t n, int64_t cols, int64_t ld, const petal_matrix& out);
+void   emit(petal_ctx& c, int dtype, const void* src, int64_t n, int64_t cols, int64_t ld, const petal_matrix& out, const double* scale = nullptr);   // scale: device, cols doubles (per-column factor on the way out)
 void   allreduce_f64(petal_ctx& c, double* dev_buf, int64_t count, int op);
 
 void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversample, int64_t n_iter, bool centering,

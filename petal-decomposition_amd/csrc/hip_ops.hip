@@ -527,6 +527,22 @@ __global__ void k_unpack_strided(const T* __restrict__ src, int64_t n, int64_t d
     if (j >= d) return;
     dst[i * rs + j * cs] = src[i * ld + j];
 }
+// the same over a flattened index -- a thread per element, consecutive threads along a row, 1024 elements per workgroup -- with
+// an optional per-column factor (fit_transform's sigma_j and svd_flip sign, applied in fp64 as k_scale_cols does).  The row-per-
+// workgroup form above launches n workgroups of mostly idle lanes: 1e6 x 64 took 0.25 ms for the scaling and the copy-out each.
+template <class T>
+__global__ __launch_bounds__(256) void k_unpack_scaled(const T* __restrict__ src, int64_t n, int64_t d, int64_t ld, T* __restrict__ dst,
+                                                       int64_t rs, int64_t cs, const double* __restrict__ scale) {
+    const int64_t total = n * d;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t e = ((int64_t)blockIdx.x * 4 + u) * 256 + threadIdx.x;
+        if (e >= total) return;
+        const int64_t i = e / d, j = e - i * d;
+        const T v = src[i * ld + j];
+        dst[i * rs + j * cs] = scale ? (T)((double)v * scale[j]) : v;
+    }
+}
 
 // Column scans over a tall row-major matrix, first stage: block = 64 column lanes x 4 row lanes over `rows` rows (the
 // loads of a thread are independent: many in flight), row lanes combined through LDS in fixed order.
@@ -5230,10 +5246,18 @@ void op_pack_strided(Dev* d, int dt, const void* src, int64_t n, int64_t dd, int
                                       (const T*)src, n, dd, rs, cs, (T*)dst, ld, dpad));
     launch_check();
 }
-void op_unpack_strided(Dev* d, int dt, const void* src, int64_t n, int64_t dd, int64_t ld, void* dst, int64_t rs, int64_t cs) {
+void op_unpack_strided(Dev* d, int dt, const void* src, int64_t n, int64_t dd, int64_t ld, void* dst, int64_t rs, int64_t cs,
+                       const double* scale) {
     if (n == 0 || dd == 0) return;
-    DISPATCH_T(dt, hipLaunchKernelGGL(k_unpack_strided<T>, dim3((unsigned)n, cdiv(dd, 256)), dim3(256), 0, d->stream,
-                                      (const T*)src, n, dd, ld, (T*)dst, rs, cs));
+    const int64_t blocks = (n * dd + 1023) / 1024;
+    if (blocks < (int64_t(1) << 31)) {
+        DISPATCH_T(dt, hipLaunchKernelGGL(k_unpack_scaled<T>, dim3((unsigned)blocks), dim3(256), 0, d->stream, (const T*)src, n, dd, ld,
+                                          (T*)dst, rs, cs, scale));
+    } else {
+        if (scale) op_scale_cols(d, dt, const_cast<void*>(src), n, dd, ld, scale);
+        DISPATCH_T(dt, hipLaunchKernelGGL(k_unpack_strided<T>, dim3((unsigned)n, cdiv(dd, 256)), dim3(256), 0, d->stream,
+                                          (const T*)src, n, dd, ld, (T*)dst, rs, cs));
+    }
     launch_check();
 }
 

@@ -70,7 +70,7 @@ void op_pack_strided(Dev*, int dtype, const void* src, int64_t n, int64_t d, int
                      void* dst, int64_t ld_dst, int64_t d_pad);
 // dst[i*rs + j*cs] = src[i*ld_src + j] (device -> device scatter), j < d
 void op_unpack_strided(Dev*, int dtype, const void* src, int64_t n, int64_t d, int64_t ld_src,
-                       void* dst, int64_t rs, int64_t cs);
+                       void* dst, int64_t rs, int64_t cs, const double* scale = nullptr);   // scale (device, d doubles): dst = src * scale[j]
 // out[j] = sum_i X[i][j]  (fp64, deterministic order)
 // with_sq: out has 2 d entries, [column sums | column sums of squares]
 void op_colsum(Dev*, int dtype, const void* X, int64_t n, int64_t d, int64_t ldx, double* out, bool with_sq = false);
