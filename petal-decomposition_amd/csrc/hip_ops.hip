@@ -527,6 +527,19 @@ __global__ void k_unpack_strided(const T* __restrict__ src, int64_t n, int64_t d
     if (j >= d) return;
     dst[i * rs + j * cs] = src[i * ld + j];
 }
+// (flattened like k_unpack_scaled below: a device input whose width is not a multiple of 16 is copied into the padded layout)
+template <class T>
+__global__ __launch_bounds__(256) void k_pack_flat(const T* __restrict__ src, int64_t n, int64_t d, int64_t rs, int64_t cs, T* __restrict__ dst,
+                                                   int64_t ld, int64_t dpad) {
+    const int64_t total = n * dpad;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t e = ((int64_t)blockIdx.x * 4 + u) * 256 + threadIdx.x;
+        if (e >= total) return;
+        const int64_t i = e / dpad, j = e - i * dpad;
+        dst[i * ld + j] = j < d ? src[i * rs + j * cs] : T(0);
+    }
+}
 // the same over a flattened index -- a thread per element, consecutive threads along a row, 1024 elements per workgroup -- with
 // an optional per-column factor (fit_transform's sigma_j and svd_flip sign, applied in fp64 as k_scale_cols does).  The row-per-
 // workgroup form above launches n workgroups of mostly idle lanes: 1e6 x 64 took 0.25 ms for the scaling and the copy-out each.
@@ -5242,8 +5255,14 @@ __global__ void k_ica_big_out(const double* __restrict__ GXp, const double* __re
 void op_pack_strided(Dev* d, int dt, const void* src, int64_t n, int64_t dd, int64_t rs, int64_t cs, void* dst, int64_t ld,
                      int64_t dpad) {
     if (n == 0 || dpad == 0) return;
-    DISPATCH_T(dt, hipLaunchKernelGGL(k_pack_strided<T>, dim3((unsigned)n, cdiv(dpad, 256)), dim3(256), 0, d->stream,
-                                      (const T*)src, n, dd, rs, cs, (T*)dst, ld, dpad));
+    const int64_t blocks = (n * dpad + 1023) / 1024;
+    if (blocks < (int64_t(1) << 31)) {
+        DISPATCH_T(dt, hipLaunchKernelGGL(k_pack_flat<T>, dim3((unsigned)blocks), dim3(256), 0, d->stream, (const T*)src, n, dd, rs, cs,
+                                          (T*)dst, ld, dpad));
+    } else {
+        DISPATCH_T(dt, hipLaunchKernelGGL(k_pack_strided<T>, dim3((unsigned)n, cdiv(dpad, 256)), dim3(256), 0, d->stream,
+                                          (const T*)src, n, dd, rs, cs, (T*)dst, ld, dpad));
+    }
     launch_check();
 }
 void op_unpack_strided(Dev* d, int dt, const void* src, int64_t n, int64_t dd, int64_t ld, void* dst, int64_t rs, int64_t cs,
