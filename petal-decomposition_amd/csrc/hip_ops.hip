@@ -5812,7 +5812,13 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     // (at 100000 rows the extra 128 slabs cost k_sum_parts2 what the kernel gains: two per CU only for long row ranges)
     const int waves_target = waves_env > 0 ? waves_env : num_cu2 * ((gemm_split_product(d) && !muB && n >= 400000) ? 8 : 4);
     int64_t nsplit = std::max<int64_t>(1, waves_target / mslices);
-    nsplit = std::min<int64_t>(nsplit, 256);  // bounds the partial-slab traffic of narrow (Gram) products
+    // A NARROW A (at most 128 columns) takes smaller workgroups -- four waves of 32 columns, two for 64 columns -- instead of eight
+    // waves of which most would re-load and re-multiply the clamped last columns (1e6 x 64: 2.3 TB/s); more row chunks keep the
+    // chip filled with them (their slabs are small)
+    const int NTall = int(N / 16);
+    const int narrow_wv = (gemm_split_product(d) && !muB && getenv("PETAL_K2_NO_NARROW") == nullptr)
+                              ? ((M <= 64 && NTall <= 4) ? 2 : ((M <= 128 && NTall <= 8) ? 4 : 0)) : 0;
+    nsplit = std::min<int64_t>(nsplit, narrow_wv ? 256 * (8 / narrow_wv) : 256);  // bounds the partial-slab traffic of narrow (Gram) products
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 64));
     const bool split3_mode = gemm_split_product(d) && !muB && n >= 32 * nsplit;
     const int64_t cq = split3_mode ? 32 : 16;  // rows per pipeline stage
@@ -5836,6 +5842,37 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
         // at 100000 x 512 that form takes 55.4 us where four 64-column waves took 57.4 (at 1e6 rows it is the slower one,
         // 0.544 vs 0.533 ms)
         const bool wv8 = M >= 512 && nsplit * mslices >= (int64_t)num_cu2 * 8;
+        if (split3_mode && narrow_wv) {
+            const dim3 grid(8 * cdiv(M, 32 * narrow_wv), (unsigned)cdiv(nsplit, 8)), block(64 * narrow_wv);
+#define ATB3N_LAUNCH(NTv, WVv)                                                                                                        \
+            do {                                                                                                                      \
+                if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, WVv, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
+                else hipLaunchKernelGGL((k_atb3<NTv, false, WVv, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
+            } while (0)
+            if (narrow_wv == 2) {
+                switch (w) {
+                    case 4: ATB3N_LAUNCH(4, 2); break;
+                    case 3: ATB3N_LAUNCH(3, 2); break;
+                    case 2: ATB3N_LAUNCH(2, 2); break;
+                    default: ATB3N_LAUNCH(1, 2); break;
+                }
+            } else {
+                switch (w) {
+                    case 8: ATB3N_LAUNCH(8, 4); break;
+                    case 7: ATB3N_LAUNCH(7, 4); break;
+                    case 6: ATB3N_LAUNCH(6, 4); break;
+                    case 5: ATB3N_LAUNCH(5, 4); break;
+                    case 4: ATB3N_LAUNCH(4, 4); break;
+                    case 3: ATB3N_LAUNCH(3, 4); break;
+                    case 2: ATB3N_LAUNCH(2, 4); break;
+                    default: ATB3N_LAUNCH(1, 4); break;
+                }
+            }
+#undef ATB3N_LAUNCH
+            launch_check();
+            nt0 += w;
+            continue;
+        }
         if (split3_mode && (w >= 6 || !wv8)) {
             const dim3 grid(8 * cdiv(M, 256), (unsigned)cdiv(nsplit, 8)), block(512);   // 8 waves x 32 columns per workgroup
 #define ATB3W_LAUNCH(NTv)                                                                                                             \
