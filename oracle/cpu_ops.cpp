@@ -18,7 +18,7 @@
 
 namespace petal {
 
-struct Dev { int tag = 0; };
+struct Dev { int tag = 0; int gemm_mode = 1; };
 
 Dev* dev_create(int, void*, char*, size_t) { return new Dev(); }
 void dev_destroy(Dev* d) { delete d; }
@@ -33,7 +33,11 @@ void dev_memset(Dev*, void* p, int v, size_t bytes) { std::memset(p, v, bytes); 
 void dev_h2d(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
 void dev_h2d_async(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
 void dev_d2h(Dev*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
-const void* dev_d2h_view(Dev*, const void* src, size_t) { return src; }
+size_t dev_view_limit(Dev*) { return size_t(8) << 20; }   // the device library's ring slot: the same limit, so the CPU suite sees a caller that ignores it
+const void* dev_d2h_view(Dev* d, const void* src, size_t bytes) {
+    if (bytes > dev_view_limit(d)) throw std::logic_error("dev_d2h_view: larger than a ring slot");
+    return src;
+}
 const void* dev_h2d_view(Dev*, const void* src, size_t) { return src; }
 void dev_d2h_multi(Dev*, int nseg, void* const* dst, const void* const* src, const size_t* bytes) { for (int i = 0; i < nseg; ++i) if (bytes[i]) std::memcpy(dst[i], src[i], bytes[i]); }
 void dev_d2d(Dev*, void* dst, const void* src, size_t bytes) { std::memmove(dst, src, bytes); }
@@ -47,8 +51,8 @@ void dev_abort(Dev*) {}
 void dev_make_current(Dev*) {}
 int dev_push_current(Dev*) { return -1; }
 void dev_pop_current(Dev*, int) {}
-void dev_set_gemm_mode(Dev*, int) {}
-int dev_gemm_mode(const Dev*) { return 1; }
+void dev_set_gemm_mode(Dev* d, int mode) { d->gemm_mode = mode; }   // 0: the split-product mode's two-plane roundings are simulated
+int dev_gemm_mode(const Dev* d) { return d->gemm_mode; }
 void dev_reset_timing(Dev*) {}
 void dev_set_tag(Dev* d, int tag) { d->tag = tag; }
 void dev_fork(Dev*, bool) {}
@@ -94,8 +98,28 @@ void op_colsum(Dev*, int dt, const void* X, int64_t n, int64_t d, int64_t ldx, d
             if (with_sq) out[d + j] += v * v;
         }
 }
-void op_gemm_xp(Dev*, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P,
-                int64_t N, int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, int) {
+// the sum of the two leading bf16 pieces of (float)v, round-to-nearest-even each (hip_ops.hip: k_trsm_pack<NB, true>, k_xp3<NPL = 2>)
+static double two_plane(double v) {
+    auto bf = [](float f) {
+        uint32_t u; std::memcpy(&u, &f, 4);
+        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+        float r; std::memcpy(&r, &u, 4); return r;
+    };
+    const float f = float(v), h = bf(f), m = bf(f - h);
+    return double(h) + double(m);
+}
+void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P0,
+                int64_t N, int64_t ldp0, const void* bias, void* Z, int64_t ldz, double* sumsq, int p_planes) {
+    // (split-product mode, fp32 data: a caller that accepts a two-plane P gets one, as on the device)
+    std::vector<double> p2;
+    const double* P = P0;
+    int64_t ldp = ldp0;
+    if (p_planes == 2 && dt == F32 && d->gemm_mode == 0 && !sumsq) {
+        p2.resize(size_t(K) * N);
+        for (int64_t k = 0; k < K; ++k)
+            for (int64_t j = 0; j < N; ++j) p2[k * N + j] = two_plane(P0[k * ldp0 + j]);
+        P = p2.data(); ldp = N;
+    }
     std::vector<double> row(K), acc(N);
     double ss = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -422,6 +446,13 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
                   int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
                   double* P_out, int64_t ldpo, void* Z, int64_t ldz) {
     op_chol_inv(d, G, L, ldg, T, ldt, rel_tol, ndead, M);
+    if (dt == F32 && d->gemm_mode == 0) {   // the two-plane iterate: P_out itself is rounded, every later use sees it
+        op_dgemm(d, false, false, K, M, M, 1.0, A, lda, T, ldt, 0.0, P_out, ldpo);
+        for (int64_t k = 0; k < K; ++k)
+            for (int64_t j = 0; j < M; ++j) P_out[k * ldpo + j] = two_plane(P_out[k * ldpo + j]);
+        op_gemm_xp(d, dt, X, n, K, ldx, mu, P_out, M, ldpo, nullptr, Z, ldz, nullptr);
+        return;
+    }
     op_gemm_xp_prod(d, dt, X, n, K, ldx, mu, A, M, lda, T, M, ldt, P_out, ldpo, Z, ldz);
 }
 

@@ -703,15 +703,23 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     for (int attempt = 0; attempt < 2; ++attempt) {
         pipeline(attempt == 1);
         if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip, true, attempt == 0 ? ndead : nullptr);
-        hres = static_cast<const double*>(dev_d2h_view(c.dev, tvp, sizeof(double) * hres_len + comp_bytes));
+        // (one view for both while they fit a ring slot; large components -- k = 128 at d = 16384, k = 512 at d = 4096 -- leave by a
+        // plain copy of their own and only the small block is viewed: ADVICE round 4)
+        const bool one_view = sizeof(double) * hres_len + comp_bytes <= dev_view_limit(c.dev);
+        hres = static_cast<const double*>(dev_d2h_view(c.dev, tvp, sizeof(double) * hres_len + (one_view ? comp_bytes : 0)));
         hcomp = hres + hres_len;
+        if (!one_view) {
+            comp_keep.resize(comp_bytes);
+            dev_d2h(c.dev, comp_keep.data(), comp_dev, comp_bytes);
+            hcomp = comp_keep.data();
+        }
         t_q = timer.ms();
         dev_sync(c.dev);
         t_s = timer.ms();
         // (the sharded fp64 path queues more copies through the ring below -- agree_any(), flip_signs(): it takes everything out
         // first; the small block is copied on every path)
         keep.assign(hres, hres + hres_len);
-        if (sharded(c) && !flip_slot_keys(c, dt)) {
+        if (one_view && sharded(c) && !flip_slot_keys(c, dt)) {
             comp_keep.assign(static_cast<const char*>(hcomp), static_cast<const char*>(hcomp) + comp_bytes);
             hcomp = comp_keep.data();
         }

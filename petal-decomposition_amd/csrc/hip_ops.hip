@@ -276,10 +276,12 @@ void dev_h2d(Dev* d, void* dst, const void* src, size_t bytes) {
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));  // callers pass short-lived pageable buffers
 }
-static void drain_pending(Dev* d) {
+// recycle = false: hand the finished copies over but keep every ring slot (a side stream may still have a queued transfer that
+// reads one: dev_sync between dev_fork_end and dev_join only waits for the main stream -- ADVICE round 4)
+static void drain_pending(Dev* d, bool recycle = true) {
     for (auto& p : d->pend) std::memcpy(p.dst, d->pin + p.off, p.bytes);
     d->pend.clear();
-    d->pin_used = 0;
+    if (recycle) d->pin_used = 0;
 }
 constexpr size_t PIN_MAX_COPY = size_t(8) << 20, PIN_RING = size_t(32) << 20;
 // Small results leave through a KERNEL that stores them straight into the pinned ring (device-visible host memory, posted writes over
@@ -424,9 +426,10 @@ void dev_copy2d(Dev* d, void* dst, size_t dpitch, const void* src, size_t spitch
     HIP_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, k, d->stream));
     if (kind == 0) HIP_CHECK(hipStreamSynchronize(d->stream));
 }
+size_t dev_view_limit(Dev*) { return PIN_MAX_COPY; }
 void dev_sync(Dev* d) {
     HIP_CHECK(hipStreamSynchronize(d->stream));
-    drain_pending(d);
+    drain_pending(d, /*recycle=*/!d->forked);
     if (!d->forked) {   // every block released so far has no user left anywhere
         for (auto& kv : d->free_list) d->free_cold.emplace(kv.first, kv.second);
         d->free_list.clear();
@@ -5502,8 +5505,11 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         const int64_t nch = (K + 31) / 32, total = nch * NTtot * 64;
         bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
         // two-plane P (five piece products) where P is the re-based iterate of a power iteration: k_trsm_pack rounds it so
+        // (development / test knobs: PETAL_NO_P2 keeps three planes everywhere, PETAL_NO_P2_ITERATE for the re-based iterate only,
+        // PETAL_NO_P2_OMEGA for the sketch matrix only)
         static const bool no_p2 = getenv("PETAL_NO_P2") != nullptr;
-        const bool p2 = ((prod_A && prod_rt) || (!prod_A && p2_hint)) && !am && !no_p2;
+        static const bool no_p2_it = no_p2 || getenv("PETAL_NO_P2_ITERATE") != nullptr, no_p2_om = no_p2 || getenv("PETAL_NO_P2_OMEGA") != nullptr;
+        const bool p2 = ((prod_A && prod_rt && !no_p2_it) || (!prod_A && p2_hint && !no_p2_om)) && !am;
         if (prod_A) {
             // P = prod_A . P: the fp64 GEMM kernel writes the product (prod_out) AND its operand planes from its epilogue
             if (prod_rt)   // P is R in RT form: blocked triangular solve instead of the product with the explicit inverse

@@ -38,6 +38,7 @@ void  dev_d2h(Dev*, void* dst, const void* src, size_t bytes);  // dst is valid 
 void  dev_d2h_multi(Dev*, int nseg, void* const* dst, const void* const* src, const size_t* bytes);   // several dev_d2h in one launch (nseg <= 8)
 const void* dev_h2d_view(Dev*, const void* src, size_t bytes);   // host bytes staged in the pinned ring; returns its device-visible address (nullptr: too large), valid until the next dev_sync
 const void* dev_d2h_view(Dev*, const void* src, size_t bytes);   // the result where the copy lands (pinned ring): readable after the next dev_sync, until the next copy is queued
+size_t dev_view_limit(Dev*);                                     // the largest dev_d2h_view / dev_h2d_view (one ring slot); dev_d2h_view THROWS above it
 void  dev_d2d(Dev*, void* dst, const void* src, size_t bytes);
 // pitched copies (bytes); kind: 0 h2d, 1 d2h, 2 d2d
 void  dev_copy2d(Dev*, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int kind);

@@ -204,23 +204,55 @@ def gemm_exact(ctx, n, K, N, seed=0, device=False, dtype=np.float32):
 
 
 # ---- model parity against the oracle on seeded synthetic inputs -----------------------------------
-def rpca_parity(ctx, n, d, k, n_iter, seed, dtype=np.float32, tol=1e-5, device=False, centering=True, tol_sigma=None):
-    """same X, same Omega, same n_iter: fp64 LAPACK oracle vs the library (BASELINE.md parity metric)"""
-    x = po.synth_pca(n, d, k, seed=seed, dtype=dtype)
-    om = np.random.default_rng(seed + 1000).standard_normal((d, k + 10))
-    o = po.RandomizedPcaOracle(k, centering=centering, n_iter=n_iter)
+def decided_signs(u, k, margin=1e-3):
+    """columns j < k of the oracle's U (after svd_flip, pca.rs:826-839) whose deciding element is NOT a near-tie: the largest |u|
+    of the column leads the runner-up by more than `margin` (relative), so a library whose U agrees to ~1e-5 must pick the same
+    element -- and therefore the same sign for component j"""
+    a = np.abs(np.asarray(u[:, :k], dtype=np.float64))
+    if a.shape[0] < 2:
+        return np.ones(k, dtype=bool)
+    top2 = np.partition(a, a.shape[0] - 2, axis=0)[-2:]
+    return top2[0] < (1.0 - margin) * top2[1]
+
+
+def rpca_parity(ctx, n, d, k, n_iter, seed, dtype=np.float32, tol=1e-5, device=False, centering=True, tol_sigma=None, x=None,
+                n_oversample=10, graded=False):
+    """same X, same Omega, same n_iter: fp64 LAPACK oracle vs the library (BASELINE.md parity metric).  Signs are compared too
+    (svd_flip, pca.rs:815-850) wherever the element that decides them is not a near-tie in the oracle's U."""
+    if x is None:
+        x = po.synth_pca(n, d, k, seed=seed, dtype=dtype)
+    assert x.shape == (n, d) and x.dtype == dtype
+    om = np.random.default_rng(seed + 1000).standard_normal((d, k + n_oversample))
+    if dtype == np.float32:
+        om = om.astype(np.float32).astype(np.float64)   # the SAME Omega on both sides: the draw the library receives, widened exactly
+    o = po.RandomizedPcaOracle(k, centering=centering, n_iter=n_iter, n_oversample=n_oversample)
     uo = o._inner_fit(x.astype(np.float64), omega=om)
     yo = po.transform_with_u(uo, o.singular, k)
     xin = x
     if device:
         import torch
         xin = torch.from_numpy(x).cuda()
-    m = petal.RandomizedPca(k, centering=centering, ctx=ctx, n_iter=n_iter)
+    m = petal.RandomizedPca(k, centering=centering, ctx=ctx, n_iter=n_iter, n_oversample=n_oversample)
     y = m.fit_transform(xin, omega=om.astype(dtype))
     if device:
         y = y.cpu().numpy()
     rel = rowwise_rel(m.components().astype(np.float64), o.components)
+    if graded:
+        # n_iter = 0 on fp32 data with a WIDE spectrum: Z = Xc Omega is stored in fp32 with every column dominated by sigma_1, so
+        # direction j of Q = orth(Z) is only good to eps32 sigma_1 / sigma_j, and row j of B = Q^T Xc (whose error is again
+        # dominated by sigma_1) to eps32 (sigma_1 / sigma_j)^2 -- the crate's own f32 instantiation is in the same position; the
+        # fp64 oracle is not.  The tolerance follows that law per component (and the flat `tol` where it is the larger one).
+        amp = (o.singular[0] / np.maximum(o.singular, 1e-300)) ** 2
+        tol_rows = np.maximum(tol, 20 * 6e-8 * amp)
+        assert np.all(rel <= tol_rows), f"components rel-err / allowed {np.max(rel / tol_rows):.3e}"
+        assert np.all(np.abs(m.singular_values() / o.singular - 1) <= tol_rows)
+        tol = float(tol_rows.max())
+        tol_sigma = tol
     assert rel.max() <= tol, f"components rel-err {rel.max():.3e} > {tol}"
+    # svd_flip against the oracle's, un-aligned: every component whose deciding |u| is not a near-tie carries the oracle's sign
+    dec = decided_signs(uo, k, margin=min(0.5, max(1e-3, 100 * tol)))
+    sgn = np.sign(np.sum(m.components().astype(np.float64) * o.components, axis=1))
+    assert np.all(sgn[dec] == 1), f"svd_flip signs differ from the oracle's on decided components {np.nonzero(dec & (sgn != 1))[0]}"
     ts = tol if tol_sigma is None else tol_sigma   # (vectors of closely spaced singular values are less well determined than the values)
     assert np.allclose(m.singular_values(), o.singular, rtol=ts, atol=0), np.abs(m.singular_values() / o.singular - 1).max()
     assert np.allclose(m.explained_variance_ratio(), o.explained_variance_ratio(), rtol=4 * ts, atol=0)
@@ -236,14 +268,41 @@ def rpca_parity(ctx, n, d, k, n_iter, seed, dtype=np.float32, tol=1e-5, device=F
     return rel.max()
 
 
+def slow_decay_matrix(n, d, kind, seed, dtype=np.float32, mean=1.0):
+    """n x d data whose singular values decay SLOWLY over all min(n, d) directions -- 0.97^i ("geo97") or 1 / sqrt(i + 1)
+    ("rsqrt") -- so that a randomized fit with few power iterations is far from converged: what it returns then depends on
+    Omega and on every product of the pipeline, which is what a same-Omega parity test at n_iter 0 .. 2 has to see."""
+    rng = np.random.default_rng(seed)
+    r = min(n, d)
+    s = 0.97 ** np.arange(r) if kind == "geo97" else 1.0 / np.sqrt(np.arange(r) + 1.0)
+    u, _ = np.linalg.qr(rng.standard_normal((n, r)))
+    v, _ = np.linalg.qr(rng.standard_normal((d, r)))
+    return ((u * (s * 30.0)) @ v.T + mean * rng.standard_normal(d)).astype(dtype)
+
+
+def rpca_low_iter(ctx, n, d, k, n_iter, spectrum, dtype, seed, device=False, tol=None):
+    """RandomizedPca at n_iter 0, 1, 2 (pca.rs:701-716 with a short loop) against the oracle fed the SAME Omega.  n_iter = 0 is the
+    branch that orthonormalises the raw sketch (Cholesky-QR2, standing for linalg.rs:127-147); n_iter 1 - 2 have the least damping
+    behind any rounding of the sketch matrix."""
+    x = None if spectrum == "planted" else slow_decay_matrix(n, d, spectrum, seed, dtype)
+    if tol is None:
+        tol = 1e-5 if dtype == np.float32 else 1e-9
+    return rpca_parity(ctx, n, d, k, n_iter, seed, dtype=dtype, tol=tol, device=device, x=x,
+                       graded=(n_iter == 0 and spectrum == "planted" and dtype == np.float32))
+
+
 def pca_parity(ctx, n, d, k, seed, dtype=np.float64, tol=1e-9, thin_oracle=False):
     x = po.synth_pca(n, d, k, seed=seed, dtype=dtype)
     o = po.PcaOracle(k, thin=thin_oracle)
-    yo = o.fit_transform(x.astype(np.float64))
+    uo = o._inner_fit(x.astype(np.float64))
+    yo = po.transform_with_u(uo, o.singular, k)
     m = petal.Pca.new(k, ctx)
     y = m.fit_transform(x)
     rel = rowwise_rel(m.components().astype(np.float64), o.components)
     assert rel.max() <= tol, rel.max()
+    dec = decided_signs(uo, k, margin=min(0.5, max(1e-3, 100 * tol)))   # svd_flip (pca.rs:223) against the oracle's, un-aligned
+    sgn = np.sign(np.sum(m.components().astype(np.float64) * o.components, axis=1))
+    assert np.all(sgn[dec] == 1), f"svd_flip signs differ from the oracle's on decided components {np.nonzero(dec & (sgn != 1))[0]}"
     assert np.allclose(m.singular_values(), o.singular, rtol=tol)
     assert np.allclose(m.explained_variance_ratio(), o.explained_variance_ratio(), rtol=10 * tol)
     s = np.sign(np.sum(y.astype(np.float64) * yo, axis=0))

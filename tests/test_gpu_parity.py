@@ -60,6 +60,32 @@ def test_rpca_parity(ctx, n, d, k, n_iter):
     pc.rpca_parity(ctx, n, d, k, n_iter, seed=n % 97, tol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("spectrum", ["planted", "geo97", "rsqrt"])
+@pytest.mark.parametrize("n_iter", [0, 1, 2])
+def test_rpca_low_iteration_counts(ctx, n_iter, spectrum, dtype):
+    """The ABI exposes n_iter (the crate's constant 7, src/pca.rs:680); everything else in this file runs 4, 5 or 7.  n_iter = 0 is a
+    branch of its own -- Cholesky-QR2 of the raw sketch Z = Xc Omega, standing for the Householder QR of src/linalg.rs:127-147 --
+    and n_iter 1 - 2 have the least damping behind the split-product mode's 16-bit rounding of Omega (round 4).  Same X, same Omega
+    as the oracle, 1e-5 (fp64: 1e-9), on the planted spectrum and on two slow decays over ALL directions (0.97^i, 1 / sqrt(i)) where
+    a short iteration is far from converged and its output depends on every product; signs compared where decided."""
+    pc.rpca_low_iter(ctx, 4000, 256, 16, n_iter, spectrum, dtype, seed=300 + n_iter, device=(n_iter == 1))
+
+
+@pytest.mark.parametrize("n_iter", [0, 1, 2, 3])
+def test_rpca_low_iteration_counts_at_the_config_width(ctx, n_iter):
+    """the same at configs[1]'s width (d = 512, l = 74: five-tile panels, the fused kernels of the power iteration)"""
+    pc.rpca_low_iter(ctx, 20000, 512, 64, n_iter, "planted", np.float32, seed=310 + n_iter, device=True)
+    pc.rpca_low_iter(ctx, 20000, 512, 64, n_iter, "geo97", np.float32, seed=320 + n_iter, device=True)
+
+
+def test_components_beyond_a_ring_slot(ctx):
+    """k d esz above the 8 MiB slot of the pinned result ring (rpca_fit's single result view threw there, e.g.
+    k = 512 at d = 2048 fp64 or d = 4096 fp32): the components then leave by a copy of their own."""
+    pc.rpca_parity(ctx, 3000, 2048, 512, 4, seed=5, dtype=np.float64, tol=1e-7, device=True)
+    pc.rpca_parity(ctx, 3000, 4096, 512, 4, seed=6, dtype=np.float32, tol=2e-2, tol_sigma=2e-5, device=True)
+
+
 @pytest.mark.parametrize("k", [4, 20, 36, 52, 60, 84, 100, 116, 132])
 def test_rebasing_block_counts(ctx, k):
     """l = k + 10 padded to 16, 32, ... 144: every block count (1 .. 9) of the triangular-solve re-basing (`k_trsm_pack<NB>`, the
@@ -686,32 +712,35 @@ def test_results_through_the_copy_kernel_match_the_memcpy_path():
     ctx_k.close(); ctx_m.close()
 
 
-def test_two_plane_iterate_against_the_three_plane_fit():
-    """The re-based iterate of a power iteration is DEFINED as the sum of its two leading bf16 pieces (k_trsm_pack<NB, true>; the next
-    K1 then needs five piece products, not six).  Any basis of range(Yp) serves the iteration, so the fit must agree with the
-    three-plane fit (PETAL_NO_P2=1, read once per process: a child) far inside the parity bar -- and, being a different rounding
-    of the iterate, must not be bit-identical to it (or the two-plane path did not run).  Both against the oracle at 1e-5."""
+@pytest.mark.parametrize("knob,n_iter", [("PETAL_NO_P2_ITERATE", 5), ("PETAL_NO_P2_OMEGA", 5), ("PETAL_NO_P2_OMEGA", 1), ("PETAL_NO_P2", 2)])
+def test_two_plane_operands_against_the_three_plane_fit(knob, n_iter):
+    """Two operands of the split-product K1 are DEFINED as the sum of their two leading bf16 pieces (five piece products, not six):
+    the re-based iterate of a power iteration (k_trsm_pack<NB, true>) and, when power iterations follow, the sketch matrix Omega.
+    Any basis of range(Yp) serves the iteration, so each switch on its own (PETAL_NO_P2_ITERATE / PETAL_NO_P2_OMEGA keep that
+    operand at three planes; PETAL_NO_P2 both; read once per process: a child) must leave the fit far inside the parity bar -- and,
+    being a different rounding, must not be bit-identical (or the two-plane path did not run).  Both against the oracle at 1e-5,
+    the oracle fed the SAME Omega the library receives."""
     import os
     import subprocess
     import sys
     import tempfile
     import petal_decomposition_amd as petal
     from oracle import petal_oracle as po
-    n, d, k, n_iter = 20000, 512, 64, 5
+    n, d, k = 20000, 512, 64
     x = po.synth_pca(n, d, k, seed=11, dtype=np.float32)
-    om = np.random.default_rng(12).standard_normal((d, k + 10))
-    ref = po.RandomizedPcaOracle(k, n_iter=n_iter).fit(x.astype(np.float64), omega=om)
+    om = np.random.default_rng(12).standard_normal((d, k + 10)).astype(np.float32)
+    ref = po.RandomizedPcaOracle(k, n_iter=n_iter).fit(x.astype(np.float64), omega=om.astype(np.float64))
     ctx = petal.Context(0)
-    m = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter).fit(x, omega=om.astype(np.float32))
+    m = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter).fit(x, omega=om)
     c2, s2 = m.components().astype(np.float64), m.singular_values().astype(np.float64)
     ctx.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as tmp:
-        np.savez(os.path.join(tmp, "in.npz"), x=x, om=om.astype(np.float32))
+        np.savez(os.path.join(tmp, "in.npz"), x=x, om=om)
         code = ("import sys, numpy as np; sys.path.insert(0, %r); import petal_decomposition_amd as petal; c = petal.Context(0); "
                 "d = np.load(%r); m = petal.RandomizedPca(%d, ctx=c, n_iter=%d).fit(d['x'], omega=d['om']); "
                 "np.savez(%r, c=m.components(), s=m.singular_values())" % (root, os.path.join(tmp, "in.npz"), k, n_iter, os.path.join(tmp, "out.npz")))
-        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PETAL_NO_P2="1"), capture_output=True, text=True, timeout=600)
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{knob: "1"}), capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         out = np.load(os.path.join(tmp, "out.npz"))
         c3, s3 = out["c"].astype(np.float64), out["s"].astype(np.float64)

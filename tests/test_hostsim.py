@@ -28,6 +28,26 @@ def test_rpca_parity(ctx, n, d, k, n_iter):
     pc.rpca_parity(ctx, n, d, k, n_iter, seed=n)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("spectrum", ["planted", "geo97", "rsqrt"])
+@pytest.mark.parametrize("n_iter", [0, 1, 2])
+def test_rpca_low_iteration_counts(ctx, n_iter, spectrum, mode):
+    """n_iter 0 (the Cholesky-QR2 branch of the raw sketch), 1 and 2 against the oracle with the same Omega, with the
+    split-product mode's roundings of the sketch matrix and of the re-based iterate simulated (oracle/cpu_ops.cpp)"""
+    ctx.set_gemm_mode(mode)
+    try:
+        pc.rpca_low_iter(ctx, 1500, 96, 12, n_iter, spectrum, np.float32, seed=11 + n_iter)
+        pc.rpca_low_iter(ctx, 900, 64, 8, n_iter, spectrum, np.float64, seed=21 + n_iter)
+    finally:
+        ctx.set_gemm_mode("fp32")
+
+
+def test_components_beyond_a_ring_slot(ctx):
+    """k d esz above the 8 MiB ring slot (the single result view threw there): the components leave by their own
+    copy.  k = 512, d = 2048 fp64 = 8 MiB + the small block."""
+    pc.rpca_parity(ctx, 700, 2048, 512, 1, seed=5, dtype=np.float64, tol=1e-7)
+
+
 def test_rpca_f64_and_no_centering(ctx):
     pc.rpca_parity(ctx, 800, 32, 4, 7, seed=3, dtype=np.float64, tol=1e-9)
     pc.rpca_parity(ctx, 800, 32, 4, 7, seed=4, centering=False)
