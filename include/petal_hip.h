@@ -78,6 +78,11 @@ typedef struct petal_stats {
                                   padding per row when its natural pitch is a multiple of 1 KiB: spreads the rows over the
                                   memory channels; a device input that is streamed in place keeps the caller's pitch)      */
     int64_t x_zero_copy;       /* 1: the caller's device buffer was streamed in place                                       */
+    /* RandomizedPca: how the last fit ran */
+    int64_t rpca_redo;         /* 0: the optimistic run stood; 1: redone with three-plane operands (heavy-tailed spectrum: the
+                                  16-bit rounding of the sketch matrix / iterates was not harmless); 2: redone on the robust path */
+    double  pow_ms;            /* fused power-iteration pass Y' = Xc^T (Xc P) (one pass over X): summed kernel time           */
+    int64_t pow_launches;
 } petal_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */

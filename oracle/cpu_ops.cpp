@@ -151,7 +151,7 @@ void op_gemm_atb(Dev*, int dt, const void* A, int64_t lda, int64_t M, const void
     }
 }
 void op_flip_key(Dev*, const double* t, double* key, int64_t L, const int* flag) {
-    if (flag) key[L] = *flag != 0 ? 1.0 : 0.0;
+    if (flag) key[L] = flag[0] != 0 ? 2.0 : (flag[1] != 0 ? 1.0 : 0.0);
     for (int64_t j = 0; j < L; ++j) {
         uint64_t bits = 0;
         const double a = t[j] < 0 ? 0.0 : t[j];
@@ -444,9 +444,9 @@ void op_gemm_xp_prod_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K,
 }
 void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                   int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
-                  double* P_out, int64_t ldpo, void* Z, int64_t ldz) {
+                  double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes) {
     op_chol_inv(d, G, L, ldg, T, ldt, rel_tol, ndead, M);
-    if (dt == F32 && d->gemm_mode == 0) {   // the two-plane iterate: P_out itself is rounded, every later use sees it
+    if (dt == F32 && d->gemm_mode == 0 && p_planes == 2) {   // the two-plane iterate: P_out itself is rounded, every later use sees it
         op_dgemm(d, false, false, K, M, M, 1.0, A, lda, T, ldt, 0.0, P_out, ldpo);
         for (int64_t k = 0; k < K; ++k)
             for (int64_t j = 0; j < M; ++j) P_out[k * ldpo + j] = two_plane(P_out[k * ldpo + j]);
@@ -454,6 +454,22 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
         return;
     }
     op_gemm_xp_prod(d, dt, X, n, K, ldx, mu, A, M, lda, T, M, ldt, P_out, ldpo, Z, ldz);
+}
+
+void op_tail_verdict(Dev*, const double* lam, int64_t L, int64_t k, const double* mu_sq, int64_t dp, int64_t d, double n_total,
+                     const double* tv, double eps2, double thr, int* flag2) {
+    if (L <= 0 || k <= 0) return;
+    double total = tv ? *tv : 0.0, head = 0;
+    if (mu_sq) { total = 0; for (int64_t j = 0; j < d; ++j) total += std::max(0.0, mu_sq[dp + j] - n_total * mu_sq[j] * mu_sq[j]); }
+    for (int64_t j = 0; j < L; ++j) head += std::max(lam[j], 0.0);
+    const double T = std::sqrt(std::max(lam[L - 1], 0.0) * std::max(total - head, 0.0) / double(d));
+    for (int64_t j = 0; j < k && j < L; ++j) {
+        const double lj = lam[j];
+        if (!(lj > 0.0)) continue;
+        double gap = j + 1 < L ? lj - std::max(lam[j + 1], 0.0) : lj;
+        if (j > 0) gap = std::min(gap, lam[j - 1] - lj);
+        if (eps2 * T / lj / std::max(gap / lj, 1e-3) > thr) flag2[1] = 1;
+    }
 }
 
 // ---- FastICA ---------------------------------------------------------------------------------

@@ -66,7 +66,8 @@ class petal_stats(C.Structure):
                 ("n_iter", C.c_int64),
                 ("allreduce_calls", C.c_int64), ("allreduce_bytes", C.c_double),
                 ("allreduce_ms", C.c_double), ("allreduce_timed", C.c_int64),
-                ("x_row_pitch_bytes", C.c_int64), ("x_zero_copy", C.c_int64)]
+                ("x_row_pitch_bytes", C.c_int64), ("x_zero_copy", C.c_int64),
+                ("rpca_redo", C.c_int64), ("pow_ms", C.c_double), ("pow_launches", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

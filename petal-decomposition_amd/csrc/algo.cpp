@@ -140,16 +140,17 @@ void flip_signs_to_slot(petal_ctx& c, int dtype, const void* U, int64_t n, int64
 // The flags behind these decisions come from replicated kernels on all-reduced inputs and are expected to be bit-identical, but
 // "expected" is not a protocol: a one-rank disagreement would desynchronise the all-reduce sequence and hang the job.  Sharded
 // fits therefore branch on the MAX over the ranks (one 8-byte all-reduce + round trip; only on paths that already synchronise).
-bool agree_any(petal_ctx& c, bool local) {
+double agree_max(petal_ctx& c, double local) {
     if (!sharded(c)) return local;
     DBuf w(c.dev, sizeof(double));
-    double v = local ? 1.0 : 0.0;
+    double v = local;
     dev_h2d(c.dev, w.p, &v, sizeof(double));
     allreduce_f64(c, w.f64(), 1, PETAL_MAX);
     dev_d2h(c.dev, &v, w.p, sizeof(double));
     dev_sync(c.dev);
-    return v != 0.0;
+    return v;
 }
+bool agree_any(petal_ctx& c, bool local) { return agree_max(c, local ? 1.0 : 0.0) != 0.0; }
 std::vector<double> flip_signs(petal_ctx& c, int dtype, const void* U, int64_t n, int64_t L, int64_t ldu,
                                int64_t row_offset, std::vector<double>* deferred = nullptr) {
     std::vector<double> h(3 * L), sg(L, 1.0);
@@ -381,6 +382,8 @@ void finish_stats(petal_ctx& c, const Timer& t) {
     c.stats.atb_launches = kt.launches[TAG_ATB];
     c.stats.ica_step_ms = kt.ms[TAG_ICA];
     c.stats.ica_step_launches = kt.launches[TAG_ICA];
+    c.stats.pow_ms = kt.ms[TAG_POW];
+    c.stats.pow_launches = kt.launches[TAG_POW];
     c.stats.allreduce_ms = kt.ms[TAG_COMM];
     c.stats.allreduce_timed = kt.launches[TAG_COMM];
 }
@@ -518,6 +521,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     const int64_t n = X.n, dp = X.dp;
     const size_t esz = dtype_size(dt);
     const double tol_drop = (dt == F32 ? 1e-6 : 1e-13);
+    const double tol_tall = (dt == F32 ? 1e-12 : 1e-13);   // dependence test of the tall-side Gram matrices (fp64 products of the stored iterate)
 
     // Everything the host reads back sits in ONE device buffer behind the all-reduced [Yp | tv] pair, so a fit ends with one
     // device-to-host copy (five separate small copies cost 4 us each):
@@ -577,19 +581,44 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // The whole device pipeline.  It runs OPTIMISTICALLY first (robust = false): every power iteration re-bases with
     // the single-Cholesky fast path and no host round trip; the kernels record the worst pivot breakdown in `ndead`,
     // which is read together with the results.  Only if a breakdown happened is the fit redone with robust = true.
-    auto pipeline = [&](bool robust) {
-    if (robust) dev_memset(c.dev, tvp, 0, sizeof(double) * (2 + LP));  // tv, ndead, lam (only lam[0 .. L) is written below); the first run's were cleared with Omega
+    // Two operands of the split-product K1 may be ROUNDED to 16 significant bits (two bf16 planes: five piece products instead
+    // of six) -- the sketch matrix when power iterations follow, and the re-based iterates.  That is a change of basis plus a
+    // perturbation of the spanned subspace: harmless when the spectrum falls off behind the block (what the rounding injects from
+    // beyond the block is damped by every later product), NOT on slowly decaying spectra, where it costs parity with a run from
+    // the un-rounded Omega 10 - 80x (measured, EXPERIMENTS.md round 5).  So the first run uses them OPTIMISTICALLY (exact = false)
+    // and a verdict formed from the spectrum the fit itself found (op_tail_verdict) sends a heavy-tailed fit back through the
+    // pipeline with three planes everywhere (exact = true); the ctx remembers the verdict for its next fit.
+    const bool two_plane_applies = dt == F32 && dev_gemm_mode(c.dev) == 0 && n_iter > 0;
+    static const double p2_thr = [] { const char* e = getenv("PETAL_P2_VERDICT_THR"); return e ? atof(e) : 4e-6; }();
+    auto pipeline = [&](bool robust, bool exact) {
+    const int planes = (n_iter > 0 && !robust && !exact) ? 2 : 3;
+    if (robust || exact) dev_memset(c.dev, tvp, 0, sizeof(double) * (2 + LP));  // tv, ndead, lam (only lam[0 .. L) is written below); the first run's were cleared with Omega
     // Z = Xc . Omega (pca.rs:707); total_variance = sum Xc^2 (pca.rs:533) is fused into this product unless tv_from_sq
     dev_set_tag(c.dev, TAG_XP);
     // (with power iterations behind it the sketch matrix may be ANY matrix: the optimistic run lets the kernel round Omega to two
     // bf16 planes -- five piece products; n_iter = 0 and the robust redo keep Omega as given)
-    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv_from_sq ? nullptr : tvp, (n_iter > 0 && !robust) ? 2 : 3);
+    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv_from_sq ? nullptr : tvp, planes);
     dev_set_tag(c.dev, TAG_NONE);
 
+    // A SHORT iteration (n_iter 1 - 2) on fp32 data re-bases the sketch Z = Xc Omega on the tall side first, as the crate does
+    // with its first LU (pca.rs:709).  Every column of Z is dominated by sigma_1, so the un-rebased double product Xc^T (Xc Omega)
+    // carries direction j at (sigma_j / sigma_1)^2 of a column -- 1e-6 on the planted spectra -- under an fp32 accumulation that
+    // is good to 6e-8 of it: the block's weakest directions come back 6 % junk, and with only one or two products behind it the
+    // fit is off by 2e-4 where the crate's own f32 path holds 1e-5 (measured, EXPERIMENTS.md round 5).  With Z = Q R first, a
+    // column of Xc^T Q carries direction j at sigma_j / sigma_1.  From three iterations on the later products wash the junk out
+    // (3e-6 at n_iter = 3) and the two extra passes over Z are not spent.
+    const void* Zfirst = Z.p;   // what the first product with Xc^T reads
+    if (n_iter >= 1 && n_iter <= 2 && dt == F32 && !robust) {
+        op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP, /*precise=*/true);
+        allreduce_f64(c, G, LP * LP, PETAL_SUM);
+        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_tall, nullptr, LP);
+        op_gemm_xp(c.dev, dt, Z.p, n, LP, LP, nullptr, T.f64(), LP, LP, nullptr, Z1.p, LP, nullptr);
+        Zfirst = Z1.p;
+    }
     double* Pcur = P.f64();  // the orthonormal basis the current Z was formed with
     for (int64_t it = 0; it < n_iter; ++it) {  // pca.rs:708-715
         dev_set_tag(c.dev, TAG_ATB);
-        op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z.p, LP, LP, nullptr, n, Yp, LP);  // Yp = Xc^T Z (pca.rs:711)
+        op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, it == 0 ? Zfirst : Z.p, LP, LP, nullptr, n, Yp, LP);  // Yp = Xc^T Z (pca.rs:711)
         dev_set_tag(c.dev, TAG_NONE);
         allreduce_f64(c, Yp, dp * LP, PETAL_SUM);
         // Re-base the d x l iterate (stands for the two pivoted-LU re-basings of pca.rs:709-713).  The next product only
@@ -603,7 +632,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
             // launch of its own; R^-1 itself is not needed during the iteration.
             op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Yp, LP, Yp, LP, 0.0, G, LP);
             dev_set_tag(c.dev, TAG_XP);   // (only the product kernel itself is bracketed)
-            op_rebase_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, G, L, LP, 1e-15, ndead, Yp, LP, LP, T.f64(), LP, Y.f64(), LP, Z.p, LP);  // pca.rs:714
+            op_rebase_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, G, L, LP, 1e-15, ndead, Yp, LP, LP, T.f64(), LP, Y.f64(), LP, Z.p, LP, planes);  // pca.rs:714
             dev_set_tag(c.dev, TAG_NONE);
         } else {
             // ill-conditioned iterate: precondition with the tall side first.  Z = Xc P gives Z^T Z = P^T (Xc^T Z) =
@@ -652,18 +681,22 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, ndead, LP, std::max<int64_t>(k, 1));
         Usrc = Z.p; Ubuf = Z1.p;
     } else {
-        // Cholesky-QR2: Z1 = Z T1, Q = Z1 T2 with T2 folded into the small side
-        op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP);
+        // Cholesky-QR2: Z1 = Z T1, Q = Z1 T2 with T2 folded into the small side.  The Gram matrices of the tall side are formed
+        // with fp64 products (`precise`): Z = Xc Omega of a wide spectrum has cond(Z)^2 ~ 1e7 .. 1e8, and a Gram matrix from fp32
+        // products (good to 6e-8 of its norm) would have to DROP the weakest columns as noise -- n_iter = 0 on a planted 1e3
+        // spectrum then lost a column of the oversampling tail and came back 9e-3 off where the crate's f32 QR (linalg.rs:127-147)
+        // holds 5e-6; with exact products every pivot above the rounding of Z itself is kept.
+        op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP, /*precise=*/true);
         allreduce_f64(c, G, LP * LP, PETAL_SUM);
-        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);
+        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_tall, nullptr, LP);
         op_gemm_xp(c.dev, dt, Z.p, n, LP, LP, nullptr, T.f64(), LP, LP, nullptr, Z1.p, LP, nullptr);
-        op_gemm_atb(c.dev, dt, Z1.p, LP, LP, nullptr, Z1.p, LP, LP, nullptr, n, G, LP);
+        op_gemm_atb(c.dev, dt, Z1.p, LP, LP, nullptr, Z1.p, LP, LP, nullptr, n, G, LP, /*precise=*/true);
         dev_set_tag(c.dev, TAG_ATB);
         op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z1.p, LP, LP, nullptr, n, Yp, LP);  // B^T = Xc^T Q (pca.rs:681)
         dev_set_tag(c.dev, TAG_NONE);
         allreduce_f64(c, G, LP * LP, PETAL_SUM);
         allreduce_f64(c, Yp, dp * LP + 1, PETAL_SUM);
-        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_drop, nullptr, LP);  // T2
+        op_chol_inv(c.dev, G, L, LP, T.f64(), LP, tol_tall, nullptr, LP);  // T2
         Usrc = Z1.p; Ubuf = Z.p;
     }
     op_dgemm(c.dev, false, false, dp, LP, LP, 1.0, Yp, LP, T.f64(), LP, 0.0, Bt.f64(), LP);
@@ -677,6 +710,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // solves with Jacobi.  Saves the two fallback launches that return at once on every separated spectrum.
     if (!robust) op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, false, LP, std::max<int64_t>(k, 1), ndead);
     else op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, true, LP);  // (zero padding of Uh included)
+    // (the two-plane verdict, from the spectrum just found; on an exact run it only refreshes the ctx's hint)
+    if (!robust && two_plane_applies)
+        op_tail_verdict(c.dev, lam, L, std::max<int64_t>(k, 1), tv_from_sq ? mu64 : nullptr, dp, d, ri.n_total, tvp, 4e-6, p2_thr, ndead);
     // rows of V^T: v_j = B^T u_j / sigma_j, sigma_j = sqrt(lam_j) (the host takes the same square roots of lam)
     op_components_out(c.dev, dt, Bt.f64(), LP, Uh.f64(), LP, lam, dt == F32 ? 1e-7 : 1e-12, d, L, k, comp_dev);
 
@@ -700,9 +736,11 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     std::vector<char> comp_keep;
     static const bool host_tl = getenv("PETAL_HOST_TIMELINE") != nullptr;
     double t_q = 0, t_s = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        pipeline(attempt == 1);
-        if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip, true, attempt == 0 ? ndead : nullptr);
+    static const bool never_p2 = getenv("PETAL_NO_P2") != nullptr;
+    bool robust = false, exact = !two_plane_applies || never_p2 || c.rpca_exact_hint;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        pipeline(robust, exact);
+        if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip, true, !robust ? ndead : nullptr);
         // (one view for both while they fit a ring slot; large components -- k = 128 at d = 16384, k = 512 at d = 4096 -- leave by a
         // plain copy of their own and only the small block is viewed: ADVICE round 4)
         const bool one_view = sizeof(double) * hres_len + comp_bytes <= dev_view_limit(c.dev);
@@ -723,12 +761,17 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
             comp_keep.assign(static_cast<const char*>(hcomp), static_cast<const char*>(hcomp) + comp_bytes);
             hcomp = comp_keep.data();
         }
-        if (attempt == 1) break;
-        int hdead = 0;
-        std::memcpy(&hdead, &keep[o_dead - o_tv], sizeof(int));
-        bool redo = hdead != 0;
-        if (sharded(c)) redo = flip_slot_keys(c, dt) ? keep[o_flip - o_tv + 4 * kp] != 0.0 : agree_any(c, redo);  // the agreed verdict
-        if (!redo) break;
+        if (robust) break;
+        // the verdict words: [0] pivot breakdowns / a cluster among the wanted values -> the robust path; [1] a heavy tail behind the
+        // block -> the same pipeline with three-plane operands.  Sharded fits branch on the MAX over the ranks.
+        int hdead[2] = {0, 0};
+        std::memcpy(hdead, &keep[o_dead - o_tv], sizeof(hdead));
+        double code = hdead[0] != 0 ? 2.0 : (hdead[1] != 0 ? 1.0 : 0.0);
+        if (sharded(c)) code = flip_slot_keys(c, dt) ? keep[o_flip - o_tv + 4 * kp] : agree_max(c, code);  // the agreed verdict
+        if (two_plane_applies && code < 2.0) c.rpca_exact_hint = code == 1.0;   // (what the next fit on this ctx starts with)
+        if (code >= 2.0) { robust = true; exact = true; c.stats.rpca_redo = 2; continue; }
+        if (code == 1.0 && !exact) { exact = true; c.stats.rpca_redo = 1; continue; }
+        break;
     }
     if (slot_flip) {
         const double* hf = &keep[o_flip - o_tv];

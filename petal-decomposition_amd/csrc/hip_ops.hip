@@ -5509,7 +5509,7 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         // PETAL_NO_P2_OMEGA for the sketch matrix only)
         static const bool no_p2 = getenv("PETAL_NO_P2") != nullptr;
         static const bool no_p2_it = no_p2 || getenv("PETAL_NO_P2_ITERATE") != nullptr, no_p2_om = no_p2 || getenv("PETAL_NO_P2_OMEGA") != nullptr;
-        const bool p2 = ((prod_A && prod_rt && !no_p2_it) || (!prod_A && p2_hint && !no_p2_om)) && !am;
+        const bool p2 = p2_hint && ((prod_A && prod_rt && !no_p2_it) || (!prod_A && !no_p2_om)) && !am;
         if (prod_A) {
             // P = prod_A . P: the fp64 GEMM kernel writes the product (prod_out) AND its operand planes from its epilogue
             if (prod_rt)   // P is R in RT form: blocked triangular solve instead of the product with the explicit inverse
@@ -5943,7 +5943,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
 
 __global__ void k_flip_key(const double* __restrict__ t, double* __restrict__ key, int64_t L, const int* __restrict__ flag) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == L && flag) key[L] = *flag != 0 ? 1.0 : 0.0;
+    if (j == L && flag) key[L] = flag[0] != 0 ? 2.0 : (flag[1] != 0 ? 1.0 : 0.0);   // (MAX over the ranks: the stronger redo wins)
     if (j >= L) return;
     const double a = t[j] < 0 ? 0.0 : t[j];
     unsigned long long bits = (unsigned long long)__double_as_longlong(a);
@@ -5956,6 +5956,43 @@ __global__ void k_flip_key(const double* __restrict__ t, double* __restrict__ ke
 void op_flip_key(Dev* d, const double* triple, double* key, int64_t L, const int* flag) {
     if (L == 0 && !flag) return;
     hipLaunchKernelGGL(k_flip_key, dim3(cdiv(L + 1, 256)), dim3(256), 0, d->stream, triple, key, L, flag);
+    launch_check();
+}
+// Was the two-plane (16-bit) rounding of the sketch matrix and of the re-based iterates harmless for THIS spectrum?  (ops.h)
+__global__ __launch_bounds__(256) void k_tail_verdict(const double* __restrict__ lam, int L, int k, const double* __restrict__ mu_sq, int dp,
+                                                       int d, double n_total, const double* __restrict__ tvp, double eps2, double thr,
+                                                       int* __restrict__ flag2) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double s = 0;
+    if (mu_sq) for (int j = tid; j < d; j += 256) s += fmax(0.0, mu_sq[dp + j] - n_total * mu_sq[j] * mu_sq[j]);
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    const double tv = mu_sq ? red[0] : tvp[0];
+    __syncthreads();
+    s = 0;
+    for (int j = tid; j < L; j += 256) s += fmax(lam[j], 0.0);
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    const double tail = fmax(tv - red[0], 0.0);
+    const double T = sqrt(fmax(lam[L - 1], 0.0) * tail / (double)d);
+    int bad = 0;
+    for (int j = tid; j < k && j < L; j += 256) {
+        const double lj = lam[j];
+        if (!(lj > 0.0)) continue;                       // (a sigma = 0 component of rank-deficient data: nothing to perturb)
+        double gap = j + 1 < L ? lj - fmax(lam[j + 1], 0.0) : lj;
+        if (j > 0) gap = fmin(gap, lam[j - 1] - lj);
+        const double relgap = fmax(gap / lj, 1e-3);
+        if (eps2 * T / lj / relgap > thr) bad = 1;
+    }
+    if (__syncthreads_or(bad) && tid == 0) flag2[1] = 1;
+}
+void op_tail_verdict(Dev* d, const double* lam, int64_t L, int64_t k, const double* mu_sq, int64_t dp, int64_t dd, double n_total,
+                     const double* tv, double eps2, double thr, int* flag2) {
+    if (L <= 0 || k <= 0) return;
+    hipLaunchKernelGGL(k_tail_verdict, dim3(1), dim3(256), 0, d->stream, lam, (int)L, (int)k, mu_sq, (int)dp, (int)dd, n_total, tv, eps2, thr, flag2);
     launch_check();
 }
 void op_col_absmax(Dev* d, int dt, const void* U, int64_t n, int64_t L, int64_t ldu, int64_t row_offset, double* absmax,
@@ -6310,7 +6347,7 @@ static void chol_inv_blocked(Dev* d, const double* G, int64_t L, int64_t ldg, do
 // while it packs the operand planes of the product that follows.
 void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                   int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
-                  double* P_out, int64_t ldpo, void* Z, int64_t ldz) {
+                  double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes) {
     static const bool no_rt = getenv("PETAL_NO_TRSM") != nullptr;
     const bool fused = dt == F32 && gemm_split_product(d) && n >= 64 && K % 16 == 0 && K > 0 && M % 16 == 0 && ldx % 4 == 0 &&
                        aligned16(X) && (!mu || aligned16(mu)) && ldz % 4 == 0 && aligned16(Z) && K < (1 << 24) && M < (1 << 24);
@@ -6323,7 +6360,7 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
     hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead,
                        (int)M, (const double*)nullptr, 1, (int)L);
     launch_check();
-    gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, M, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, true);
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, M, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, true, nullptr, p_planes == 2);
 }
 
 void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz,

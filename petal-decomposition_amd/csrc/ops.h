@@ -19,10 +19,10 @@ inline size_t dtype_size(int dt) { return dt == F64 ? 8 : 4; }
 struct Dev;  // opaque: stream, allocator cache, event pool (hip) / nothing much (cpu sim)
 
 // hot-kernel tags: launches issued while a tag is set are bracketed with events when profiling is on
-enum Tag : int { TAG_NONE = 0, TAG_XP = 1, TAG_ATB = 2, TAG_ICA = 3, TAG_COMM = 4, TAG_COUNT = 5 };
+enum Tag : int { TAG_NONE = 0, TAG_XP = 1, TAG_ATB = 2, TAG_ICA = 3, TAG_COMM = 4, TAG_POW = 5, TAG_COUNT = 6 };
 struct KernelTiming {
-    double ms[TAG_COUNT] = {0, 0, 0, 0, 0};
-    int64_t launches[TAG_COUNT] = {0, 0, 0, 0, 0};
+    double ms[TAG_COUNT] = {0, 0, 0, 0, 0, 0};
+    int64_t launches[TAG_COUNT] = {0, 0, 0, 0, 0, 0};
 };
 
 // ---- lifetime / memory ---------------------------------------------------------------------
@@ -105,9 +105,20 @@ void op_gemm_xp_absmax(Dev*, int dtype, const void* X, int64_t n, int64_t K, int
 // One re-basing step of the power iteration: G (L x L, ldg) = R^T R, P_out (K x M fp64, ldpo) = A R^-1 (A: K x M, lda; columns
 // L .. M of the result are zero), Z = (X - mu) . P_out.  Same results contract as op_chol_inv(G -> T, Lz = M) followed by
 // op_gemm_xp_prod(A, T); T (M x M, ldt) is SCRATCH here -- it may hold R^-1 or a factored form of it, callers must not read it.
+// p_planes = 2: P_out may be ROUNDED to the sum of its two leading bf16 pieces (in P_out itself and in the product's operand) where
+// that saves a piece product; 3: P_out is the re-based iterate to fp64 / fp32 accuracy.
 void op_rebase_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                   int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
-                  double* P_out, int64_t ldpo, void* Z, int64_t ldz);
+                  double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes = 2);
+// Was a 16-bit (two-plane) rounding of the sketch matrix and of the re-based iterates harmless for the spectrum this fit found?
+// A rounding E of the basis P (|E_ij| <= eps2 |P_ij|) reaches the next iterate as C E, C = Xc^T Xc: directions the block already
+// spans are harmless, the part from BEYOND the block -- sum_{i > L} sigma_i^2 v_i (v_i^T E), of size eps2 T with
+// T^2 = sum_{i > L} sigma_i^4 / d <= lam_{L-1} (tv - sum_j lam_j) / d -- tilts wanted direction j by eps2 T / lam_j, and the
+// component that comes out by that over the relative gap to its neighbours.  lam (L, descending): the eigenvalues of B B^T (squared
+// singular values); mu_sq ([means | sums of squares], 2 dp; nullable): the total variance is sum_j (sq_j - n_total mu_j^2), else *tv.
+// Sets flag2[1] = 1 when that estimate exceeds thr for one of the k wanted components (flag2[0] is not touched).
+void op_tail_verdict(Dev*, const double* lam, int64_t L, int64_t k, const double* mu_sq, int64_t dp, int64_t d, double n_total,
+                     const double* tv, double eps2, double thr, int* flag2);
 // C[M x N] (f64, ldc) = (A - muA)^T . (B - muB),  A: n x M (lda), B: n x N (ldb), reduction over n rows.
 // precise: every product and the whole accumulation in fp64 (needed where the result's small eigenvalues
 // matter: exact Pca, FastICA whitening); otherwise fp32 MFMA chunks combined in fp64.
@@ -122,8 +133,8 @@ void op_col_absmax(Dev*, int dtype, const void* U, int64_t n, int64_t L, int64_t
 // svd_flip across ranks, fp32 data: key[j] = the fp64 image of absmax[j] with (2^28 - 1 - row[j], sign[j] < 0) packed into
 // the 29 low mantissa bits an fp32 magnitude leaves zero (absmax < 0, an empty shard, gives key 0); `triple` is
 // op_col_absmax's [absmax | row | sign] (3 L).  A MAX all-reduce of the keys elects the first element of maximal magnitude.
-// flag != nullptr: key[L] = (*flag != 0) -- a replicated decision word riding the same MAX all-reduce, so that every rank
-// branches on the agreed value
+// flag != nullptr (two ints): key[L] = flag[0] != 0 ? 2 : flag[1] != 0 ? 1 : 0 -- a replicated decision word riding the same MAX
+// all-reduce, so that every rank branches on the agreed value; the stronger redo (2) wins
 void op_flip_key(Dev*, const double* triple, double* key, int64_t L, const int* flag = nullptr);
 // A[i][j] *= s[j] (dtype matrix, f64 scale vector), i < n, j < L
 void op_scale_cols(Dev*, int dtype, void* A, int64_t n, int64_t L, int64_t lda, const double* s);

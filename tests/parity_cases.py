@@ -238,16 +238,16 @@ def rpca_parity(ctx, n, d, k, n_iter, seed, dtype=np.float32, tol=1e-5, device=F
         y = y.cpu().numpy()
     rel = rowwise_rel(m.components().astype(np.float64), o.components)
     if graded:
-        # n_iter = 0 on fp32 data with a WIDE spectrum: Z = Xc Omega is stored in fp32 with every column dominated by sigma_1, so
-        # direction j of Q = orth(Z) is only good to eps32 sigma_1 / sigma_j, and row j of B = Q^T Xc (whose error is again
-        # dominated by sigma_1) to eps32 (sigma_1 / sigma_j)^2 -- the crate's own f32 instantiation is in the same position; the
-        # fp64 oracle is not.  The tolerance follows that law per component (and the flat `tol` where it is the larger one).
-        amp = (o.singular[0] / np.maximum(o.singular, 1e-300)) ** 2
-        tol_rows = np.maximum(tol, 20 * 6e-8 * amp)
-        assert np.all(rel <= tol_rows), f"components rel-err / allowed {np.max(rel / tol_rows):.3e}"
-        assert np.all(np.abs(m.singular_values() / o.singular - 1) <= tol_rows)
-        tol = float(tol_rows.max())
-        tol_sigma = tol
+        # fp32 data, few power iterations, a WIDE spectrum: every column of the sketch is dominated by sigma_1, and a result
+        # that is not yet converged keeps what fp32 storage of the iterates does to the weak directions -- the crate's own f32
+        # instantiation (the oracle run in the data's type: same algorithm, LAPACK's s-routines) is in the same position, the
+        # fp64 oracle is not.  The bar is that reference error with head-room, and the flat `tol` where that is the larger one.
+        o32 = po.RandomizedPcaOracle(k, centering=centering, n_iter=n_iter, n_oversample=n_oversample)
+        o32._inner_fit(x, omega=om.astype(np.float32))
+        ref32 = rowwise_rel(o32.components.astype(np.float64), o.components).max()
+        sig32 = np.abs(o32.singular.astype(np.float64) / o.singular - 1).max()
+        tol = max(tol, 3.0 * ref32)
+        tol_sigma = max(tol if tol_sigma is None else tol_sigma, 3.0 * sig32)
     assert rel.max() <= tol, f"components rel-err {rel.max():.3e} > {tol}"
     # svd_flip against the oracle's, un-aligned: every component whose deciding |u| is not a near-tie carries the oracle's sign
     dec = decided_signs(uo, k, margin=min(0.5, max(1e-3, 100 * tol)))
@@ -287,8 +287,29 @@ def rpca_low_iter(ctx, n, d, k, n_iter, spectrum, dtype, seed, device=False, tol
     x = None if spectrum == "planted" else slow_decay_matrix(n, d, spectrum, seed, dtype)
     if tol is None:
         tol = 1e-5 if dtype == np.float32 else 1e-9
-    return rpca_parity(ctx, n, d, k, n_iter, seed, dtype=dtype, tol=tol, device=device, x=x,
-                       graded=(n_iter == 0 and spectrum == "planted" and dtype == np.float32))
+    return rpca_parity(ctx, n, d, k, n_iter, seed, dtype=dtype, tol=tol, device=device, x=x, graded=(dtype == np.float32))
+
+
+def two_plane_verdict_case(ctx, n=3000, d=128, k=12):
+    """The optimistic two-plane run and its verdict (algo.cpp, rpca_fit; op_tail_verdict): a planted spectrum that falls off behind
+    the block keeps the first run (rpca_redo = 0); a slowly decaying one is sent back through the pipeline with three-plane
+    operands (rpca_redo = 1) and then matches the oracle like the fp32-MFMA mode does -- and the ctx starts its NEXT fit in that
+    mode (no second redo), dropping the hint again when a well-separated spectrum follows."""
+    ctx.set_gemm_mode("bf16x3")
+    try:
+        rpca_parity(ctx, n, d, k, 2, seed=71)
+        assert ctx.stats()["rpca_redo"] == 0
+        x = slow_decay_matrix(n, d, "rsqrt", 72)
+        rpca_parity(ctx, n, d, k, 2, seed=72, x=x, tol=3e-6)
+        assert ctx.stats()["rpca_redo"] == 1
+        rpca_parity(ctx, n, d, k, 2, seed=73, x=x, tol=3e-6)
+        assert ctx.stats()["rpca_redo"] == 0          # the hint: straight to three planes
+        rpca_parity(ctx, n, d, k, 2, seed=74)             # a fast spectrum clears it (this fit still ran exact) ...
+        rpca_parity(ctx, n, d, k, 2, seed=75, x=x, tol=3e-6)
+        assert ctx.stats()["rpca_redo"] == 1          # ... so the slow one is found out again
+        rpca_parity(ctx, n, d, k, 2, seed=76)
+    finally:
+        ctx.set_gemm_mode("fp32")
 
 
 def pca_parity(ctx, n, d, k, seed, dtype=np.float64, tol=1e-9, thin_oracle=False):

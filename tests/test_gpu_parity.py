@@ -79,6 +79,17 @@ def test_rpca_low_iteration_counts_at_the_config_width(ctx, n_iter):
     pc.rpca_low_iter(ctx, 20000, 512, 64, n_iter, "geo97", np.float32, seed=320 + n_iter, device=True)
 
 
+def test_two_plane_verdict_and_exact_redo():
+    """(split-product mode only: the fp32-MFMA mode has no two-plane operands)"""
+    import petal_decomposition_amd as petal
+    c = petal.Context(0)
+    try:
+        pc.two_plane_verdict_case(c, n=20000, d=512, k=64)
+        pc.two_plane_verdict_case(c, n=4000, d=256, k=16)
+    finally:
+        c.close()
+
+
 def test_components_beyond_a_ring_slot(ctx):
     """k d esz above the 8 MiB slot of the pinned result ring (rpca_fit's single result view threw there, e.g.
     k = 512 at d = 2048 fp64 or d = 4096 fp32): the components then leave by a copy of their own."""

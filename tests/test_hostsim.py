@@ -42,6 +42,10 @@ def test_rpca_low_iteration_counts(ctx, n_iter, spectrum, mode):
         ctx.set_gemm_mode("fp32")
 
 
+def test_two_plane_verdict_and_exact_redo(ctx):
+    pc.two_plane_verdict_case(ctx)
+
+
 def test_components_beyond_a_ring_slot(ctx):
     """k d esz above the 8 MiB ring slot (the single result view threw there): the components leave by their own
     copy.  k = 512, d = 2048 fp64 = 8 MiB + the small block."""
