@@ -171,6 +171,14 @@ int petal_gemm_xp(petal_ctx* ctx, const petal_matrix* x, const void* mu, const v
 int petal_gemm_atb(petal_ctx* ctx, const petal_matrix* a, const void* mu_a, const petal_matrix* b, const void* mu_b,
                    double* c_out);
 
+/* One power iteration of the range finder as ONE pass over x (src/pca.rs:711 + 714: `input.t().dot(&pl)` of `input.dot(&pl)`):
+ *   y_out[K x N] (HOST, row-major, fp64) = (x - mu)^T . ((x - mu) . p),   z_out (nullable) [n x N] = (x - mu) . p
+ * with p taken as the sum of its two leading bf16 pieces (16 significant bits: exact for the small integers of the parity tests).
+ * *fused_out (nullable) = 1 when the fused kernel ran (fp32 data, split-product mode, K = 512, N <= 80), 0 when the two GEMM
+ * kernels formed the same products one after the other (every other shape / mode: p then counts in full). */
+int petal_power_pass(petal_ctx* ctx, const petal_matrix* x, const void* mu, const void* p, int64_t N, double* y_out,
+                     const petal_matrix* z_out, int* fused_out);
+
 #ifdef __cplusplus
 }
 #endif

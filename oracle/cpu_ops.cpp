@@ -456,6 +456,31 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
     op_gemm_xp_prod(d, dt, X, n, K, ldx, mu, A, M, lda, T, M, ldt, P_out, ldpo, Z, ldz);
 }
 
+// the fused power-iteration pass: simulated for fp32 data in the split-product mode at ANY width (the device kernel exists for
+// K = 512, N <= 80), so that the host sequencing of the fused pipeline is covered by the CPU suite
+bool op_power_pass_applies(Dev* d, int dt, const void*, int64_t n, int64_t K, int64_t, const void*, int64_t N) {
+    static const bool off = std::getenv("PETAL_NO_POW3") != nullptr;
+    return !off && dt == F32 && d->gemm_mode == 0 && n >= 64 && K % 16 == 0 && N % 16 == 0 && N <= 80;
+}
+bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
+                   void* Z, int64_t ldz, double* Y, int64_t ldy) {
+    if (!op_power_pass_applies(d, dt, X, n, K, ldx, mu, N)) return false;
+    std::vector<float> ztmp;
+    if (!Z) { ztmp.resize(size_t(n) * N); Z = ztmp.data(); ldz = N; }
+    op_gemm_xp(d, dt, X, n, K, ldx, mu, P, N, ldp, nullptr, Z, ldz, nullptr, 2);
+    op_gemm_atb(d, dt, X, ldx, K, mu, Z, ldz, N, nullptr, n, Y, ldy, false);
+    return true;
+}
+bool op_rebase_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
+                          int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
+                          double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy) {
+    if (!op_power_pass_applies(d, dt, X, n, K, ldx, mu, M) || L == 0 || P_out == nullptr) return false;
+    op_chol_inv(d, G, L, ldg, T, ldt, rel_tol, ndead, M);
+    op_dgemm(d, false, false, K, M, M, 1.0, A, lda, T, ldt, 0.0, P_out, ldpo);
+    for (int64_t k = 0; k < K; ++k)
+        for (int64_t j = 0; j < M; ++j) P_out[k * ldpo + j] = two_plane(P_out[k * ldpo + j]);
+    return op_power_pass(d, dt, X, n, K, ldx, mu, P_out, M, ldpo, Z, ldz, Y, ldy);
+}
 void op_tail_verdict(Dev*, const double* lam, int64_t L, int64_t k, const double* mu_sq, int64_t dp, int64_t d, double n_total,
                      const double* tv, double eps2, double thr, int* flag2) {
     if (L <= 0 || k <= 0) return;

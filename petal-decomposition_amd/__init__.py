@@ -89,6 +89,7 @@ ABI = [
     ("petal_rccl_unique_id", C.c_int, [_P]),
     ("petal_ctx_init_rccl", C.c_int, [_P, _P, C.c_int, C.c_int]),
     ("petal_get_stats", C.c_int, [_P, C.POINTER(petal_stats)]),
+    ("petal_power_pass", C.c_int, [_P, _M, _P, _P, C.c_int64, C.POINTER(C.c_double), _M, C.POINTER(C.c_int)]),
     ("petal_pca_fit", C.c_int, [_P, _M, C.c_int64, C.c_int, _P, _P, _P, _P, _M]),
     ("petal_rpca_fit", C.c_int, [_P, _M, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _M]),
     ("petal_transform", C.c_int, [_P, _M, _P, _P, C.c_int64, C.c_int64, C.c_int, _M]),
@@ -840,6 +841,26 @@ def gemm_xp(x, p, mu=None, bias=None, ctx: Optional[Context] = None):
     ctx.check(ctx.lib.petal_gemm_xp(ctx._h, C.byref(mx), muh.ctypes.data if muh is not None else None, ph.ctypes.data, N,
                                     bh.ctypes.data if bh is not None else None, C.byref(mz)))
     return z
+
+
+def power_pass(x, p, mu=None, want_z=False, ctx: Optional[Context] = None):
+    """(y, z, fused): y (fp64, host) = (x - mu)^T ((x - mu) p) -- one power iteration of the range finder as ONE pass over x
+    (src/pca.rs:711 + 714) where the fused kernel exists (fused = True), the two GEMM kernels otherwise; z = (x - mu) p if wanted."""
+    ctx = ctx or default_context()
+    keep = []
+    mx = describe(x, keep)
+    ph = _host(p, mx.dtype)
+    if ph.shape[0] != mx.cols:
+        raise InvalidInput(f"p should have {mx.cols} rows")
+    N = ph.shape[1]
+    muh = _host(mu, mx.dtype, (mx.cols,)) if mu is not None else None
+    y = np.zeros((mx.cols, N), dtype=np.float64)
+    z = _alloc_like(x, mx.rows, N, mx.dtype) if want_z else None
+    mz = describe(z, keep) if want_z else None
+    fused = C.c_int(0)
+    ctx.check(ctx.lib.petal_power_pass(ctx._h, C.byref(mx), muh.ctypes.data if muh is not None else None, ph.ctypes.data, N,
+                                       y.ctypes.data_as(C.POINTER(C.c_double)), C.byref(mz) if want_z else None, C.byref(fused)))
+    return y, z, bool(fused.value)
 
 
 def gemm_atb(a, b=None, mu_a=None, mu_b=None, ctx: Optional[Context] = None):

@@ -593,6 +593,17 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     auto pipeline = [&](bool robust, bool exact) {
     const int planes = (n_iter > 0 && !robust && !exact) ? 2 : 3;
     if (robust || exact) dev_memset(c.dev, tvp, 0, sizeof(double) * (2 + LP));  // tv, ndead, lam (only lam[0 .. L) is written below); the first run's were cleared with Omega
+    // The FUSED power-iteration pass Y' = Xc^T (Xc P) (one pass over X where K1 + K2 make two; it needs P on two planes, so it
+    // belongs to the optimistic run): every product pair of the loop below, the last one also storing Z.
+    const bool use_pow = planes == 2 && op_power_pass_applies(c.dev, dt, X.p, n, dp, X.ld, muT.p, LP);
+    bool have_yp = false;   // Yp already holds Xc^T Z for the current basis
+    if (use_pow && n_iter >= 3 && tv_from_sq) {
+        dev_set_tag(c.dev, TAG_POW);
+        have_yp = op_power_pass(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, LP, Yp, LP);   // pca.rs:707 + 711
+        dev_set_tag(c.dev, TAG_NONE);
+        if (have_yp) allreduce_f64(c, Yp, dp * LP, PETAL_SUM);
+    }
+    if (!have_yp) {
     // Z = Xc . Omega (pca.rs:707); total_variance = sum Xc^2 (pca.rs:533) is fused into this product unless tv_from_sq
     dev_set_tag(c.dev, TAG_XP);
     // (with power iterations behind it the sketch matrix may be ANY matrix: the optimistic run lets the kernel round Omega to two
@@ -607,6 +618,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // fit is off by 2e-4 where the crate's own f32 path holds 1e-5 (measured, EXPERIMENTS.md round 5).  With Z = Q R first, a
     // column of Xc^T Q carries direction j at sigma_j / sigma_1.  From three iterations on the later products wash the junk out
     // (3e-6 at n_iter = 3) and the two extra passes over Z are not spent.
+    }
     const void* Zfirst = Z.p;   // what the first product with Xc^T reads
     if (n_iter >= 1 && n_iter <= 2 && dt == F32 && !robust) {
         op_gemm_atb(c.dev, dt, Z.p, LP, LP, nullptr, Z.p, LP, LP, nullptr, n, G, LP, /*precise=*/true);
@@ -617,10 +629,13 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     }
     double* Pcur = P.f64();  // the orthonormal basis the current Z was formed with
     for (int64_t it = 0; it < n_iter; ++it) {  // pca.rs:708-715
-        dev_set_tag(c.dev, TAG_ATB);
-        op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, it == 0 ? Zfirst : Z.p, LP, LP, nullptr, n, Yp, LP);  // Yp = Xc^T Z (pca.rs:711)
-        dev_set_tag(c.dev, TAG_NONE);
-        allreduce_f64(c, Yp, dp * LP, PETAL_SUM);
+        if (!have_yp) {
+            dev_set_tag(c.dev, TAG_ATB);
+            op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, it == 0 ? Zfirst : Z.p, LP, LP, nullptr, n, Yp, LP);  // Yp = Xc^T Z (pca.rs:711)
+            dev_set_tag(c.dev, TAG_NONE);
+            allreduce_f64(c, Yp, dp * LP, PETAL_SUM);
+        }
+        have_yp = false;
         // Re-base the d x l iterate (stands for the two pivoted-LU re-basings of pca.rs:709-713).  The next product only
         // needs SOME well-conditioned basis of range(Yp): P = Yp T spans range(Yp) exactly for any invertible
         // triangular T, so the accuracy of T only decides how well-conditioned P is, never which subspace it spans (the
@@ -631,9 +646,19 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
             // Y = Yp R^-1 is formed inside the next product's operand-packing kernel (op_rebase_xp), by substitution, not by a
             // launch of its own; R^-1 itself is not needed during the iteration.
             op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Yp, LP, Yp, LP, 0.0, G, LP);
+            if (use_pow) {   // re-base, then BOTH products of the next iteration in one pass (the last one keeps Z for U = Z (T Uh))
+                const bool last = it + 1 == n_iter;
+                dev_set_tag(c.dev, TAG_POW);
+                have_yp = op_rebase_power_pass(c.dev, dt, X.p, n, dp, X.ld, muT.p, G, L, LP, 1e-15, ndead, Yp, LP, LP, T.f64(), LP, Y.f64(), LP,
+                                               last ? Z.p : nullptr, LP, Yp, LP);   // pca.rs:714 + 711
+                dev_set_tag(c.dev, TAG_NONE);
+                if (have_yp) allreduce_f64(c, Yp, dp * LP + (last ? 1 : 0), PETAL_SUM);   // (the last one: [ Xc^T Z | sum Xc^2 ])
+            }
+            if (!have_yp) {
             dev_set_tag(c.dev, TAG_XP);   // (only the product kernel itself is bracketed)
             op_rebase_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, G, L, LP, 1e-15, ndead, Yp, LP, LP, T.f64(), LP, Y.f64(), LP, Z.p, LP, planes);  // pca.rs:714
             dev_set_tag(c.dev, TAG_NONE);
+            }
         } else {
             // ill-conditioned iterate: precondition with the tall side first.  Z = Xc P gives Z^T Z = P^T (Xc^T Z) =
             // P^T Yp without a pass over Z (op_chol_inv reads the upper triangle only); T = chol(Z^T Z)^-1 is applied on
@@ -667,10 +692,12 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         // (I + E)^T H with ||E|| ~ 1e-8, and ||Q^T Q - I|| ~ ||E|| cond(R) ~ 1e-5 instead of eps cond(Z)^2 (measured 1e-6 ..
         // 1e-5 up to cond(Z) = 2.5e4; the singular values match the two-pass Cholesky-QR2 form to its own accuracy).  Not so
         // for a non-orthonormal Pcur (n_iter = 0: the raw Omega) and on the robust redo: those keep Cholesky-QR2 below.
-        dev_set_tag(c.dev, TAG_ATB);
-        op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z.p, LP, LP, nullptr, n, Yp, LP);
-        dev_set_tag(c.dev, TAG_NONE);
-        allreduce_f64(c, Yp, dp * LP + 1, PETAL_SUM);  // [ Xc^T Z | sum Xc^2 ]
+        if (!have_yp) {   // (the fused pass of the last iteration has formed this product already)
+            dev_set_tag(c.dev, TAG_ATB);
+            op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, Z.p, LP, LP, nullptr, n, Yp, LP);
+            dev_set_tag(c.dev, TAG_NONE);
+            allreduce_f64(c, Yp, dp * LP + 1, PETAL_SUM);  // [ Xc^T Z | sum Xc^2 ]
+        }
         op_dgemm(c.dev, true, false, LP, LP, dp, 1.0, Pcur, LP, Yp, LP, 0.0, G, LP);
         // (a pivot lost here -- H is only symmetric / positive up to the fp32 rounding of Pcur and Z -- is recorded like the
         // breakdowns of the power iterations: the fit is then redone on the robust Cholesky-QR2 path instead of silently
@@ -1389,6 +1416,52 @@ void gemm_xp(petal_ctx& c, const petal_matrix& x, const void* mu, const void* p,
     op_gemm_xp(c.dev, dt, X.p, X.n, K, X.ld, mu ? muT.p : nullptr, P.f64(), NP, NP, bias ? bT.p : nullptr, Z.p, NP, nullptr);
     dev_set_tag(c.dev, TAG_NONE);
     emit(c, dt, Z.p, X.n, N, NP, z_out);
+    finish_stats(c, timer);
+}
+
+// one power iteration on its own: the fused pass where it exists, K1 + K2 otherwise (parity tests / roofline measurement)
+void power_pass(petal_ctx& c, const petal_matrix& x, const void* mu, const void* p, int64_t N, double* y_out, const petal_matrix* z_out,
+                int* fused_out) {
+    Timer timer;
+    dev_reset_timing(c.dev);
+    c.stats = petal_stats{};
+    check_matrix(x, "input");
+    const int dt = x.dtype;
+    if (N < 0) invalid_input("negative parameter");
+    if (fused_out) *fused_out = 0;
+    if (x.cols == 0 || N == 0) { if (z_out) emit(c, dt, nullptr, x.rows, N, 0, *z_out); return; }
+    if (x.rows == 0) { std::memset(y_out, 0, sizeof(double) * x.cols * N); if (z_out) emit(c, dt, nullptr, 0, N, 0, *z_out); return; }
+    DevMat X = ingest(c, x);
+    const int64_t K = X.dp, NP = round_up(N, 16);
+    std::vector<double> hP(size_t(K) * NP, 0.0);
+    for (int64_t i = 0; i < x.cols; ++i)
+        for (int64_t j = 0; j < N; ++j) hP[size_t(i) * NP + j] = get_elem(p, dt, i * N + j);
+    DBuf P(c.dev, sizeof(double) * K * NP), muT(c.dev, dtype_size(dt) * K), Y(c.dev, sizeof(double) * K * NP);
+    dev_h2d(c.dev, P.p, hP.data(), P.bytes);
+    std::vector<char> hmu(dtype_size(dt) * K, 0);
+    if (mu) std::memcpy(hmu.data(), mu, dtype_size(dt) * x.cols);
+    dev_h2d(c.dev, muT.p, hmu.data(), muT.bytes);
+    DBuf Z(c.dev, dtype_size(dt) * size_t(X.n) * NP);
+    c.stats.pass_flops = 4.0 * double(X.n) * double(x.cols) * double(N);
+    c.stats.pass_bytes = double(dtype_size(dt)) * (double(X.n) * x.cols + 2.0 * double(x.cols) * N);
+    const void* mup = mu ? muT.p : nullptr;
+    dev_set_tag(c.dev, TAG_POW);
+    const bool fused = op_power_pass(c.dev, dt, X.p, X.n, K, X.ld, mup, P.f64(), NP, NP, z_out ? Z.p : nullptr, NP, Y.f64(), NP);
+    dev_set_tag(c.dev, TAG_NONE);
+    if (!fused) {
+        dev_set_tag(c.dev, TAG_XP);
+        op_gemm_xp(c.dev, dt, X.p, X.n, K, X.ld, mup, P.f64(), NP, NP, nullptr, Z.p, NP, nullptr);
+        dev_set_tag(c.dev, TAG_ATB);
+        op_gemm_atb(c.dev, dt, X.p, X.ld, K, mup, Z.p, NP, NP, nullptr, X.n, Y.f64(), NP);
+        dev_set_tag(c.dev, TAG_NONE);
+    }
+    if (fused_out) *fused_out = fused ? 1 : 0;
+    std::vector<double> h(size_t(K) * NP);
+    dev_d2h(c.dev, h.data(), Y.p, Y.bytes);
+    dev_sync(c.dev);
+    for (int64_t i = 0; i < x.cols; ++i)
+        for (int64_t j = 0; j < N; ++j) y_out[i * N + j] = h[size_t(i) * NP + j];
+    if (z_out) emit(c, dt, Z.p, X.n, N, NP, *z_out);
     finish_stats(c, timer);
 }
 

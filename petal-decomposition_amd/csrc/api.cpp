@@ -213,6 +213,16 @@ int petal_gemm_xp(petal_ctx* ctx, const petal_matrix* x, const void* mu, const v
     });
 }
 
+int petal_power_pass(petal_ctx* ctx, const petal_matrix* x, const void* mu, const void* p, int64_t N, double* y_out,
+                     const petal_matrix* z_out, int* fused_out) {
+    return guarded(ctx, [&] {
+        need(x, "x");
+        need(p, "p");
+        need(y_out, "y_out");
+        power_pass(*ctx, *x, mu, p, N, y_out, z_out, fused_out);
+    });
+}
+
 int petal_gemm_atb(petal_ctx* ctx, const petal_matrix* a, const void* mu_a, const petal_matrix* b, const void* mu_b,
                    double* c_out) {
     return guarded(ctx, [&] {

@@ -105,5 +105,7 @@ void svd_flip(petal_ctx& c, const petal_matrix& u, const petal_matrix& vt);
 void gemm_xp(petal_ctx& c, const petal_matrix& x, const void* mu, const void* p, int64_t N, const void* bias,
              const petal_matrix& z_out);
 void gemm_atb(petal_ctx& c, const petal_matrix& a, const void* mu_a, const petal_matrix* b, const void* mu_b, double* c_out);
+void power_pass(petal_ctx& c, const petal_matrix& x, const void* mu, const void* p, int64_t N, double* y_out, const petal_matrix* z_out,
+                int* fused_out);
 
 }  // namespace petal

@@ -1862,6 +1862,292 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3 "k_pow3": one power-iteration pass  Y' = Xc^T (Xc P)  (pca.rs:711 + 714) with ONE pass over X -- the two products K1 and K2
+// form from two, and no Z in between (round 5).  For K = 512 features and N = 16 NT <= 80 columns; P is the re-based iterate
+// DEFINED on two bf16 planes (k_trsm_pack<NB, true>) or a two-plane sketch matrix, so a wave's slice of it fits its registers.
+//
+// One persistent 8-wave workgroup per CU walks over 32-row stages of X.  Wave w owns the features [64 w, 64 w + 64) in BOTH
+// products:
+//   * its slice of P sits in registers for the whole launch as MFMA B operands (2 chunks x NT tiles x 2 planes = 80 VGPRs at
+//     NT = 5), its slice of the Y' accumulators likewise (4 x NT tiles = 80 VGPRs);
+//   * it loads its 32 x 64 piece of the stage in K1's layout (lane (i, q): row 16 t + i, features 32 c + 8 q .. + 7: two 16-B
+//     loads), one stage ahead, centres and splits it ONCE into three bf16 planes -- which feed product 1 from registers and go to
+//     a wave-private LDS image that product 2 reads back TRANSPOSED with ds_read_b64_tr_b16 (its A operand wants feature i with
+//     eight samples per lane): X goes through the vector-memory pipeline once per power iteration;
+//   * product 1 gives the wave a PARTIAL z (its 64 of the 512 features) per 16-row half of the stage, in accumulator layout
+//     (lane (i, q): samples 4 q + r, column 16 u + i).  The eight partials meet in LDS; wave u < NT adds them for column tile u --
+//     after both halves a lane holds the eight samples {4 q + r, 16 + 4 q + r} of one column, which IS a B-operand fragment of
+//     product 2 once its k-slots are declared to be those samples (the X side reads its transposed blocks at the same rows) --
+//     splits the sum into three planes and publishes the fragment; rows beyond n are zeroed here (their X rows are clamped
+//     loads of the last row), and the last pass of a fit stores z as the iterate Z;
+//   * product 2 accumulates Y'[64 w .. + 64][:] += Xc^T z over the stage (six piece products, smallest first, as K2).
+// LDS: X planes 8 x 12 KB (16-B chunks XOR-swizzled by the row so that the row writes and the transposed reads are both
+// conflict-free on 128-B rows), partial z 8 x NT KB, z fragments 3 NT KB, mu 2 KB: 153 KB at NT = 5 -- one workgroup per CU, two
+// waves per SIMD, <= 256 registers.  Four barriers per stage (the partial-z buffer holds ONE half: there is no room for two).
+// Every workgroup ends with its own 512 x 16 NT fp32 slab of Y', combined in fp64 in a fixed order by k_sum_parts4 like K2's.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 lds_tr2(const unsigned char* a0, const unsigned char* a1) {
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a1));
+    return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+// byte offset of 16-B chunk `ch` (eight features) of row `row` inside one plane of a wave's image ([32 rows][128 B])
+__device__ __forceinline__ int pow3_xoff(int row, int ch) { return row * 128 + 16 * (ch ^ ((2 * ((row >> 1) & 3)) ^ (row & 1))); }
+template <int NT, bool CENTER, bool STOREZ>
+__global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64_t n, int64_t ldx, const float* __restrict__ mu,
+                                              const bf16x8* __restrict__ Ppk3, int NTtot, float* __restrict__ part,
+                                              float* __restrict__ Z, int64_t ldz, int64_t nstages) {
+    constexpr int WV = 8, K = 512, XIMG = 3 * 32 * 128;          // bytes of one wave's plane image
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_pow3[];
+    unsigned char* const sX = sm_pow3;                                           // [WV][3][32][128 B]
+    f32x4* const sZp = reinterpret_cast<f32x4*>(sm_pow3 + WV * XIMG);            // [WV][NT][64]
+    bf16x8* const sZB = reinterpret_cast<bf16x8*>(sm_pow3 + WV * XIMG + WV * NT * 1024);   // [NT][3][64]
+    float* const sMu = reinterpret_cast<float*>(sm_pow3 + WV * XIMG + WV * NT * 1024 + NT * 3072);   // [K]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);           // (uniform: scalar registers)
+    // Register budget: two waves per SIMD leave 256, and P (80) + Y' (80) + the raw stage in flight (32) are fixed.  Every per-lane
+    // index below is therefore re-derived, phase by phase, from a LAUNDERED copy of the thread index -- left to itself hipcc hoists
+    // some thirty loop-invariant LDS offsets and pointers into registers of their own and spills P fragments to pay for them
+    // (each reload then waits behind the stage's X loads: vmcnt retires in order -- 7300 cycles for a 1300-cycle phase, measured).
+#define POW3_LANE(ln) int ln = threadIdx.x & 63; asm volatile("" : "+v"(ln))
+    if (CENTER)
+        for (int k = threadIdx.x; k < K; k += 64 * WV) sMu[k] = mu[k];
+    // this wave's slice of P: chunk c <-> features 64 wave + 32 c .. + 32, B-operand fragments of the packed planes (k_pack_p3's
+    // layout: lane (j, q) holds P[32 c' + 8 q + e][16 u + j])
+    bf16x8 ph[2][NT], pm[2][NT];
+    {
+        POW3_LANE(ln);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const bf16x8* src = Ppk3 + (((int64_t)(2 * wave + c) * NTtot + u) * 3) * 64 + ln;
+                ph[c][u] = src[0];
+                pm[c][u] = src[64];
+            }
+    }
+    f32x4 acc2[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc2[m][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // stage range of this workgroup (contiguous, balanced to one stage)
+    const int64_t s0 = (int64_t)blockIdx.x * nstages / gridDim.x, s1 = (int64_t)(blockIdx.x + 1) * nstages / gridDim.x;
+    f32x8 xa[2][2];
+    auto load_x = [&](int64_t s) {
+        POW3_LANE(ln);
+        const int li = ln & 15, lq = ln >> 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t r = min(s * 32 + 16 * t + li, n - 1);   // rows beyond n: the last row (finite); their z is zeroed below
+            const float* p = X + r * ldx + 64 * wave + 8 * lq;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f32x4 lo = ld_stream(p + 32 * c), hi = ld_stream(p + 32 * c + 4);
+                xa[t][c] = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        }
+    };
+    if (s0 < s1) load_x(s0);
+    unsigned char* const myX = sX + wave * XIMG;
+    // product 1 of one 16-row half: operands read back from the wave's image (rows 16 h + i), X fragment as A (rows = samples), P
+    // fragment as B; five piece products per tile, smallest first
+    auto prod1 = [&](f32x4(&acc1)[NT], int h) {
+        POW3_LANE(ln);
+        const int li = ln & 15, lq = ln >> 4;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const unsigned char* a = myX + pow3_xoff(16 * h + li, 4 * c + lq);
+            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(a), xm = *reinterpret_cast<const bf16x8*>(a + 4096),
+                         xl = *reinterpret_cast<const bf16x8*>(a + 8192);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                f32x4 c4 = acc1[u];
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, ph[c][u], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, pm[c][u], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, ph[c][u], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, pm[c][u], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, ph[c][u], c4, 0, 0, 0);
+                acc1[u] = c4;
+            }
+        }
+    };
+    auto park_partials = [&](const f32x4(&acc1)[NT]) {
+        POW3_LANE(ln);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) sZp[(wave * NT + u) * 64 + ln] = acc1[u];
+    };
+    // wave u < NT adds the eight partials of column tile u (fixed order)
+    auto add_partials = [&]() {
+        POW3_LANE(ln);
+        f32x4 zs = sZp[(0 * NT + wave) * 64 + ln];
+#pragma unroll
+        for (int w = 1; w < WV; ++w) zs += sZp[(w * NT + wave) * 64 + ln];
+        return zs;
+    };
+    // the raw fragments of feature chunk c (both row tiles): centred, split into three planes, parked in the wave's image; one
+    // piece at a time (two splits in flight cost 28 registers)
+    auto split_park = [&](int c) {
+        POW3_LANE(ln);
+        const int li = ln & 15, lq = ln >> 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x8 x = xa[t][c];
+            if (CENTER) {
+                const float* mp = sMu + 64 * wave + 32 * c + 8 * lq;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(mp), hi = *reinterpret_cast<const f32x4*>(mp + 4);
+                x -= f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            bf16x8 xh, xm, xl;
+            split3(x, xh, xm, xl);
+            unsigned char* a = myX + pow3_xoff(16 * t + li, 4 * c + lq);
+            *reinterpret_cast<bf16x8*>(a) = xh;
+            *reinterpret_cast<bf16x8*>(a + 4096) = xm;
+            *reinterpret_cast<bf16x8*>(a + 8192) = xl;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    __syncthreads();   // mu
+    // Software pipeline over the stages: the planes of stage s + 1 are produced UNDER product 2 of stage s -- its feature tile m
+    // reads chunks 2 m, 2 m + 1 of every row, so once the fragments of tiles 0, 1 are in registers the image's first half (chunks
+    // 0 .. 3) is free for the next stage's c = 0 pieces, and after those of tiles 2, 3 the second half: the split (180 VALU instructions and twelve
+    // 16-B LDS stores per wave and stage) runs beside the other wave's MFMAs instead of in front of everybody's (phase stamps,
+    // round 5: the split at the head of the stage was 1400 of its 16000 cycles with the matrix pipe idle).
+    if (s0 < s1) {
+        split_park(0);
+        split_park(1);
+        if (s0 + 1 < s1) load_x(s0 + 1);
+    }
+#ifdef PETAL_DEBUG_COUNTERS
+    long long php[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tqp = __builtin_amdgcn_s_memtime();
+#define POW3_STAMP(i) do { const long long _t = __builtin_amdgcn_s_memtime(); php[i] += _t - tqp; tqp = _t; } while (0)
+#else
+#define POW3_STAMP(i) do {} while (0)
+#endif
+    for (int64_t s = s0; s < s1; ++s) {
+        f32x4 zlo = f32x4{0.f, 0.f, 0.f, 0.f}, zhi = zlo;
+        {
+            f32x4 acc1[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            prod1(acc1, 0);
+            POW3_STAMP(0);
+            park_partials(acc1);                 // (ordered behind the previous stage's adders by that stage's last barrier)
+            __syncthreads();
+            POW3_STAMP(1);
+            if (wave < NT) zlo = add_partials();
+            POW3_STAMP(2);
+        }
+        {
+            f32x4 acc1[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            prod1(acc1, 1);
+            POW3_STAMP(3);
+            __syncthreads();                     // the adders have read the first half's partials
+            park_partials(acc1);
+            __syncthreads();
+            POW3_STAMP(4);
+            if (wave < NT) zhi = add_partials();
+        }
+        if (wave < NT) {
+            // lane (i, q): z[row 4 q + r][16 wave + i] (zlo), z[16 + 4 q + r][...] (zhi); rows beyond n are zeroed
+            POW3_LANE(ln);
+            const int li = ln & 15, lq = ln >> 4;
+            const int64_t rb = s * 32 + 4 * lq;
+            f32x8 z8;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z8[r] = rb + r < n ? zlo[r] : 0.f;
+                z8[4 + r] = rb + 16 + r < n ? zhi[r] : 0.f;
+            }
+            if (STOREZ) {
+                float* zp = Z + rb * ldz + 16 * wave + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (rb + r < n) zp[r * ldz] = z8[r];
+                    if (rb + 16 + r < n) zp[(16 + r) * ldz] = z8[4 + r];
+                }
+            }
+            bf16x8 zh, zm, zl;
+            split3(z8, zh, zm, zl);
+            sZB[(wave * 3 + 0) * 64 + ln] = zh;
+            sZB[(wave * 3 + 1) * 64 + ln] = zm;
+            sZB[(wave * 3 + 2) * 64 + ln] = zl;
+        }
+        POW3_STAMP(5);
+        __syncthreads();                         // the z fragments of this stage are published
+        POW3_STAMP(6);
+        // product 2: Y'[16 m + 4 q + r][16 u + i] += sum over the stage's samples; A = X^T (transposed reads), B = z fragments.
+        // Transposed-read addresses (T10): lane 16 g + 4 q' + p of group g supplies block row q', columns 4 p .. 4 p + 3; the block
+        // of k-slots e < 4 is rows 4 g + q', of e >= 4 rows 16 + 4 g + q' (g = q: the lane group IS the k group of the operand).
+        {
+            POW3_LANE(ln);
+            const int trq = (ln >> 2) & 3, trp = ln & 3, lq = ln >> 4;
+#pragma unroll
+            for (int mp = 0; mp < 2; ++mp) {     // feature tiles in PAIRS: one set of z fragments feeds twelve MFMAs
+                bf16x8 ax[2][3];
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    const unsigned char* a0 = myX + pow3_xoff(4 * lq + trq, 2 * (2 * mp + mm) + (trp >> 1)) + 8 * (trp & 1);   // (row + 16: + 2048, same swizzle)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) ax[mm][pl] = lds_tr2(a0 + pl * 4096, a0 + pl * 4096 + 2048);
+                }
+                if (s + 1 < s1) {                // this half of the image has been read for the last time: the next stage's pieces
+                    __builtin_amdgcn_sched_barrier(0);
+                    split_park(mp);
+                }
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    // (ONE set of z fragments, re-read for each pair of feature tiles: its latency is covered by the twelve MFMAs of the
+                    // other wave of the SIMD; kept across the pairs, or fetched a tile ahead, it costs registers the kernel does not have)
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 zh = sZB[(u * 3 + 0) * 64 + ln], zm = sZB[(u * 3 + 1) * 64 + ln], zl = sZB[(u * 3 + 2) * 64 + ln];
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) {
+                        f32x4 c4 = acc2[2 * mp + mm][u];
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][2], zh, c4, 0, 0, 0);   // smallest terms first
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][1], zm, c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][0], zl, c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][1], zh, c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][0], zm, c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][0], zh, c4, 0, 0, 0);
+                        acc2[2 * mp + mm][u] = c4;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // (the next stage's first barrier orders these reads of the z fragments and of the partial buffer before they are rewritten)
+        if (s + 2 < s1) load_x(s + 2);           // the raw registers are free again: three quarters of a stage ahead of their use
+        POW3_STAMP(7);
+    }
+#ifdef PETAL_DEBUG_COUNTERS
+    if ((threadIdx.x & 63) == 0) {
+        for (int e = 0; e < 8; ++e) atomicAdd((unsigned long long*)&g_cyc[e], (unsigned long long)php[e]);
+        atomicAdd((unsigned long long*)&g_cyc[8], (unsigned long long)(s1 - s0));
+    }
+#endif
+    // this workgroup's slab: D[row = 4 q + r][col = i] of tile (m, u) is Y'[64 wave + 16 m + 4 q + r][16 u + i]
+    {
+        POW3_LANE(ln);
+        const int li = ln & 15, lq = ln >> 4;
+        float* out = part + (int64_t)blockIdx.x * K * (16 * NT);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* row = out + (int64_t)(64 * wave + 16 * m + 4 * lq + r) * (16 * NT);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) row[16 * u + li] = acc2[m][u][r];
+            }
+    }
+#undef POW3_LANE
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2p: the `precise` form of C = (A - muA)^T (B - muB): every product and the whole accumulation in fp64 on
 // v_mfma_f64_16x16x4_f64 (exact Pca and FastICA whitening need the small eigenvalues of the Gram matrix, which an fp32
 // accumulation would drown).  A wave owns 32 columns of A (2 m-tiles: one 8-B load per lane, tile t row i <-> m =
@@ -6361,6 +6647,91 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
                        (int)M, (const double*)nullptr, 1, (int)L);
     launch_check();
     gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, M, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, true, nullptr, p_planes == 2);
+}
+
+// ---- the fused power-iteration pass (k_pow3) ------------------------------------------------------------------------------
+static bool pow3_ok(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N, const void* Z, int64_t ldz) {
+    static const bool off = getenv("PETAL_NO_POW3") != nullptr;
+    static const int64_t min_rows = [] { const char* e = getenv("PETAL_POW3_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();
+    return !off && dt == F32 && gemm_split_product(d) && K == 512 && N % 16 == 0 && N >= 16 && N <= 80 && n >= min_rows &&
+           n < (int64_t(1) << 40) && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && (!Z || (ldz >= N && aligned16(Z)));
+}
+bool op_power_pass_applies(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N) {
+    return pow3_ok(d, dt, X, n, K, ldx, mu, N, nullptr, 0);
+}
+// Ppk3: the packed planes of the K x N small operand (k_pack_p3's layout; planes 0 and 1 are read)
+static void launch_pow3(Dev* d, const float* X, int64_t n, int64_t ldx, const float* mu, const bf16x8* Ppk3, int64_t N, float* Z, int64_t ldz,
+                        double* Y, int64_t ldy) {
+    const int NT = (int)(N / 16);
+    const int64_t nstages = cdiv(n, 32);
+    const int grid = (int)std::min<int64_t>(num_cus(d), nstages);
+    float* part = (float*)dev_alloc(d, sizeof(float) * (size_t)grid * 512 * N);
+    const size_t lds = (size_t)8 * 12288 + (size_t)8 * NT * 1024 + (size_t)NT * 3072 + 2048;
+#define POW3_GO(NTv, CE, SZ)                                                                                                      \
+    do {                                                                                                                          \
+        set_max_lds(d, reinterpret_cast<const void*>(k_pow3<NTv, CE, SZ>));                                                       \
+        hipLaunchKernelGGL((k_pow3<NTv, CE, SZ>), dim3(grid), dim3(512), lds, d->stream, X, n, ldx, mu, Ppk3, NT, part, Z, ldz, nstages); \
+    } while (0)
+#define POW3_NT(NTv)                                                                                                              \
+    do {                                                                                                                          \
+        if (mu && Z) POW3_GO(NTv, true, true); else if (mu) POW3_GO(NTv, true, false);                                            \
+        else if (Z) POW3_GO(NTv, false, true); else POW3_GO(NTv, false, false);                                                   \
+    } while (0)
+    {
+        TagScope ts(d);
+        switch (NT) {
+            case 5: POW3_NT(5); break;
+            case 4: POW3_NT(4); break;
+            case 3: POW3_NT(3); break;
+            case 2: POW3_NT(2); break;
+            default: POW3_NT(1); break;
+        }
+        launch_check();
+        ts.stop();
+    }
+#undef POW3_NT
+#undef POW3_GO
+    hipLaunchKernelGGL(k_sum_parts4, dim3(cdiv(512 * N, 128)), dim3(256), 0, d->stream, part, (int64_t)grid, (int64_t)512 * N, Y, N, ldy);
+    launch_check();
+    dev_free(d, part);
+}
+bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
+                   void* Z, int64_t ldz, double* Y, int64_t ldy) {
+    if (!pow3_ok(d, dt, X, n, K, ldx, mu, N, Z, ldz)) return false;
+    const int64_t total = (K / 32) * (N / 16) * 64;
+    bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
+    hipLaunchKernelGGL(k_pack_p3, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk3, (int)(N / 16), total);
+    launch_check();
+    launch_pow3(d, (const float*)X, n, ldx, (const float*)mu, Ppk3, N, (float*)Z, ldz, Y, ldy);
+    dev_free(d, Ppk3);
+    return true;
+}
+bool op_rebase_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
+                          int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
+                          double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy) {
+    static const bool no_rt = getenv("PETAL_NO_TRSM") != nullptr;
+    if (!pow3_ok(d, dt, X, n, K, ldx, mu, M, Z, ldz) || no_rt || L == 0 || L > CHOL2_MAXL || M > TRSM_MAXM || M < L || P_out == nullptr) return false;
+    set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
+    hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead,
+                       (int)M, (const double*)nullptr, 1, (int)L);
+    launch_check();
+    const int NTtot = (int)(M / 16);
+    const int64_t total = (K / 32) * (int64_t)NTtot * 64;
+    bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
+    switch (NTtot) {   // P_out = A R^-1, ROUNDED to two planes, and its operand planes
+#define PETAL_TRSM_CASE(NB)                                                                                                            \
+    case NB:                                                                                                                           \
+        hipLaunchKernelGGL((k_trsm_pack<NB, true>), dim3(cdiv(K, 16)), dim3(64), trsm_lds_bytes(16 * NB), d->stream, A, lda, T, ldt, K, P_out, \
+                           ldpo, Ppk3, NTtot);                                                                                         \
+        break
+        PETAL_TRSM_CASE(1); PETAL_TRSM_CASE(2); PETAL_TRSM_CASE(3); PETAL_TRSM_CASE(4); PETAL_TRSM_CASE(5);
+#undef PETAL_TRSM_CASE
+        default: throw std::runtime_error("op_rebase_power_pass: order out of range");
+    }
+    launch_check();
+    launch_pow3(d, (const float*)X, n, ldx, (const float*)mu, Ppk3, M, (float*)Z, ldz, Y, ldy);
+    dev_free(d, Ppk3);
+    return true;
 }
 
 void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz,

@@ -110,6 +110,17 @@ void op_gemm_xp_absmax(Dev*, int dtype, const void* X, int64_t n, int64_t K, int
 void op_rebase_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                   int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
                   double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes = 2);
+// One FUSED power-iteration pass, the two products of pca.rs:711 + 714 in ONE pass over X:
+//     Y (K x N fp64, ldy) = (X - mu)^T ((X - mu) P),     Z (nullable, n x N, ldz) = (X - mu) P
+// with P rounded to the sum of its two leading bf16 pieces (a caller that needs P to fp32 accuracy uses op_gemm_xp + op_gemm_atb).
+// Returns false, NOTHING done, where no fused kernel exists for the shape / mode (op_power_pass_applies says so up front).
+bool op_power_pass_applies(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N);
+bool op_power_pass(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
+                   void* Z, int64_t ldz, double* Y, int64_t ldy);
+// the same behind one re-basing step (arguments as op_rebase_xp, p_planes = 2): P_out = A R^-1 rounded, then the fused pass with it
+bool op_rebase_power_pass(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
+                          int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
+                          double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy);
 // Was a 16-bit (two-plane) rounding of the sketch matrix and of the re-based iterates harmless for the spectrum this fit found?
 // A rounding E of the basis P (|E_ij| <= eps2 |P_ij|) reaches the next iterate as C E, C = Xc^T Xc: directions the block already
 // spans are harmless, the part from BEYOND the block -- sum_{i > L} sigma_i^2 v_i (v_i^T E), of size eps2 T with

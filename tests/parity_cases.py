@@ -203,6 +203,33 @@ def gemm_exact(ctx, n, K, N, seed=0, device=False, dtype=np.float32):
     assert np.array_equal(c, x.astype(np.float64).T @ x.astype(np.float64))
 
 
+def power_pass_exact(ctx, n, K, N, seed=0, device=False, expect_fused=None, centre=True):
+    """y = (x - mu)^T ((x - mu) p) and z = (x - mu) p on exact-integer data (every product and partial sum an integer below 2^24:
+    fp32 accumulation is exact, so a slip in the fused kernel's fragment layouts, LDS images or row masks is an exact mismatch)"""
+    rng = np.random.default_rng(seed)
+    x = rng.integers(-4, 5, (n, K)).astype(np.float32)
+    p = rng.integers(-3, 4, (K, N)).astype(np.float32)
+    mu = rng.integers(-2, 3, K).astype(np.float32) if centre else None
+    xin = x
+    if device:
+        import torch
+        xin = torch.from_numpy(x).cuda()
+    xc = x.astype(np.float64) - (mu.astype(np.float64) if centre else 0.0)
+    zr = xc @ p.astype(np.float64)
+    yr = xc.T @ zr
+    assert np.abs(zr).max() < 2 ** 24 and np.abs(yr).max() < 2 ** 40
+    for want_z in (False, True):
+        y, z, fused = petal.power_pass(xin, p, mu, want_z=want_z, ctx=ctx)
+        if expect_fused is not None:
+            assert fused == expect_fused, f"fused = {fused}"
+        assert np.array_equal(y, yr), f"power_pass y mismatch n={n} K={K} N={N} fused={fused}: max|d|={np.abs(y - yr).max()} at {np.argwhere(y != yr)[:5].tolist()}"
+        if want_z:
+            if device:
+                z = z.cpu().numpy()
+            assert np.array_equal(z.astype(np.float64), zr), f"power_pass z mismatch: max|d|={np.abs(z - zr).max()} rows {np.unique(np.argwhere(z != zr)[:, 0])[:8].tolist()}"
+    return fused
+
+
 # ---- model parity against the oracle on seeded synthetic inputs -----------------------------------
 def decided_signs(u, k, margin=1e-3):
     """columns j < k of the oracle's U (after svd_flip, pca.rs:826-839) whose deciding element is NOT a near-tie: the largest |u|

@@ -31,6 +31,24 @@ def test_gemm_kernels_exact(ctx, n, K, N):
     pc.gemm_exact(ctx, n, K, N, seed=n + K + N)
 
 
+@pytest.mark.parametrize("n,N", [(8192, 80), (20011, 74), (9000, 64), (8200, 48), (33333, 30), (8193, 16), (12000, 7)])
+def test_fused_power_pass_exact(ctx, n, N):
+    """The fused power-iteration kernel (k_pow3: both products of src/pca.rs:711 + 714 in one pass over X, K = 512) on exact-integer
+    data, with and without centring, with and without the stored iterate, host and device inputs: ragged last stages, every
+    column-tile count, stage counts around the number of CUs.  In fp32-MFMA mode the same entry runs K1 + K2 (fused = False)."""
+    import petal_decomposition_amd as petal
+    fused = pc.power_pass_exact(ctx, n, 512, N, seed=n + N, device=(n % 2 == 0))
+    pc.power_pass_exact(ctx, n, 512, N, seed=n + N + 1, centre=False)
+    st = ctx.stats()
+    assert fused == (st["pow_launches"] > 0 or st["pow_ms"] == 0.0 and fused)   # (the stats of the last call; pow_launches counts only under profiling)
+
+
+def test_fused_power_pass_falls_back_outside_its_shape(ctx):
+    assert pc.power_pass_exact(ctx, 3000, 512, 80, seed=1) is False      # too few rows for a persistent launch: K1 + K2
+    assert pc.power_pass_exact(ctx, 9000, 256, 80, seed=2) is False      # K != 512
+    assert pc.power_pass_exact(ctx, 9000, 512, 96, seed=3) is False      # more than five column tiles
+
+
 def test_gemm_kernels_exact_random_shapes(ctx):
     """Seeded random shapes through both X-streaming kernels (ragged row counts, K % 32 == 16, several column panels,
     shapes that fall back to the generic kernels): exact-integer data, so any indexing slip is an exact mismatch."""

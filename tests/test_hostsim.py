@@ -52,6 +52,17 @@ def test_components_beyond_a_ring_slot(ctx):
     pc.rpca_parity(ctx, 700, 2048, 512, 1, seed=5, dtype=np.float64, tol=1e-7)
 
 
+def test_power_pass_entry(ctx):
+    """petal_power_pass through the host simulation: the fused form (split-product mode) and the K1 + K2 fall-back"""
+    assert pc.power_pass_exact(ctx, 300, 48, 20, seed=1) is False
+    ctx.set_gemm_mode("bf16x3")
+    try:
+        assert pc.power_pass_exact(ctx, 300, 48, 20, seed=2) is True
+        assert pc.power_pass_exact(ctx, 300, 48, 100, seed=3) is False
+    finally:
+        ctx.set_gemm_mode("fp32")
+
+
 def test_rpca_f64_and_no_centering(ctx):
     pc.rpca_parity(ctx, 800, 32, 4, 7, seed=3, dtype=np.float64, tol=1e-9)
     pc.rpca_parity(ctx, 800, 32, 4, 7, seed=4, centering=False)

@@ -23,6 +23,10 @@ BUDGETS = [
     (r"k_xp3<4, 5, 1, (true|false), 4, 2, [23]>$", 232, 0, "K1 split-product, l = 74"),
     (r"k_xp3<2, 9, 1, (true|false), 8, 2, [23]>$", 180, 0, "K1 split-product, l = 138"),
     (r"k_xp3<", 256, 0, "every K1 split-product instantiation: no scratch"),
+    # (one 8-wave workgroup per CU, two waves per SIMD: 256 is the whole budget, and a spilled P fragment is reloaded BEHIND the
+    # stage's X loads -- vmcnt retires in order -- which cost the first build 7300 cycles in a 1300-cycle phase)
+    (r"k_pow3<5, (true|false), (true|false)>$", 256, 0, "fused power-iteration pass, l = 74 (configs[1], the north-star point)"),
+    (r"k_pow3<", 256, 0, "every fused-pass instantiation: no scratch"),
     (r"k_ica3<2>$", 128, 0, "FastICA step, 32 components: 4 waves/SIMD"),
     (r"k_ica3<4>$", 256, 0, "FastICA step, 64 components"),
     # (3 waves/SIMD.  Forcing 4 with __launch_bounds__(256, 4) gives 96 registers and a slower kernel -- 3244 vs 2760 us at
