@@ -269,16 +269,18 @@ def main():
     for _ in range(args.warmup):
         model.fit(x, omega=omega)
     sync_all()
-    acc = {"xp_ms": 0.0, "xp_launches": 0, "atb_ms": 0.0, "atb_launches": 0, "allreduce_ms": 0.0, "allreduce_timed": 0}
+    acc = {"xp_ms": 0.0, "xp_launches": 0, "atb_ms": 0.0, "atb_launches": 0, "pow_ms": 0.0, "pow_launches": 0,
+           "allreduce_ms": 0.0, "allreduce_timed": 0}
+    redo = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.fit(x, omega=omega)
         st = ctx.stats()
         for key in acc:
             acc[key] += st[key]
+        redo = max(redo, int(st["rpca_redo"]))
     sync_all()
     elapsed = time.perf_counter() - t0
-    pass_flops, pass_bytes = st["pass_flops"], st["pass_bytes"]
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if args.share_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,13 +289,16 @@ def main():
     out = None
     if rank == 0:
         # dominant kernel = the power-iteration GEMM kind with the larger summed time
-        kinds = {"K1 (Z = Xc.P)": (acc["xp_ms"], acc["xp_launches"]),
-                 "K2 (Y = Xc^T.Z)": (acc["atb_ms"], acc["atb_launches"])}
-        per = {kname: (ms / max(cnt, 1)) for kname, (ms, cnt) in kinds.items()}
-        # (both kinds run n_iter + 1 times per fit; level-1 profiling samples them alternately, so the SUMS over a few steps
-        # say which kind was sampled more often, not which is slower: the dominant kind is the one with the longer launch)
-        dom = max(per, key=per.get)
-        roofline = roofline_entry(dom, per, pass_flops, pass_bytes, args.gemm, args.pmc_traffic, n, d, l)
+        sampled = {"K1 (Z = Xc.P)": (acc["xp_ms"], acc["xp_launches"]),
+                   "K2 (Y = Xc^T.Z)": (acc["atb_ms"], acc["atb_launches"]),
+                   "K3 (Y' = Xc^T.(Xc.P), fused)": (acc["pow_ms"], acc["pow_launches"])}
+        per = {kname: (ms / max(cnt, 1)) for kname, (ms, cnt) in sampled.items()}
+        # (level-1 profiling samples ONE launch per fit, the kind rotating: the SUMS over a few steps say which kind was sampled
+        # more often, not which is slower.  The dominant kernel is the kind a fit spends most of its time in: the fused pass where
+        # it runs -- n_iter + 1 launches per fit, K1 / K2 then do not run in the loop at all -- else the longer of K1 / K2)
+        kinds = kind_table(n, d, l, args.gemm, two_plane=(redo == 0 and n_iter > 0))
+        dom = "K3 (Y' = Xc^T.(Xc.P), fused)" if per["K3 (Y' = Xc^T.(Xc.P), fused)"] > 0 else max(per, key=per.get)
+        roofline = roofline_entry(dom, per, kinds, args.gemm, args.pmc_traffic, n, d, l)
         out = {
             "metric": "samples/sec for RandomizedPca.fit() on n x d fp32",
             "value": round(n_total * args.steps / elapsed, 1),
@@ -317,11 +322,20 @@ def main():
                        "collective": collective, "clock_ramp_s": args.clock_ramp_s},
             "roofline": roofline,
             "fit_roofline": fit_roofline(n, d, l, n_iter, 4, args.gemm, elapsed / args.steps * 1e3),
+            "rpca_redo": redo,   # 0: every timed fit stood on its optimistic (two-plane, fused) run
             # what went through the collective per fit (sharded runs; zeros on one GPU).  The stream time is sampled: one
             # bracketed all-reduce per fit, the index rotating from fit to fit -> average call time x calls per fit
             "collective": collective_entry(st, acc, args.steps),
         }
 
+        if per["K3 (Y' = Xc^T.(Xc.P), fused)"] > 0:
+            v = per["K3 (Y' = Xc^T.(Xc.P), fused)"]
+            out["fused_pass"] = {"kernel": "k_pow3", "avg_launch_ms": round(v, 5), "launches_per_fit": n_iter + 1,
+                                 "algorithmic_bytes": 4.0 * (n * d + 2 * d * l), "GB/s_algorithmic": round(4.0 * (n * d + 2 * d * l) / (v * 1e-3) / 1e9, 1),
+                                 "note": "Y' = Xc^T (Xc P): both products of a power iteration in one pass, X read ONCE, Z neither written "
+                                         "nor read (the last pass of a fit also stores Z)"}
+        if not strong or world == 1:
+            out["serial_chain"] = serial_chain(ctx, model, x, omega, elapsed / args.steps * 1e3)
         if world == 1 and x_host is not None:
             # host-ndarray-in rate (H2D over PCIe included) -- informational, never `value`
             model.fit(x_host, omega=omega)
@@ -428,70 +442,124 @@ BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: Peak BF16 MFMA, dense (never 
 INFINITY_CACHE_BYTES = 256 * 1024 * 1024
 
 
-def pass_bound(pass_flops, pass_bytes, mode):
+def pass_bound(pass_flops, pass_bytes, mode, pieces=6.0):
     """Which roofline binds ONE power-iteration GEMM launch of this shape -- computed, not assumed: the largest of
       hbm        algorithmic bytes / 8 TB/s
-      mfma-bf16  (bf16x3 mode) six bf16 piece products per fp32 product: 6 x algorithmic flops / 2.5 PFLOP/s dense
+      mfma-bf16  (bf16x3 mode) `pieces` bf16 piece products per fp32 product -- six, or the FIVE a launch issues when its small
+                 operand is a two-plane one (K1 behind a re-basing, K1 with the sketch matrix of an optimistic fit), or 5.5 for the
+                 fused pass (five in its first product, six in its second): pieces x algorithmic flops / 2.5 PFLOP/s dense
       mfma-fp32  (fp32 mode) algorithmic flops / 157.3 TFLOP/s
     Returns {"bound": "hbm" | "mfma", "pipe": ..., "floor_s": the binding time, "times_s": every candidate}."""
     times = {"hbm": pass_bytes / (HBM_PEAK_GBS * 1e9)}
     if mode == "bf16x3":
-        times["mfma-bf16"] = 6.0 * pass_flops / (BF16_MFMA_PEAK_TF * 1e12)
+        times["mfma-bf16"] = pieces * pass_flops / (BF16_MFMA_PEAK_TF * 1e12)
     else:
         times["mfma-fp32"] = pass_flops / (FP32_MFMA_PEAK_TF * 1e12)
     pipe = max(times, key=times.get)
     return {"bound": "hbm" if pipe == "hbm" else "mfma", "pipe": pipe, "floor_s": times[pipe], "times_s": times}
 
 
-def roofline_entry(dom, per, pass_flops, pass_bytes, mode, traffic_override, n, d, l):
+def kind_table(n, d, l, mode, two_plane):
+    """algorithmic work of ONE launch of each kernel kind: (flops, bytes, bf16 piece products per fp32 product)"""
+    gemm = (2.0 * n * d * l, 4.0 * (n * d + n * l + d * l))
+    return {"K1 (Z = Xc.P)": gemm + (5.0 if two_plane and mode == "bf16x3" else 6.0,),
+            "K2 (Y = Xc^T.Z)": gemm + (6.0,),
+            # both products of a power iteration in ONE pass: X is read once, Z is neither written nor read
+            "K3 (Y' = Xc^T.(Xc.P), fused)": (4.0 * n * d * l, 4.0 * (n * d + 2 * d * l), 5.5)}
+
+
+KERNEL_NAMES = {"K1": "k_xp3", "K2": "k_atb3", "K3": "k_pow3"}
+
+
+def roofline_entry(dom, per, kinds, mode, traffic_override, n, d, l):
     """The `roofline` object of the bench line for the dominant kernel `dom`, against the roofline that BINDS its shape
-    (pass_bound): "hbm" -> achieved = algorithmic bytes / duration vs 8 TB/s; "mfma" on the bf16 pipe -> achieved = the six
-    bf16 piece products' flops / duration vs 2.5 PFLOP/s dense (l = 138: the matrix pipe binds, not the X stream); "mfma" on
-    the fp32 pipe (--gemm fp32) -> algorithmic flops / duration vs 157.3 TFLOP/s.  frac = floor time / measured duration."""
+    (pass_bound): "hbm" -> achieved = algorithmic bytes / duration vs 8 TB/s; "mfma" on the bf16 pipe -> achieved = the bf16
+    piece products' flops / duration vs 2.5 PFLOP/s dense (the fused pass at l = 74 and every kernel at l = 138: the matrix pipe
+    binds, not the X stream); "mfma" on the fp32 pipe (--gemm fp32) -> algorithmic flops / duration vs 157.3 TFLOP/s.
+    frac = floor time / measured duration.  `kinds`: kind_table()."""
     avg_ms = per[dom]
-    tf = pass_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    gbs = pass_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    b = pass_bound(pass_flops, pass_bytes, mode)
+    flops, nbytes, pieces = kinds[dom]
+    tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    gbs = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    b = pass_bound(flops, nbytes, mode, pieces)
+    short = dom.split(" ")[0]
     traffic, measured_at = (traffic_override, "--pmc-traffic") if traffic_override is not None else \
-        pmc_traffic(n, d, l, mode, dom.split(" ")[0], with_commit=True)
-    other = {kname: {"avg_launch_ms": round(v, 5), "GB/s_algorithmic": round(pass_bytes / (v * 1e-3) / 1e9, 1) if v > 0 else 0.0,
-                     "fp32_equivalent_TFLOP/s": round(pass_flops / (v * 1e-3) / 1e12, 3) if v > 0 else 0.0,
-                     "frac_of_binding_roofline": round(b["floor_s"] / (v * 1e-3), 4) if v > 0 else 0.0}
-             for kname, v in per.items() if kname != dom}
+        pmc_traffic(n, d, l, mode, short, with_commit=True)
+    other = {}
+    for kname, v in per.items():
+        if kname == dom or v <= 0:
+            continue
+        f2, b2, p2 = kinds[kname]
+        other[kname] = {"avg_launch_ms": round(v, 5), "GB/s_algorithmic": round(b2 / (v * 1e-3) / 1e9, 1),
+                        "fp32_equivalent_TFLOP/s": round(f2 / (v * 1e-3) / 1e12, 3), "piece_products": p2,
+                        "frac_of_binding_roofline": round(pass_bound(f2, b2, mode, p2)["floor_s"] / (v * 1e-3), 4)}
     common = {"pipe": b["pipe"],
               "candidate_floors_us": {k2: round(v * 1e6, 2) for k2, v in b["times_s"].items()},
-              "kernel": dom + (" k_xp3 / k_atb3 (bf16x3 split-product, fp32 accumulate)" if mode == "bf16x3"
+              "kernel": dom + (f" {KERNEL_NAMES.get(short, '')} (bf16x3 split-product, fp32 accumulate)" if mode == "bf16x3"
                                else " k_xp_* / k_atb_mfma (fp32 MFMA)"),
+              "piece_products": pieces if mode == "bf16x3" else None,
               "traffic": traffic, "traffic_measured_at": measured_at,
               "traffic_note": "FETCH_SIZE x 2 + WRITE_SIZE (the gfx950 guide's correction); the x 2 is exact for 128-B requests but "
                               "over-counts reads issued as 64-B segments such as K2's Z stage (factor 1.5 measured, profiles/r02_fetch_size_calibration.txt)",
-              "avg_launch_ms": round(avg_ms, 5), "flops_per_launch": pass_flops,
-              "bytes_per_launch": pass_bytes, "other_kernel": other,
+              "avg_launch_ms": round(avg_ms, 5), "flops_per_launch": flops,
+              "bytes_per_launch": nbytes, "other_kernel": other,
               "hbm_GBps_algorithmic": round(gbs, 1), "fp32_equivalent_TFLOP/s": round(tf, 3)}
     if b["pipe"] == "hbm":
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **common}
     if b["pipe"] == "mfma-bf16":
-        tf6 = 6.0 * tf
-        return {"bound": "mfma", "achieved": round(tf6, 2), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(tf6 / BF16_MFMA_PEAK_TF, 4), **common,
-                "achieved_note": "bf16 flops issued for the algorithmic product: 6 piece products x 2 n d l"}
+        tfp = pieces * tf
+        return {"bound": "mfma", "achieved": round(tfp, 2), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(tfp / BF16_MFMA_PEAK_TF, 4), **common,
+                "achieved_note": f"bf16 flops issued for the algorithmic product: {pieces:g} piece products per fp32 product"}
     return {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(tf / FP32_MFMA_PEAK_TF, 4), **common}
 
 
 def fit_roofline(n, d, l, n_iter, esz, mode, ms_per_step):
-    """Whole-fit fraction: the algorithmic floor of one RandomizedPca.fit -- (2 n_iter + 2) GEMM passes at their binding
-    roofline, one means pass (n d bytes) and U = Q.Uh (2 n l^2 flop, 2 n l bytes) -- over the measured time per fit."""
-    flops, nbytes = 2.0 * n * d * l, float(esz) * (n * d + n * l + d * l)
-    b = pass_bound(flops, nbytes, mode)
-    passes = 2 * n_iter + 2
+    """Whole-fit fraction: the algorithmic floor of one RandomizedPca.fit over the measured time per fit.  The floor is that of
+    the cheapest pass structure the product has: n_iter + 1 FUSED passes Y' = Xc^T (Xc P) (one read of X each; 5 + 6 bf16 piece
+    products) where the fused kernel exists (bf16x3 mode, d = 512, l <= 80), (2 n_iter + 2) separate GEMM passes otherwise --
+    each at its binding roofline -- plus one means pass (n d bytes) and U = Q.Uh (2 n l^2 flop, 2 n l bytes)."""
+    fused = mode == "bf16x3" and d == 512 and l <= 80 and n_iter >= 1
+    if fused:
+        b = pass_bound(4.0 * n * d * l, float(esz) * (n * d + 2 * d * l), mode, 5.5)
+        passes = n_iter + 1
+    else:
+        b = pass_bound(2.0 * n * d * l, float(esz) * (n * d + n * l + d * l), mode)
+        passes = 2 * n_iter + 2
     means_s = esz * n * d / (HBM_PEAK_GBS * 1e9)
     u_s = pass_bound(2.0 * n * l * l, float(esz) * 2 * n * l, mode)["floor_s"]
     floor_ms = (passes * b["floor_s"] + means_s + u_s) * 1e3
     return {"floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ms_per_step, 4) if ms_per_step > 0 else 0.0,
-            "passes": passes, "pass_floor_us": round(b["floor_s"] * 1e6, 2), "pass_pipe": b["pipe"],
-            "note": "floor = (2 n_iter + 2) GEMM passes at their binding roofline + the means pass + U = Q.Uh; the serial "
-                    "small-matrix steps between the passes have no floor of their own here"}
+            "passes": passes, "pass_kind": "fused (one read of X per power iteration)" if fused else "K1 + K2",
+            "pass_floor_us": round(b["floor_s"] * 1e6, 2), "pass_pipe": b["pipe"],
+            "note": "floor = the passes over X at their binding roofline + the means pass + U = Q.Uh; the serial small-matrix "
+                    "steps between the passes have no floor of their own here (serial_chain_ms reports them)"}
+
+
+def serial_chain(ctx, model, x, omega, ms_per_step, reps=8):
+    """The replicated small-matrix chain of a fit: time per fit minus every row-streaming kernel and every all-reduce.  The kernel
+    sums come from a few extra fits with EVERY tagged launch bracketed (profiling level 2; the bracketing itself slows those fits,
+    so their own wall time is not used): chain = ms_per_step of the timed region - (K1 + K2 + K3 + means pass + U product + comm).
+    This is the part of a sharded fit that does not shrink with the number of GPUs."""
+    ctx.set_profiling(2)
+    sums = []
+    try:
+        for _ in range(reps):
+            model.fit(x, omega=omega)
+            st = ctx.stats()
+            sums.append({k: st[k] for k in ("xp_ms", "atb_ms", "pow_ms", "stream_ms", "allreduce_ms")} |
+                        {"launches": int(st["xp_launches"] + st["atb_launches"] + st["pow_launches"] + st["stream_launches"])})
+    finally:
+        ctx.set_profiling(True)
+    med = {k: float(np.median([s_[k] for s_ in sums])) for k in sums[0]}
+    streaming = med["xp_ms"] + med["atb_ms"] + med["pow_ms"] + med["stream_ms"]
+    return {"serial_chain_ms": round(ms_per_step - streaming - med["allreduce_ms"], 4),
+            "streaming_kernels_ms": round(streaming, 4), "allreduce_ms": round(med["allreduce_ms"], 4),
+            "streaming_launches": int(med["launches"]),
+            "breakdown_ms": {k: round(v, 4) for k, v in med.items() if k.endswith("_ms")},
+            "note": "ms_per_step minus the bracketed row-streaming kernels (K1, K2, fused pass, means pass, U = Z (T Uh)) and "
+                    "all-reduces: Cholesky / triangular solve / Gram / eigen-solve / slab combines / launch gaps -- replicated on every rank"}
 
 
 def padded_pitch_extra(petal, ctx, torch, model, x, omega, steps=20, pad_elems=32):

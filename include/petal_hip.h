@@ -83,6 +83,9 @@ typedef struct petal_stats {
                                   16-bit rounding of the sketch matrix / iterates was not harmless); 2: redone on the robust path */
     double  pow_ms;            /* fused power-iteration pass Y' = Xc^T (Xc P) (one pass over X): summed kernel time           */
     int64_t pow_launches;
+    double  stream_ms;         /* the other row-streaming kernels of a RandomizedPca fit (means pass, U = Z (T Uh)): with profiling at
+                                  level 2, fit time - (xp + atb + pow + stream + allreduce) is the replicated small-matrix chain   */
+    int64_t stream_launches;
 } petal_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -110,9 +113,15 @@ int         petal_ctx_set_profiling(petal_ctx* ctx, int profiling);
  *   PETAL_GEMM_SPLIT_BF16X3 (default): every fp32 operand is split exactly into three bf16 pieces and the product is the
  *     sum of the six piece products of weight >= 2^-16, on the bf16 matrix cores with fp32 accumulation (dropped terms
  *     <= 2^-24 relative, below one fp32 rounding); 2.7x less matrix-pipe time, the kernels become HBM-bound;
- *   PETAL_GEMM_FP32_MFMA: v_mfma_f32_16x16x4_f32, exact fp32 products.  Env PETAL_GEMM=fp32 selects it at ctx creation. */
+ *     RandomizedPca runs OPTIMISTICALLY in this mode: the sketch matrix and the re-based iterates are taken on two bf16 planes (16
+ *     significant bits), which makes the fused one-pass power iteration possible, and a verdict formed from the spectrum the fit
+ *     found sends heavy-tailed data back through the pipeline with three-plane operands (petal_stats.rpca_redo = 1: twice the time);
+ *   PETAL_GEMM_FP32_MFMA: v_mfma_f32_16x16x4_f32, exact fp32 products.  Env PETAL_GEMM=fp32 selects it at ctx creation;
+ *   PETAL_GEMM_SPLIT_BF16X3_EXACT: the split-product kernels with three-plane operands from the start -- for callers who know their
+ *     spectra decay slowly (no optimistic run, no redo).  Env PETAL_GEMM=bf16x3-exact. */
 #define PETAL_GEMM_SPLIT_BF16X3 0
 #define PETAL_GEMM_FP32_MFMA 1
+#define PETAL_GEMM_SPLIT_BF16X3_EXACT 2
 int         petal_ctx_set_gemm_mode(petal_ctx* ctx, int mode);
 int         petal_get_stats(const petal_ctx* ctx, petal_stats* out);
 

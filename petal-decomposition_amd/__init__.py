@@ -25,7 +25,7 @@ PETAL_OK, PETAL_INVALID_INPUT, PETAL_LINALG_ERROR, PETAL_DEVICE_ERROR = 0, 1, 2,
 PETAL_F32, PETAL_F64 = 0, 1
 PETAL_HOST, PETAL_DEVICE = 0, 1
 PETAL_SUM, PETAL_MAX, PETAL_MIN = 0, 1, 2
-GEMM_SPLIT_BF16X3, GEMM_FP32_MFMA = 0, 1
+GEMM_SPLIT_BF16X3, GEMM_FP32_MFMA, GEMM_SPLIT_BF16X3_EXACT = 0, 1, 2
 ICA_TEXTBOOK, ICA_REFERENCE_LITERAL = 0, 1
 
 
@@ -67,7 +67,8 @@ class petal_stats(C.Structure):
                 ("allreduce_calls", C.c_int64), ("allreduce_bytes", C.c_double),
                 ("allreduce_ms", C.c_double), ("allreduce_timed", C.c_int64),
                 ("x_row_pitch_bytes", C.c_int64), ("x_zero_copy", C.c_int64),
-                ("rpca_redo", C.c_int64), ("pow_ms", C.c_double), ("pow_launches", C.c_int64)]
+                ("rpca_redo", C.c_int64), ("pow_ms", C.c_double), ("pow_launches", C.c_int64),
+                ("stream_ms", C.c_double), ("stream_launches", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -246,9 +247,10 @@ class Context:
         self.check(self.lib.petal_ctx_set_profiling(self._h, int(level)))
 
     def set_gemm_mode(self, mode):
-        """GEMM_SPLIT_BF16X3 (default) or GEMM_FP32_MFMA; also accepts "bf16x3" / "fp32" (petal_hip.h)."""
+        """GEMM_SPLIT_BF16X3 (default), GEMM_FP32_MFMA or GEMM_SPLIT_BF16X3_EXACT; also accepts "bf16x3" / "fp32" / "bf16x3-exact"
+        (petal_hip.h)."""
         if isinstance(mode, str):
-            mode = {"bf16x3": GEMM_SPLIT_BF16X3, "fp32": GEMM_FP32_MFMA}[mode]
+            mode = {"bf16x3": GEMM_SPLIT_BF16X3, "fp32": GEMM_FP32_MFMA, "bf16x3-exact": GEMM_SPLIT_BF16X3_EXACT}[mode]
         self.check(self.lib.petal_ctx_set_gemm_mode(self._h, int(mode)))
 
     def stats(self) -> dict:

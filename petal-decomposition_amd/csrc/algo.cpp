@@ -384,6 +384,8 @@ void finish_stats(petal_ctx& c, const Timer& t) {
     c.stats.ica_step_launches = kt.launches[TAG_ICA];
     c.stats.pow_ms = kt.ms[TAG_POW];
     c.stats.pow_launches = kt.launches[TAG_POW];
+    c.stats.stream_ms = kt.ms[TAG_STREAM];
+    c.stats.stream_launches = kt.launches[TAG_STREAM];
     c.stats.allreduce_ms = kt.ms[TAG_COMM];
     c.stats.allreduce_timed = kt.launches[TAG_COMM];
 }
@@ -547,7 +549,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // The column-means pass is queued FIRST: the device starts on it at once, and the host's copy of Omega into the pinned ring
     // runs beside it.
     if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
+    dev_set_tag(c.dev, TAG_STREAM);
     column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq, sharded(c) && centering ? pro.sums : nullptr);
+    dev_set_tag(c.dev, TAG_NONE);
     if (sharded(c)) {
         P = DBuf(c.dev, sizeof(double) * dp * LP);
         op_pad_to_f64(c.dev, F64, P.f64(), dp, LP, pro.draw, d, L, l_req, tvp, 2 + LP);
@@ -587,7 +591,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // beyond the block is damped by every later product), NOT on slowly decaying spectra, where it costs parity with a run from
     // the un-rounded Omega 10 - 80x (measured, EXPERIMENTS.md round 5).  So the first run uses them OPTIMISTICALLY (exact = false)
     // and a verdict formed from the spectrum the fit itself found (op_tail_verdict) sends a heavy-tailed fit back through the
-    // pipeline with three planes everywhere (exact = true); the ctx remembers the verdict for its next fit.
+    // pipeline with three planes everywhere (exact = true).  Nothing is remembered from fit to fit: the same input gives the same
+    // bits whatever the ctx ran before (a caller who knows the data selects PETAL_GEMM_SPLIT_BF16X3_EXACT and skips the first run).
     const bool two_plane_applies = dt == F32 && dev_gemm_mode(c.dev) == 0 && n_iter > 0;
     static const double p2_thr = [] { const char* e = getenv("PETAL_P2_VERDICT_THR"); return e ? atof(e) : 4e-6; }();
     auto pipeline = [&](bool robust, bool exact) {
@@ -737,8 +742,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // solves with Jacobi.  Saves the two fallback launches that return at once on every separated spectrum.
     if (!robust) op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, false, LP, std::max<int64_t>(k, 1), ndead);
     else op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, true, LP);  // (zero padding of Uh included)
-    // (the two-plane verdict, from the spectrum just found; on an exact run it only refreshes the ctx's hint)
-    if (!robust && two_plane_applies)
+    // (the two-plane verdict, from the spectrum just found)
+    if (!robust && !exact && two_plane_applies)
         op_tail_verdict(c.dev, lam, L, std::max<int64_t>(k, 1), tv_from_sq ? mu64 : nullptr, dp, d, ri.n_total, tvp, 4e-6, p2_thr, ndead);
     // rows of V^T: v_j = B^T u_j / sigma_j, sigma_j = sqrt(lam_j) (the host takes the same square roots of lam)
     op_components_out(c.dev, dt, Bt.f64(), LP, Uh.f64(), LP, lam, dt == F32 ? 1e-7 : 1e-12, d, L, k, comp_dev);
@@ -746,11 +751,13 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // U = Q Uh = Usrc (T Uh) (pca.rs:683) and svd_flip (pca.rs:684)
     // (only the k columns svd_flip signs and fit_transform returns: kp = k rounded up to whole 16-column tiles; the small
     // product T Uh is formed by the operand-packing kernel of the n x l product)
+    dev_set_tag(c.dev, TAG_STREAM);
     if (slot_flip)   // ... and svd_flip's column scan by its epilogue
         op_gemm_xp_prod_absmax(c.dev, dt, Usrc, n, LP, LP, nullptr, T.f64(), LP, LP, Uh.f64(), kp, LP, M2.f64(), LP, Ubuf, LP,
                                ri.row_offset, flip, flip + kp, flip + 2 * kp, /*store_product=*/y_out != nullptr);
     else
         op_gemm_xp_prod(c.dev, dt, Usrc, n, LP, LP, nullptr, T.f64(), LP, LP, Uh.f64(), kp, LP, M2.f64(), LP, Ubuf, LP);
+    dev_set_tag(c.dev, TAG_NONE);
     Uout = Ubuf;
     };  // pipeline
 
@@ -764,7 +771,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     static const bool host_tl = getenv("PETAL_HOST_TIMELINE") != nullptr;
     double t_q = 0, t_s = 0;
     static const bool never_p2 = getenv("PETAL_NO_P2") != nullptr;
-    bool robust = false, exact = !two_plane_applies || never_p2 || c.rpca_exact_hint;
+    bool robust = false, exact = !two_plane_applies || never_p2;
     for (int attempt = 0; attempt < 3; ++attempt) {
         pipeline(robust, exact);
         if (slot_flip) flip_signs_to_slot(c, dt, Uout, n, kp, LP, ri.row_offset, flip, true, !robust ? ndead : nullptr);
@@ -795,7 +802,6 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         std::memcpy(hdead, &keep[o_dead - o_tv], sizeof(hdead));
         double code = hdead[0] != 0 ? 2.0 : (hdead[1] != 0 ? 1.0 : 0.0);
         if (sharded(c)) code = flip_slot_keys(c, dt) ? keep[o_flip - o_tv + 4 * kp] : agree_max(c, code);  // the agreed verdict
-        if (two_plane_applies && code < 2.0) c.rpca_exact_hint = code == 1.0;   // (what the next fit on this ctx starts with)
         if (code >= 2.0) { robust = true; exact = true; c.stats.rpca_redo = 2; continue; }
         if (code == 1.0 && !exact) { exact = true; c.stats.rpca_redo = 1; continue; }
         break;

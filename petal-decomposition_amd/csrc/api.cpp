@@ -112,7 +112,7 @@ int petal_ctx_set_profiling(petal_ctx* ctx, int profiling) {
 
 int petal_ctx_set_gemm_mode(petal_ctx* ctx, int mode) {
     return guarded(ctx, [&] {
-        if (mode != PETAL_GEMM_SPLIT_BF16X3 && mode != PETAL_GEMM_FP32_MFMA) invalid_input("unknown GEMM mode");
+        if (mode != PETAL_GEMM_SPLIT_BF16X3 && mode != PETAL_GEMM_FP32_MFMA && mode != PETAL_GEMM_SPLIT_BF16X3_EXACT) invalid_input("unknown GEMM mode");
         dev_set_gemm_mode(ctx->dev, mode);
     });
 }

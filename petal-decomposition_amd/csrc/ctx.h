@@ -22,9 +22,6 @@ struct petal_ctx {
     void* rccl = nullptr;  // the built-in RCCL communicator (rccl.cpp), when petal_ctx_init_rccl installed it
     // the fixed pseudo-random start block of the subspace iteration (topk_eigh), kept on the device per shape: generating it on the
     // host and uploading it cost 20 us of idle device per exact Pca / FastICA fit
-    // RandomizedPca: the last fit's two-plane verdict (algo.cpp, rpca_fit) -- a ctx that has just seen a heavy-tailed spectrum
-    // starts its next fit with three-plane operands instead of finding out again at the end
-    bool rpca_exact_hint = false;
     double* topk_seed = nullptr;
     int64_t topk_seed_d = 0, topk_seed_dp = 0, topk_seed_p = 0;
 };

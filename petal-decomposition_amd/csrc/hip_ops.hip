@@ -73,7 +73,7 @@ struct Dev {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool forked = false, on_side = false;
     std::vector<void*> deferred_free;   // blocks released while forked: back to the pool at the join
-    int gemm_mode = [] { const char* e = getenv("PETAL_GEMM"); return (e && std::string(e) == "fp32") ? 1 : 0; }();
+    int gemm_mode = [] { const char* e = getenv("PETAL_GEMM"); return (e && std::string(e) == "fp32") ? 1 : (e && std::string(e) == "bf16x3-exact") ? 2 : 0; }();
     // FastICA: W's bf16 planes for the split-product step kernel; the tail kernel refreshes them with the W it writes, so only
     // the first iteration of a fit runs the separate pack kernel
     void* ica_wpk3 = nullptr;
@@ -5598,7 +5598,11 @@ void op_colmean(Dev* d, int dt, const void* X, int64_t n, int64_t dd, int64_t ld
     if (n == 0) { dev_memset(d, mu64, 0, sizeof(double) * w); dev_memset(d, muT, 0, dtype_size(dt) * dd); return; }
     const int64_t rows = scan_rows_per_block(n, dd), nparts = cdiv(n, rows);
     double* part = (double*)dev_alloc(d, sizeof(double) * nparts * w);
-    launch_colsum_parts(d, dt, X, n, dd, ldx, rows, nparts, part, with_sq);
+    {
+        TagScope ts(d);   // (the pass over X; bracketed when the caller tagged it)
+        launch_colsum_parts(d, dt, X, n, dd, ldx, rows, nparts, part, with_sq);
+        ts.stop();
+    }
     DISPATCH_T(dt, hipLaunchKernelGGL(k_colmean_final<T>, dim3(cdiv(w, 8)), dim3(256), 0, d->stream, part, nparts, w, dd, 1.0 / n_total, mu64, (T*)muT));
     launch_check();
     dev_free(d, part);
@@ -5611,7 +5615,7 @@ void op_sigma_inv(Dev* d, const double* lam, double* sig, double* inv, int64_t c
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // split-product (bf16x3, see k_xp3) kernels unless the ctx asks for the fp32-MFMA ones (petal_ctx_set_gemm_mode /
 // PETAL_GEMM=fp32)
-static bool gemm_split_product(const Dev* d) { return d->gemm_mode == 0; }
+static bool gemm_split_product(const Dev* d) { return d->gemm_mode != 1; }   // (mode 2: the same kernels, three-plane operands only: algo.cpp)
 // kernels that ask for more than 64 KB of dynamic LDS: the attribute is set once per device (ctx)
 static void set_max_lds(Dev* d, const void* fn) {
     if (d->max_lds_set.count(fn)) return;
@@ -6653,7 +6657,7 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
 static bool pow3_ok(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N, const void* Z, int64_t ldz) {
     static const bool off = getenv("PETAL_NO_POW3") != nullptr;
     static const int64_t min_rows = [] { const char* e = getenv("PETAL_POW3_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();
-    return !off && dt == F32 && gemm_split_product(d) && K == 512 && N % 16 == 0 && N >= 16 && N <= 80 && n >= min_rows &&
+    return !off && dt == F32 && d->gemm_mode == 0 && K == 512 && N % 16 == 0 && N >= 16 && N <= 80 && n >= min_rows &&
            n < (int64_t(1) << 40) && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && (!Z || (ldz >= N && aligned16(Z)));
 }
 bool op_power_pass_applies(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N) {

@@ -19,10 +19,12 @@ inline size_t dtype_size(int dt) { return dt == F64 ? 8 : 4; }
 struct Dev;  // opaque: stream, allocator cache, event pool (hip) / nothing much (cpu sim)
 
 // hot-kernel tags: launches issued while a tag is set are bracketed with events when profiling is on
-enum Tag : int { TAG_NONE = 0, TAG_XP = 1, TAG_ATB = 2, TAG_ICA = 3, TAG_COMM = 4, TAG_POW = 5, TAG_COUNT = 6 };
+// (TAG_STREAM: the other kernels of a fit whose time falls with the rows a rank holds -- the means pass, U = Z (T Uh) -- so that
+// fit time minus every tagged kernel is the REPLICATED small-matrix chain, the part of a sharded fit that does not shrink with N)
+enum Tag : int { TAG_NONE = 0, TAG_XP = 1, TAG_ATB = 2, TAG_ICA = 3, TAG_COMM = 4, TAG_POW = 5, TAG_STREAM = 6, TAG_COUNT = 7 };
 struct KernelTiming {
-    double ms[TAG_COUNT] = {0, 0, 0, 0, 0, 0};
-    int64_t launches[TAG_COUNT] = {0, 0, 0, 0, 0, 0};
+    double ms[TAG_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    int64_t launches[TAG_COUNT] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 // ---- lifetime / memory ---------------------------------------------------------------------

@@ -49,15 +49,27 @@ def test_roofline_bound_is_computed_from_the_shape():
         b = bench.pass_bound(flops, nbytes, mode)
         assert (b["bound"], b["pipe"]) == (bound, pipe), (n, d, l, mode, b)
         assert b["floor_s"] == max(b["times_s"].values())
-    # the entry itself: cfg4's K1 at 0.42 ms is 0.40 of the bf16 pipe, not 0.35 "of HBM"
-    flops, nbytes = 2.0 * 250000 * 1024 * 138, 4.0 * (250000 * 1024 + 250000 * 138 + 1024 * 138)
-    e = bench.roofline_entry("K1 (Z = Xc.P)", {"K1 (Z = Xc.P)": 0.42, "K2 (Y = Xc^T.Z)": 0.41}, flops, nbytes, "bf16x3", 0.0, 250000, 1024, 138)
+    # the entry itself: cfg4's K1 at 0.42 ms is 0.40 of the bf16 pipe with SIX piece products -- and 0.34 with the FIVE it issues
+    # behind a two-plane operand (round-4 verdict: the line charged six to both kernels and overstated K1)
+    kinds6 = bench.kind_table(250000, 1024, 138, "bf16x3", two_plane=False)
+    e = bench.roofline_entry("K1 (Z = Xc.P)", {"K1 (Z = Xc.P)": 0.42, "K2 (Y = Xc^T.Z)": 0.41}, kinds6, "bf16x3", 0.0, 250000, 1024, 138)
     assert e["bound"] == "mfma" and e["pipe"] == "mfma-bf16" and abs(e["frac"] - 0.404) < 0.002, e
     assert abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-3
-    e = bench.roofline_entry("K2 (Y = Xc^T.Z)", {"K1 (Z = Xc.P)": 0.055, "K2 (Y = Xc^T.Z)": 0.0565}, 7577600000.0, 234551552.0, "bf16x3", 0.0, 100000, 512, 74)
+    kinds5 = bench.kind_table(250000, 1024, 138, "bf16x3", two_plane=True)
+    e = bench.roofline_entry("K1 (Z = Xc.P)", {"K1 (Z = Xc.P)": 0.351, "K2 (Y = Xc^T.Z)": 0.40}, kinds5, "bf16x3", 0.0, 250000, 1024, 138)
+    assert e["piece_products"] == 5.0 and e["pipe"] == "hbm" and abs(e["frac"] - 0.413) < 0.003, e   # five products: the X stream binds (145 us)
+    assert e["other_kernel"]["K2 (Y = Xc^T.Z)"]["piece_products"] == 6.0
+    kinds = bench.kind_table(100000, 512, 74, "bf16x3", two_plane=True)
+    e = bench.roofline_entry("K2 (Y = Xc^T.Z)", {"K1 (Z = Xc.P)": 0.055, "K2 (Y = Xc^T.Z)": 0.0565, "K3 (Y' = Xc^T.(Xc.P), fused)": 0.0}, kinds, "bf16x3", 0.0, 100000, 512, 74)
     assert e["bound"] == "hbm" and abs(e["frac"] - 0.519) < 0.002 and "fp32_equivalent_frac_of_fp32_mfma_peak" not in e
+    # the fused pass: one read of X, 5 + 6 piece products -- at l = 74 the matrix pipe binds it (33 us against 26 us of bytes)
+    e = bench.roofline_entry("K3 (Y' = Xc^T.(Xc.P), fused)", {"K1 (Z = Xc.P)": 0.0, "K2 (Y = Xc^T.Z)": 0.0, "K3 (Y' = Xc^T.(Xc.P), fused)": 0.1}, kinds, "bf16x3", 0.0, 100000, 512, 74)
+    assert e["bound"] == "mfma" and e["piece_products"] == 5.5 and abs(e["frac"] - 0.333) < 0.003, e
+    assert e["bytes_per_launch"] == 4.0 * (100000 * 512 + 2 * 512 * 74)
     f = bench.fit_roofline(100000, 512, 74, 5, 4, "bf16x3", 1.39)
-    assert f["passes"] == 12 and 0.2 < f["frac"] < 0.35, f
+    assert f["passes"] == 6 and f["pass_pipe"] == "mfma-bf16" and 0.1 < f["frac"] < 0.35, f
+    f = bench.fit_roofline(250000, 1024, 138, 7, 4, "bf16x3", 7.5)
+    assert f["passes"] == 16, f
 
 
 def test_default_workload_per_gpu_count():
