@@ -286,6 +286,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # every rank's own view of the collective (gathered: a SCALE line can then show N distinct devices inside ONE communicator)
+    me = {"rank": rank, **ctx.collective_info()}
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        me["device_uuid"] = str(getattr(props, "uuid", ""))
+    except Exception:
+        me["device_uuid"] = None
+    ranks_info = [me]
+    if dist is not None:
+        try:
+            ranks_info = [None] * world
+            dist.all_gather_object(ranks_info, me)
+        except Exception as e:  # informational
+            ranks_info = [me, {"error": repr(e)}]
+
     out = None
     if rank == 0:
         # dominant kernel = the power-iteration GEMM kind with the larger summed time
@@ -325,7 +340,7 @@ def main():
             "rpca_redo": redo,   # 0: every timed fit stood on its optimistic (two-plane, fused) run
             # what went through the collective per fit (sharded runs; zeros on one GPU).  The stream time is sampled: one
             # bracketed all-reduce per fit, the index rotating from fit to fit -> average call time x calls per fit
-            "collective": collective_entry(st, acc, args.steps),
+            "collective": {**collective_entry(st, acc, args.steps, ctx, torch, dev), "ranks": ranks_info},
         }
 
         if per["K3 (Y' = Xc^T.(Xc.P), fused)"] > 0:
@@ -393,10 +408,20 @@ def ramp(fn, seconds=0.25):
         fn()
 
 
-def collective_entry(st, acc, steps):
+def collective_entry(st, acc, steps, ctx=None, torch=None, dev=None):
     calls, timed = int(st["allreduce_calls"]), int(acc["allreduce_timed"])
     avg = acc["allreduce_ms"] / timed if timed else 0.0
-    return {"allreduce_calls_per_fit": calls, "allreduce_bytes_per_fit": float(st["allreduce_bytes"]),
+    who = {}
+    if ctx is not None:
+        # what the communicator ITSELF reports (ncclCommCount / ncclCommCuDevice / ncclCommUserRank), not the launcher's environment:
+        # a scaling line can show that RCCL spanned N ranks
+        who = {"communicator": ctx.collective_info()}
+        try:
+            props = torch.cuda.get_device_properties(dev)
+            who["device"] = {"name": props.name, "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
+        except Exception:
+            pass
+    return {**who, "allreduce_calls_per_fit": calls, "allreduce_bytes_per_fit": float(st["allreduce_bytes"]),
             "allreduce_avg_call_ms": round(avg, 5), "allreduce_ms_per_fit": round(avg * calls, 4),
             "timed_calls": timed,
             "note": "stream time between events around the all-reduce calls (includes waiting for the slowest rank)"}

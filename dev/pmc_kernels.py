@@ -14,5 +14,6 @@ mu = np.random.default_rng(8).standard_normal(d).astype(np.float32)
 for _ in range(3):
     petal.gemm_xp(x, p, mu, ctx=ctx)
     petal.gemm_atb(x, z, mu, ctx=ctx)
+    petal.power_pass(x, p, mu, ctx=ctx)      # the fused pass (k_pow3) in the split-product mode, K1 + K2 otherwise
 torch.cuda.synchronize()
 print("done", n)

@@ -4,7 +4,8 @@ usage: python dev/pmc_traffic.py"""
 import csv, glob, json, os, collections, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d, l = 512, 74
-KIND = {"k_xp3": "K1", "k_xp_pers": "K1", "k_xp_mfma": "K1", "k_atb3": "K2", "k_atb_mfma": "K2"}
+KIND = {"k_xp3": "K1", "k_xp_pers": "K1", "k_xp_mfma": "K1", "k_atb3": "K2", "k_atb_mfma": "K2", "k_pow3": "K3"}
+ALGO = {"K1": lambda n: 4 * (n * d + n * l + d * l), "K2": lambda n: 4 * (n * d + n * l + d * l), "K3": lambda n: 4 * (n * d + 2 * d * l)}
 out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (with --kernel-trace only) on "
                "dev/pmc_kernels.py (dev/pmc_pass.sh), per GEMM mode; counter values are KB per launch; gfx950 correction "
                "(MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of wide coalesced streaming reads -- calibrated on "
@@ -29,7 +30,7 @@ for mode in ("bf16x3", "fp32"):
             if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 ent[kind] = {"FETCH_SIZE_KB": round(v["FETCH_SIZE"], 2), "WRITE_SIZE_KB": round(v["WRITE_SIZE"], 2),
                              "hbm_bytes_corrected": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
-                             "algorithmic_bytes": 4 * (n * d + n * l + d * l)}
+                             "algorithmic_bytes": ALGO[kind](n)}
         out.setdefault(f"{n}x{d} l={l}", {})[mode] = ent
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 try:

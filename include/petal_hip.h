@@ -104,6 +104,11 @@ int         petal_ctx_set_collective(petal_ctx* ctx, petal_allreduce_fn fn, void
  * with dlopen at the first call (the copy already loaded in the process wins), error 3 when it cannot be found. */
 int         petal_rccl_unique_id(void* out128);
 int         petal_ctx_init_rccl(petal_ctx* ctx, const void* unique_id128, int rank, int world_size);
+/* What the collective of this ctx is: *kind = 0 none, 1 a caller's hook (petal_ctx_set_collective), 2 the built-in RCCL communicator;
+ * for the built-in one, what RCCL ITSELF reports -- ncclCommCount / ncclCommCuDevice / ncclCommUserRank (-1 where unavailable) -- so a
+ * scaling record can show that the communicator spanned N ranks (rank / world_size as the ctx was told them come back too). */
+int         petal_ctx_collective_info(const petal_ctx* ctx, int* kind, int* rank, int* world_size, int* comm_count, int* comm_device,
+                                      int* comm_rank);
 /* profiling: 0 off; 1 = bracket ONE launch per fit with hipEvents (the kernel kind -- K1, K2, the FastICA step, the all-reduce --
  * and the launch index within the kind rotate from fit to fit, so K fits sample every launch position of every kind; an event
  * pair is a ~5 us bubble in the stream); 2 = every launch.

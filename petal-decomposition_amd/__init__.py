@@ -90,6 +90,7 @@ ABI = [
     ("petal_rccl_unique_id", C.c_int, [_P]),
     ("petal_ctx_init_rccl", C.c_int, [_P, _P, C.c_int, C.c_int]),
     ("petal_get_stats", C.c_int, [_P, C.POINTER(petal_stats)]),
+    ("petal_ctx_collective_info", C.c_int, [_P] + [C.POINTER(C.c_int)] * 6),
     ("petal_power_pass", C.c_int, [_P, _M, _P, _P, C.c_int64, C.POINTER(C.c_double), _M, C.POINTER(C.c_int)]),
     ("petal_pca_fit", C.c_int, [_P, _M, C.c_int64, C.c_int, _P, _P, _P, _P, _M]),
     ("petal_rpca_fit", C.c_int, [_P, _M, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _M]),
@@ -252,6 +253,14 @@ class Context:
         if isinstance(mode, str):
             mode = {"bf16x3": GEMM_SPLIT_BF16X3, "fp32": GEMM_FP32_MFMA, "bf16x3-exact": GEMM_SPLIT_BF16X3_EXACT}[mode]
         self.check(self.lib.petal_ctx_set_gemm_mode(self._h, int(mode)))
+
+    def collective_info(self) -> dict:
+        """kind ("none" / "hook" / "rccl"), rank / world_size as the ctx was told them, and -- for the built-in communicator -- what
+        RCCL itself reports: ncclCommCount, ncclCommCuDevice, ncclCommUserRank (-1 where unavailable)."""
+        v = [C.c_int(-1) for _ in range(6)]
+        self.check(self.lib.petal_ctx_collective_info(self._h, *[C.byref(x) for x in v]))
+        return {"kind": {0: "none", 1: "hook", 2: "rccl"}.get(v[0].value, "?"), "rank": v[1].value, "world_size": v[2].value,
+                "ncclCommCount": v[3].value, "ncclCommCuDevice": v[4].value, "ncclCommUserRank": v[5].value}
 
     def stats(self) -> dict:
         s = petal_stats()

@@ -110,6 +110,20 @@ int petal_ctx_set_profiling(petal_ctx* ctx, int profiling) {
     });
 }
 
+int petal_ctx_collective_info(const petal_ctx* ctx, int* kind, int* rank, int* world_size, int* comm_count, int* comm_device,
+                              int* comm_rank) {
+    if (!ctx) return PETAL_INVALID_INPUT;
+    int cnt = -1, dev = -1, rk = -1;
+    petal::rccl_info(*ctx, &cnt, &dev, &rk);
+    if (kind) *kind = ctx->rccl ? 2 : (ctx->allreduce ? 1 : 0);
+    if (rank) *rank = ctx->rank;
+    if (world_size) *world_size = ctx->world;
+    if (comm_count) *comm_count = cnt;
+    if (comm_device) *comm_device = dev;
+    if (comm_rank) *comm_rank = rk;
+    return PETAL_OK;
+}
+
 int petal_ctx_set_gemm_mode(petal_ctx* ctx, int mode) {
     return guarded(ctx, [&] {
         if (mode != PETAL_GEMM_SPLIT_BF16X3 && mode != PETAL_GEMM_FP32_MFMA && mode != PETAL_GEMM_SPLIT_BF16X3_EXACT) invalid_input("unknown GEMM mode");

@@ -48,6 +48,7 @@ inline bool sharded(const petal_ctx& c) {
 void rccl_unique_id(void* out128);
 void rccl_init(petal_ctx& c, const void* unique_id128, int rank, int world);
 void rccl_release(petal_ctx& c);
+void rccl_info(const petal_ctx& c, int* count, int* device, int* rank);
 
 // RAII device buffer from the ctx's caching allocator
 struct DBuf {

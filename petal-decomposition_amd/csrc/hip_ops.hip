@@ -6699,9 +6699,12 @@ static void launch_pow3(Dev* d, const float* X, int64_t n, int64_t ldx, const fl
     launch_check();
     dev_free(d, part);
 }
+// (the knobs that keep an operand at three planes also keep its product off the fused kernel, whose P is a two-plane one by construction)
+static bool pow3_knob_off(const char* name) { return getenv("PETAL_NO_P2") != nullptr || getenv(name) != nullptr; }
 bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
                    void* Z, int64_t ldz, double* Y, int64_t ldy) {
-    if (!pow3_ok(d, dt, X, n, K, ldx, mu, N, Z, ldz)) return false;
+    static const bool knob = pow3_knob_off("PETAL_NO_P2_OMEGA");
+    if (knob || !pow3_ok(d, dt, X, n, K, ldx, mu, N, Z, ldz)) return false;
     const int64_t total = (K / 32) * (N / 16) * 64;
     bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
     hipLaunchKernelGGL(k_pack_p3, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk3, (int)(N / 16), total);
@@ -6713,7 +6716,7 @@ bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t 
 bool op_rebase_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                           int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
                           double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy) {
-    static const bool no_rt = getenv("PETAL_NO_TRSM") != nullptr;
+    static const bool no_rt = getenv("PETAL_NO_TRSM") != nullptr || pow3_knob_off("PETAL_NO_P2_ITERATE");
     if (!pow3_ok(d, dt, X, n, K, ldx, mu, M, Z, ldz) || no_rt || L == 0 || L > CHOL2_MAXL || M > TRSM_MAXM || M < L || P_out == nullptr) return false;
     set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
     hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead,

@@ -28,6 +28,9 @@ struct RcclApi {
     int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, void*) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommCount)(NcclComm, int*) = nullptr;        // optional: what the communicator itself says about its size, device, rank
+    int (*CommCuDevice)(NcclComm, int*) = nullptr;
+    int (*CommUserRank)(NcclComm, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string why, path;
 };
@@ -58,6 +61,9 @@ RcclApi& api() {
         a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.handle, "ncclAllReduce"));
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
+        a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(a.handle, "ncclCommCount"));
+        a.CommCuDevice = reinterpret_cast<decltype(a.CommCuDevice)>(dlsym(a.handle, "ncclCommCuDevice"));
+        a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(a.handle, "ncclCommUserRank"));
         if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy) a.why = "librccl.so lacks the nccl* entry points";
     });
     return a;
@@ -87,6 +93,19 @@ void rccl_unique_id(void* out128) {
     const int rc = a.GetUniqueId(&id);
     if (rc != 0) device_error(nccl_error(rc));
     std::memcpy(out128, id.internal, sizeof(id.internal));
+}
+
+// what the built-in communicator reports about itself (ncclCommCount / ncclCommCuDevice / ncclCommUserRank): -1 where there is
+// no built-in communicator or the library lacks the query.  A scaling record can then show that RCCL really spanned N ranks.
+void rccl_info(const petal_ctx& c, int* count, int* device, int* rank) {
+    *count = *device = *rank = -1;
+    if (!c.rccl) return;
+    const RcclComm* rc = static_cast<const RcclComm*>(c.rccl);
+    RcclApi& a = api();
+    int v = -1;
+    if (a.CommCount && a.CommCount(rc->comm, &v) == 0) *count = v;
+    if (a.CommCuDevice && a.CommCuDevice(rc->comm, &v) == 0) *device = v;
+    if (a.CommUserRank && a.CommUserRank(rc->comm, &v) == 0) *rank = v;
 }
 
 void rccl_release(petal_ctx& c) {

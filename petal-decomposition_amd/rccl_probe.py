@@ -28,6 +28,11 @@ def main() -> int:
     if world == 1:
         os.environ["PETAL_FORCE_COLLECTIVE"] = "1"
     ctx.use_rccl()
+    info = ctx.collective_info()
+    # the communicator itself must say it spans the job (a library without the query reports -1: not a failure)
+    if info["kind"] != "rccl" or info["ncclCommCount"] not in (-1, world) or info["ncclCommUserRank"] not in (-1, rank):
+        print(f"rccl_probe: rank {rank}: communicator reports {info}, expected {world} ranks", file=sys.stderr)
+        return 1
     n, d, k = 256, 32, 4
     rng = np.random.default_rng(100 + rank)
     x = (rng.standard_normal((n, k)) @ np.random.default_rng(5).standard_normal((k, d))

@@ -243,7 +243,7 @@ def decided_signs(u, k, margin=1e-3):
 
 
 def rpca_parity(ctx, n, d, k, n_iter, seed, dtype=np.float32, tol=1e-5, device=False, centering=True, tol_sigma=None, x=None,
-                n_oversample=10, graded=False):
+                n_oversample=10, graded=False, host_layout=None):
     """same X, same Omega, same n_iter: fp64 LAPACK oracle vs the library (BASELINE.md parity metric).  Signs are compared too
     (svd_flip, pca.rs:815-850) wherever the element that decides them is not a near-tie in the oracle's U."""
     if x is None:
@@ -256,6 +256,12 @@ def rpca_parity(ctx, n, d, k, n_iter, seed, dtype=np.float32, tol=1e-5, device=F
     uo = o._inner_fit(x.astype(np.float64), omega=om)
     yo = po.transform_with_u(uo, o.singular, k)
     xin = x
+    if host_layout == "fortran":        # a column-major HOST array (row stride 1): legal ndarray input in the crate (pca.rs:509-531)
+        xin = np.asfortranarray(x)
+    elif host_layout == "strided":      # every second row and column of a larger host array
+        big = np.zeros((2 * n, 2 * d), dtype=dtype)
+        big[::2, ::2] = x
+        xin = big[::2, ::2]
     if device:
         import torch
         xin = torch.from_numpy(x).cuda()

@@ -162,5 +162,7 @@ def test_single_gpu_record_has_the_northstar_fit():
     nf = rec["northstar_fit"]
     for key in ("n_iter_5", "n_iter_7"):
         assert nf[key]["ms_per_fit"] > 0 and 0 < nf[key]["fit_roofline"]["frac"] <= 1.0
-    assert nf["n_iter_7"]["fit_roofline"]["passes"] == 16
+    assert nf["n_iter_7"]["fit_roofline"]["passes"] == 8 and nf["n_iter_7"]["fit_roofline"]["pass_kind"].startswith("fused")
+    assert rec["fused_pass"]["launches_per_fit"] == 6 and rec["roofline"]["kernel"].startswith("K3")
+    assert rec["serial_chain"]["serial_chain_ms"] > 0
     assert rec["host_in"]["row_pitch_bytes"] == 2048 + 128

@@ -108,6 +108,24 @@ def test_two_plane_verdict_and_exact_redo():
         c.close()
 
 
+@pytest.mark.parametrize("layout", ["fortran", "strided"])
+def test_host_inputs_that_are_not_row_major(ctx, layout):
+    """A Fortran-order / strided HOST ndarray (legal in the crate, src/pca.rs:509-531): its span is uploaded as it lies and gathered
+    into the row-major layout on the device (round 4 gathered it element by element on one host thread: 0.3 s at configs[1])."""
+    import time
+    pc.rpca_parity(ctx, 20000, 512, 64, 5, seed=9, host_layout=layout)
+    pc.rpca_parity(ctx, 3001, 100, 10, 4, seed=10, dtype=np.float64, tol=1e-9, host_layout=layout)
+    if layout == "fortran":
+        import petal_decomposition_amd as petal
+        x = np.asfortranarray(pc.po.synth_pca(100000, 512, 64, seed=2, dtype=np.float32))
+        om = np.random.default_rng(3).standard_normal((512, 74)).astype(np.float32)
+        m = petal.RandomizedPca(64, ctx=ctx, n_iter=5)
+        m.fit(x, omega=om)
+        t0 = time.perf_counter()
+        m.fit(x, omega=om)
+        assert time.perf_counter() - t0 < 0.1      # (upload + device gather + fit; the host gather alone took 0.3 s)
+
+
 def test_components_beyond_a_ring_slot(ctx):
     """k d esz above the 8 MiB slot of the pinned result ring (rpca_fit's single result view threw there, e.g.
     k = 512 at d = 2048 fp64 or d = 4096 fp32): the components then leave by a copy of their own."""

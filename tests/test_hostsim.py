@@ -52,6 +52,12 @@ def test_components_beyond_a_ring_slot(ctx):
     pc.rpca_parity(ctx, 700, 2048, 512, 1, seed=5, dtype=np.float64, tol=1e-7)
 
 
+@pytest.mark.parametrize("layout", ["fortran", "strided"])
+def test_host_inputs_that_are_not_row_major(ctx, layout):
+    pc.rpca_parity(ctx, 900, 40, 6, 4, seed=9, host_layout=layout)
+    pc.rpca_parity(ctx, 500, 24, 4, 4, seed=10, dtype=np.float64, tol=1e-9, host_layout=layout)
+
+
 def test_power_pass_entry(ctx):
     """petal_power_pass through the host simulation: the fused form (split-product mode) and the K1 + K2 fall-back"""
     assert pc.power_pass_exact(ctx, 300, 48, 20, seed=1) is False
