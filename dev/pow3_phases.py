@@ -23,3 +23,14 @@ for n in (100000, 1000000):
         ws = max(cyc[8], 1)     # wave-stages
         per = [cyc[i] / ws for i in range(8)]
         print(f"n={n} N={N}: pass {st['pow_ms']*1e3:.1f} us; cycles per stage per wave:", {k: round(v) for k, v in zip(names, per)}, "sum", round(sum(per)), flush=True)
+
+# absolute timeline of ONE stage of one workgroup (its 8 waves): when each wave passed each mark, relative to the earliest
+tr = (C.c_longlong * 128)()
+lib.petal_debug_trace(tr)
+base = min(tr[w * 16 + 7] for w in range(8)) if any(tr) else 0
+# the marks are stamped in the order 0..7 within a stage; mark 7 of the PREVIOUS stage is not recorded, so show marks relative to the earliest mark 0
+t0 = min(tr[w * 16 + 0] for w in range(8))
+print("one stage of workgroup 7 (cycles after the earliest mark 0):")
+print("wave " + " ".join(f"{nm[:10]:>11s}" for nm in names))
+for w in range(8):
+    print(f"{w:4d} " + " ".join(f"{tr[w * 16 + i] - t0:11d}" for i in range(8)))

@@ -45,9 +45,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifdef PETAL_DEBUG_COUNTERS
 __device__ int g_dbg[4];
 __device__ long long g_cyc[32];
+__device__ long long g_trace[8 * 16];   // k_pow3: absolute s_memtime of one workgroup's waves at the marks of one stage
 #define DBG_T(i) do { if (threadIdx.x == 0) { long long _t = clock64(); g_cyc[i] += _t - _t0; _t0 = _t; } } while (0)
 }  // namespace petal
 // development builds only (-DPETAL_DEBUG_COUNTERS): read and clear the in-kernel phase counters
+extern "C" void petal_debug_trace(long long* out128) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out128, HIP_SYMBOL(petal::g_trace), sizeof(long long) * 128);
+}
 extern "C" void petal_debug_counters(long long* cyc16, int* dbg4) {  // (32 counters)
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(cyc16, HIP_SYMBOL(petal::g_cyc), sizeof(long long) * 32);
@@ -2022,7 +2027,8 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
 #ifdef PETAL_DEBUG_COUNTERS
     long long php[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tqp = __builtin_amdgcn_s_memtime();
-#define POW3_STAMP(i) do { const long long _t = __builtin_amdgcn_s_memtime(); php[i] += _t - tqp; tqp = _t; } while (0)
+#define POW3_STAMP(i) do { const long long _t = __builtin_amdgcn_s_memtime(); php[i] += _t - tqp; tqp = _t; \
+        if (blockIdx.x == 7 && s == s0 + 5 && (threadIdx.x & 63) == 0) g_trace[wave * 16 + (i)] = _t; } while (0)
 #else
 #define POW3_STAMP(i) do {} while (0)
 #endif
