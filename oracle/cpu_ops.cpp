@@ -471,6 +471,35 @@ bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t 
     op_gemm_atb(d, dt, X, ldx, K, mu, Z, ldz, N, nullptr, n, Y, ldy, false);
     return true;
 }
+bool op_power_pass_means(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t dcols, int64_t ldx, double n_total, const double* P,
+                         int64_t N, int64_t ldp, int64_t L, double* Y, int64_t ldy, double* mu64, void* muT, double* ssq_scratch, double* tv) {
+    static const bool off = std::getenv("PETAL_NO_MEANS_FOLD") != nullptr;
+    if (off || L >= N || !op_power_pass_applies(d, dt, X, n, K, ldx, muT, N)) return false;
+    // as on the device: a provisional centre from a strided row sample, the exact sums about it from the pass, then the move
+    const int64_t ns = std::min<int64_t>(n, 4096), stride = n / ns;
+    op_colmean(d, dt, X, ns, K, ldx * stride, double(ns), mu64, muT, false);
+    std::vector<double> sums(K, 0.0);
+    double ssq = 0;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t f = 0; f < K; ++f) { const double v = centred(X, dt, i * ldx + f, muT, f); sums[f] += v; ssq += v * v; }
+    if (!op_power_pass(d, dt, X, n, K, ldx, muT, P, N, ldp, nullptr, 0, Y, ldy)) return false;
+    std::vector<double> t(N, 0.0);
+    double q = 0;
+    for (int64_t f = 0; f < K; ++f) {
+        const double del = f < dcols ? sums[f] / n_total : 0.0;
+        sums[f] = del;
+        q += del * del;
+        for (int64_t j = 0; j < L; ++j) t[j] += del * two_plane(P[f * ldp + j]);
+    }
+    for (int64_t f = 0; f < K; ++f) {
+        for (int64_t j = 0; j < N; ++j) Y[f * ldy + j] = j == N - 1 ? 0.0 : Y[f * ldy + j] - n_total * sums[f] * t[j];
+        mu64[f] += sums[f];
+        st(muT, dt, f, mu64[f]);
+    }
+    *ssq_scratch = ssq;
+    *tv = std::max(ssq - n_total * q, 0.0);
+    return true;
+}
 bool op_rebase_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                           int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
                           double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy) {

@@ -560,10 +560,26 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     DBuf P;
     // The column-means pass is queued FIRST: the device starts on it at once, and the host's copy of Omega into the pinned ring
     // runs beside it.
-    if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
-    dev_set_tag(c.dev, TAG_STREAM);
-    column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq, sharded(c) && centering ? pro.sums : nullptr);
-    dev_set_tag(c.dev, TAG_NONE);
+    // Single-rank fp32 fits whose first product is a FUSED pass gather the means inside it (op_power_pass_means: X is read once for
+    // the means, the sums of squares and the first power iteration together -- round 4 spent a pass of its own on the first two,
+    // the reference three: pca.rs:520-533): the means pass is then not queued here but decided in the pipeline.
+    // (From 200000 rows on: at configs[1]'s 100000 x 512 the matrix sits in the Infinity Cache, the means pass costs 37 us and what
+    // replaces it -- the sample's means, the all-ones column and the squares in the first pass, the move to the true centre -- costs
+    // the same; at 1e6 rows the pass is 0.33 ms of HBM time and the fold takes 5 % off the fit.)
+    const char* fold_env = getenv("PETAL_MEANS_FOLD_ROWS");   // (read per fit: the tests lower it)
+    const int64_t fold_rows = fold_env ? (int64_t)atoll(fold_env) : (int64_t)200000;
+    const bool fold_means = !sharded(c) && tv_from_sq && dev_gemm_mode(c.dev) == 0 && n_iter >= 3 && L < LP && n >= fold_rows &&
+                            op_power_pass_applies(c.dev, dt, X.p, n, dp, X.ld, X.p, LP) && getenv("PETAL_NO_P2") == nullptr;
+    bool means_done = false, tv_direct = false;
+    auto means_pass = [&] {
+        if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
+        dev_set_tag(c.dev, TAG_STREAM);
+        column_means_into(c, X, ri.n_total, centering, mu64, muT, tv_from_sq, sharded(c) && centering ? pro.sums : nullptr);
+        dev_set_tag(c.dev, TAG_NONE);
+        means_done = true;
+    };
+    if (!fold_means) means_pass();
+    else muT = DBuf(c.dev, esz * size_t(dp));   // (mu64: means and, in its second half's first slot, the variance -- both written by the pass)
     if (sharded(c)) {
         P = DBuf(c.dev, sizeof(double) * dp * LP);
         op_pad_to_f64(c.dev, F64, P.f64(), dp, LP, pro.draw, d, L, l_req, tvp, 2 + LP);
@@ -614,7 +630,17 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // belongs to the optimistic run): every product pair of the loop below, the last one also storing Z.
     const bool use_pow = planes == 2 && op_power_pass_applies(c.dev, dt, X.p, n, dp, X.ld, muT.p, LP);
     bool have_yp = false;   // Yp already holds Xc^T Z for the current basis
-    if (use_pow && n_iter >= 3 && tv_from_sq) {
+    if (!means_done) {      // (fold_means: the first run of the pipeline)
+        if (use_pow) {
+            dev_set_tag(c.dev, TAG_POW);
+            // mu64 = [means | tv, scratch, 0 ...]: the total variance lands where the sums of squares would have
+            have_yp = op_power_pass_means(c.dev, dt, X.p, n, dp, d, X.ld, ri.n_total, P.f64(), LP, LP, L, Yp, LP, mu64, muT.p, mu64 + dp + 1, mu64 + dp);
+            dev_set_tag(c.dev, TAG_NONE);
+        }
+        if (have_yp) { means_done = true; tv_direct = true; }
+        else means_pass();
+    }
+    if (!have_yp && use_pow && n_iter >= 3 && tv_from_sq) {
         dev_set_tag(c.dev, TAG_POW);
         have_yp = op_power_pass(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, LP, Yp, LP);   // pca.rs:707 + 711
         dev_set_tag(c.dev, TAG_NONE);
@@ -756,7 +782,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     else op_eigh(c.dev, S.f64(), L, LP, Uh.f64(), LP, lam, dt == F32 ? 1e-8 : 1e-15, true, LP);  // (zero padding of Uh included)
     // (the two-plane verdict, from the spectrum just found)
     if (!robust && !exact && two_plane_applies)
-        op_tail_verdict(c.dev, lam, L, std::max<int64_t>(k, 1), tv_from_sq ? mu64 : nullptr, dp, d, ri.n_total, tvp, 4e-6, p2_thr, ndead);
+        op_tail_verdict(c.dev, lam, L, std::max<int64_t>(k, 1), (tv_from_sq && !tv_direct) ? mu64 : nullptr, dp, d, ri.n_total,
+                        tv_direct ? mu64 + dp : tvp, 4e-6, p2_thr, ndead);
     // rows of V^T: v_j = B^T u_j / sigma_j, sigma_j = sqrt(lam_j) (the host takes the same square roots of lam)
     op_components_out(c.dev, dt, Bt.f64(), LP, Uh.f64(), LP, lam, dt == F32 ? 1e-7 : 1e-12, d, L, k, comp_dev);
 
@@ -829,7 +856,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     for (int64_t j = 0; j < k; ++j) hs[j] = std::sqrt(std::max(hlam[j], 0.0));
     const double* hmu = &keep[o_mu - o_tv];
     double htv = keep[0];
-    if (tv_from_sq) {  // sum (x - mu)^2 = sum x^2 - n mu^2 per column, in fp64
+    if (tv_direct) htv = hmu[dp];   // (the means were gathered inside the first fused pass: the variance came with them)
+    else if (tv_from_sq) {  // sum (x - mu)^2 = sum x^2 - n mu^2 per column, in fp64
         htv = 0;
         for (int64_t j = 0; j < d; ++j) htv += std::max(0.0, hmu[dp + j] - ri.n_total * hmu[j] * hmu[j]);
     }

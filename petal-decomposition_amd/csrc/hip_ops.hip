@@ -1900,10 +1900,17 @@ __device__ __forceinline__ bf16x8 lds_tr2(const unsigned char* a0, const unsigne
 }
 // byte offset of 16-B chunk `ch` (eight features) of row `row` inside one plane of a wave's image ([32 rows][128 B])
 __device__ __forceinline__ int pow3_xoff(int row, int ch) { return row * 128 + 16 * (ch ^ ((2 * ((row >> 1) & 3)) ^ (row & 1))); }
-template <int NT, bool CENTER, bool STOREZ>
+// MEANS (the FIRST pass of a fit, round 5): `mu` is only a provisional centre mu0 (the means of a strided row sample), and the pass
+// gathers what the separate means pass used to: the LAST column of the last tile -- zero padding of P, so z is 0 there -- is set
+// to 1 for every valid row, which makes Y'[:, 16 NT - 1] = Xc0^T 1 the column sums about mu0 (product 2 forms them for free), and
+// the splits accumulate sum (x - mu0)^2 over the valid rows (one partial per wave in ssq_part).  k_mean_fix then moves everything
+// to the true centre mu = mu0 + delta, delta = sums / n:  Xc^T Xc P = Xc0^T Xc0 P - n delta (delta^T P),  sum (x - mu)^2 = ssq - n |delta|^2
+// -- a rank-one correction of relative size (delta / sigma)^2, i.e. harmless, where the same identity about mu0 = 0 would cancel
+// (mu / sigma)^2 of the product.
+template <int NT, bool CENTER, bool STOREZ, bool MEANS = false>
 __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64_t n, int64_t ldx, const float* __restrict__ mu,
                                               const bf16x8* __restrict__ Ppk3, int NTtot, float* __restrict__ part,
-                                              float* __restrict__ Z, int64_t ldz, int64_t nstages) {
+                                              float* __restrict__ Z, int64_t ldz, int64_t nstages, double* __restrict__ ssq_part) {
     constexpr int WV = 8, K = 512, XIMG = 3 * 32 * 128;          // bytes of one wave's plane image
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_pow3[];
     unsigned char* const sX = sm_pow3;                                           // [WV][3][32][128 B]
@@ -1993,7 +2000,8 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
     };
     // the raw fragments of feature chunk c (both row tiles): centred, split into three planes, parked in the wave's image; one
     // piece at a time (two splits in flight cost 28 registers)
-    auto split_park = [&](int c) {
+    float ssq = 0.f;
+    auto split_park = [&](int c, int64_t sidx) {
         POW3_LANE(ln);
         const int li = ln & 15, lq = ln >> 4;
 #pragma unroll
@@ -2003,6 +2011,12 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
                 const float* mp = sMu + 64 * wave + 32 * c + 8 * lq;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(mp), hi = *reinterpret_cast<const f32x4*>(mp + 4);
                 x -= f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            if (MEANS) {   // sum (x - mu0)^2 over the valid rows (rows beyond n are clamped loads of the last row)
+                float q2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q2 = fmaf(x[e], x[e], q2);
+                ssq += sidx * 32 + 16 * t + li < n ? q2 : 0.f;
             }
             bf16x8 xh, xm, xl;
             split3(x, xh, xm, xl);
@@ -2020,8 +2034,8 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
     // 16-B LDS stores per wave and stage) runs beside the other wave's MFMAs instead of in front of everybody's (phase stamps,
     // round 5: the split at the head of the stage was 1400 of its 16000 cycles with the matrix pipe idle).
     if (s0 < s1) {
-        split_park(0);
-        split_park(1);
+        split_park(0, s0);
+        split_park(1, s0);
         if (s0 + 1 < s1) load_x(s0 + 1);
     }
 #ifdef PETAL_DEBUG_COUNTERS
@@ -2069,6 +2083,13 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
                 z8[r] = rb + r < n ? zlo[r] : 0.f;
                 z8[4 + r] = rb + 16 + r < n ? zhi[r] : 0.f;
             }
+            if (MEANS && wave == NT - 1 && li == 15) {   // the all-ones column: Y'[:, 16 NT - 1] = Xc0^T 1
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z8[r] = rb + r < n ? 1.f : 0.f;
+                    z8[4 + r] = rb + 16 + r < n ? 1.f : 0.f;
+                }
+            }
             if (STOREZ) {
                 float* zp = Z + rb * ldz + 16 * wave + li;
 #pragma unroll
@@ -2103,7 +2124,7 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
                 }
                 if (s + 1 < s1) {                // this half of the image has been read for the last time: the next stage's pieces
                     __builtin_amdgcn_sched_barrier(0);
-                    split_park(mp);
+                    split_park(mp, s + 1);
                 }
 #pragma unroll
                 for (int u = 0; u < NT; ++u) {
@@ -2136,6 +2157,12 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
         atomicAdd((unsigned long long*)&g_cyc[8], (unsigned long long)(s1 - s0));
     }
 #endif
+    if (MEANS) {         // one partial of sum (x - mu0)^2 per wave, lanes added in a fixed order
+        float v = ssq;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) ssq_part[(int64_t)blockIdx.x * WV + wave] = (double)v;
+    }
     // this workgroup's slab: D[row = 4 q + r][col = i] of tile (m, u) is Y'[64 wave + 16 m + 4 q + r][16 u + i]
     {
         POW3_LANE(ln);
@@ -6666,26 +6693,33 @@ static bool pow3_ok(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t
     return !off && dt == F32 && d->gemm_mode == 0 && K == 512 && N % 16 == 0 && N >= 16 && N <= 80 && n >= min_rows &&
            n < (int64_t(1) << 40) && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && (!Z || (ldz >= N && aligned16(Z)));
 }
+// (the knobs that keep an operand at three planes also keep its product off the fused kernel, whose P is a two-plane one by construction)
+static bool pow3_knob_off(const char* name) { return getenv("PETAL_NO_P2") != nullptr || getenv(name) != nullptr; }
 bool op_power_pass_applies(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N) {
     return pow3_ok(d, dt, X, n, K, ldx, mu, N, nullptr, 0);
 }
 // Ppk3: the packed planes of the K x N small operand (k_pack_p3's layout; planes 0 and 1 are read)
+// ssq_parts_out (nullable; needs mu and no Z): the MEANS form -- mu is a provisional centre, Y's last column comes back as the column
+// sums about it and *ssq_parts_out as a device array of *nparts_out partials of sum (x - mu)^2 (see k_pow3)
 static void launch_pow3(Dev* d, const float* X, int64_t n, int64_t ldx, const float* mu, const bf16x8* Ppk3, int64_t N, float* Z, int64_t ldz,
-                        double* Y, int64_t ldy) {
+                        double* Y, int64_t ldy, double** ssq_parts_out = nullptr, int* nparts_out = nullptr) {
+    const bool ssq_out = ssq_parts_out != nullptr;
     const int NT = (int)(N / 16);
     const int64_t nstages = cdiv(n, 32);
     const int grid = (int)std::min<int64_t>(num_cus(d), nstages);
     float* part = (float*)dev_alloc(d, sizeof(float) * (size_t)grid * 512 * N);
+    double* ssq_part = ssq_out ? (double*)dev_alloc(d, sizeof(double) * (size_t)grid * 8) : nullptr;
     const size_t lds = (size_t)8 * 12288 + (size_t)8 * NT * 1024 + (size_t)NT * 3072 + 2048;
-#define POW3_GO(NTv, CE, SZ)                                                                                                      \
+#define POW3_GO(NTv, CE, SZ, ME)                                                                                                  \
     do {                                                                                                                          \
-        set_max_lds(d, reinterpret_cast<const void*>(k_pow3<NTv, CE, SZ>));                                                       \
-        hipLaunchKernelGGL((k_pow3<NTv, CE, SZ>), dim3(grid), dim3(512), lds, d->stream, X, n, ldx, mu, Ppk3, NT, part, Z, ldz, nstages); \
+        set_max_lds(d, reinterpret_cast<const void*>(k_pow3<NTv, CE, SZ, ME>));                                                   \
+        hipLaunchKernelGGL((k_pow3<NTv, CE, SZ, ME>), dim3(grid), dim3(512), lds, d->stream, X, n, ldx, mu, Ppk3, NT, part, Z, ldz, nstages, ssq_part); \
     } while (0)
 #define POW3_NT(NTv)                                                                                                              \
     do {                                                                                                                          \
-        if (mu && Z) POW3_GO(NTv, true, true); else if (mu) POW3_GO(NTv, true, false);                                            \
-        else if (Z) POW3_GO(NTv, false, true); else POW3_GO(NTv, false, false);                                                   \
+        if (ssq_out) POW3_GO(NTv, true, false, true);                                                                             \
+        else if (mu && Z) POW3_GO(NTv, true, true, false); else if (mu) POW3_GO(NTv, true, false, false);                         \
+        else if (Z) POW3_GO(NTv, false, true, false); else POW3_GO(NTv, false, false, false);                                     \
     } while (0)
     {
         TagScope ts(d);
@@ -6704,9 +6738,87 @@ static void launch_pow3(Dev* d, const float* X, int64_t n, int64_t ldx, const fl
     hipLaunchKernelGGL(k_sum_parts4, dim3(cdiv(512 * N, 128)), dim3(256), 0, d->stream, part, (int64_t)grid, (int64_t)512 * N, Y, N, ldy);
     launch_check();
     dev_free(d, part);
+    if (ssq_parts_out) { *ssq_parts_out = ssq_part; *nparts_out = grid * 8; }   // (the caller's next kernel adds them; it frees the block)
 }
-// (the knobs that keep an operand at three planes also keep its product off the fused kernel, whose P is a two-plane one by construction)
-static bool pow3_knob_off(const char* name) { return getenv("PETAL_NO_P2") != nullptr || getenv(name) != nullptr; }
+// the move from the provisional centre to the true one (see k_pow3, MEANS).  One workgroup per FOUR columns of Y:
+//   delta_f = Y[f][c1] / n;  t_j = sum_f delta_f P[f][j];  Y[f][j] -= n delta_f t_j (j < L);  Y[f][c1] = 0;
+// workgroup 0 also: mu64 = mu0 + delta (+ muT, the data type's copy) and *tv = (sum of the waves' partials of sum (x - mu0)^2) - n |delta|^2.
+// (every workgroup reads the sums column c1, so nobody may zero it in the same launch: that is the second launch, k_mean_fix<true>)
+template <bool FINISH>
+__global__ __launch_bounds__(256) void k_mean_fix(double* __restrict__ Y, int K, int d, int N, int64_t ldy, int c1, int L, double n_total,
+                                                  const double* __restrict__ P, int64_t ldp, double* __restrict__ mu64, float* __restrict__ muT,
+                                                  const double* __restrict__ ssq_part, int nparts, double* __restrict__ tv) {
+    __shared__ double sd[512];
+    __shared__ double sr[256];
+    __shared__ double st[4];
+    const int tid = threadIdx.x;
+    if (FINISH) {        // (second launch, one workgroup: the sums column is no longer needed)
+        for (int f = tid; f < K; f += 256) Y[(int64_t)f * ldy + c1] = 0.0;
+        return;
+    }
+    for (int f = tid; f < K; f += 256) sd[f] = f < d ? Y[(int64_t)f * ldy + c1] / n_total : 0.0;
+    __syncthreads();
+    const int j0 = blockIdx.x * 4, jj = tid & 3, fl = tid >> 2;      // 64 row lanes x 4 columns
+    double acc = 0;
+    if (j0 + jj < L)
+        for (int f = fl; f < K; f += 64) acc += sd[f] * P[(int64_t)f * ldp + j0 + jj];
+    sr[tid] = acc;
+    __syncthreads();
+    if (tid < 4) {
+        double t = 0;
+        for (int g = 0; g < 64; ++g) t += sr[g * 4 + tid];
+        st[tid] = t;
+    }
+    __syncthreads();
+    if (j0 + jj < L && j0 + jj != c1)
+        for (int f = fl; f < K; f += 64) Y[(int64_t)f * ldy + j0 + jj] -= n_total * sd[f] * st[jj];
+    if (blockIdx.x == 0) {
+        double q = 0;
+        for (int f = tid; f < K; f += 256) q += sd[f] * sd[f];
+        double sp = 0;
+        for (int e = tid; e < nparts; e += 256) sp += ssq_part[e];
+        __syncthreads();
+        sr[tid] = q;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) { if (tid < h) sr[tid] += sr[tid + h]; __syncthreads(); }
+        const double q2 = sr[0];
+        __syncthreads();
+        sr[tid] = sp;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) { if (tid < h) sr[tid] += sr[tid + h]; __syncthreads(); }
+        if (tid == 0) tv[0] = fmax(sr[0] - n_total * q2, 0.0);
+        for (int f = tid; f < K; f += 256) {
+            const double m = mu64[f] + sd[f];
+            mu64[f] = m;
+            muT[f] = (float)m;
+        }
+    }
+}
+bool op_power_pass_means(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t dcols, int64_t ldx, double n_total, const double* P,
+                         int64_t N, int64_t ldp, int64_t L, double* Y, int64_t ldy, double* mu64, void* muT, double* ssq_scratch, double* tv) {
+    static const bool off = getenv("PETAL_NO_MEANS_FOLD") != nullptr || pow3_knob_off("PETAL_NO_P2_OMEGA");
+    if (off || L >= N || !pow3_ok(d, dt, X, n, K, ldx, muT, N, nullptr, 0)) return false;
+    // the provisional centre: the means of a strided sample of the rows (one small pass)
+    const int64_t ns = std::min<int64_t>(n, 4096), stride = n / ns;
+    op_colmean(d, dt, X, ns, K, ldx * stride, double(ns), mu64, muT, false);
+    const int64_t total = (K / 32) * (N / 16) * 64;
+    bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
+    hipLaunchKernelGGL(k_pack_p3, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk3, (int)(N / 16), total);
+    launch_check();
+    double* parts = nullptr;
+    int nparts = 0;
+    launch_pow3(d, (const float*)X, n, ldx, (const float*)muT, Ppk3, N, nullptr, 0, Y, ldy, &parts, &nparts);
+    dev_free(d, Ppk3);
+    (void)ssq_scratch;
+    const int c1 = (int)(N - 1);
+    hipLaunchKernelGGL(k_mean_fix<false>, dim3((unsigned)cdiv(L, 4)), dim3(256), 0, d->stream, Y, (int)K, (int)dcols, (int)N, ldy, c1, (int)L, n_total, P, ldp,
+                       mu64, (float*)muT, (const double*)parts, nparts, tv);
+    hipLaunchKernelGGL(k_mean_fix<true>, dim3(1), dim3(256), 0, d->stream, Y, (int)K, (int)dcols, (int)N, ldy, c1, (int)L, n_total, P, ldp, mu64,
+                       (float*)muT, (const double*)parts, nparts, tv);
+    launch_check();
+    dev_free(d, parts);
+    return true;
+}
 bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
                    void* Z, int64_t ldz, double* Y, int64_t ldy) {
     static const bool knob = pow3_knob_off("PETAL_NO_P2_OMEGA");

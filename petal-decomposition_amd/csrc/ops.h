@@ -119,6 +119,13 @@ void op_rebase_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t 
 bool op_power_pass_applies(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N);
 bool op_power_pass(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
                    void* Z, int64_t ldz, double* Y, int64_t ldy);
+// The FIRST fused pass of a fit with the means pass folded in (single rank, fp32, centring; L < N: a padding column is free):
+// mu64 / muT come back as the column means of X (d real columns of K), *tv as sum (X - mean)^2, and Y = Xc^T (Xc P) about that
+// mean -- X is read once, not twice: the kernel centres about the means of a row SAMPLE, gathers the exact column sums and the sum
+// of squares about that provisional centre in the same pass, and a one-workgroup kernel moves Y, the means and the variance to the
+// true centre (a rank-one correction of relative size (delta / sigma)^2).  ssq_scratch: one device double.  False: nothing done.
+bool op_power_pass_means(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t d, int64_t ldx, double n_total, const double* P,
+                         int64_t N, int64_t ldp, int64_t L, double* Y, int64_t ldy, double* mu64, void* muT, double* ssq_scratch, double* tv);
 // the same behind one re-basing step (arguments as op_rebase_xp, p_planes = 2): P_out = A R^-1 rounded, then the fused pass with it
 bool op_rebase_power_pass(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                           int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,

@@ -352,6 +352,19 @@ def two_plane_verdict_case(ctx, n=3000, d=128, k=12):
         ctx.set_gemm_mode("fp32")
 
 
+def means_fold_case(ctx, n, d, k, n_iter=5, seed=81, device=False):
+    """The means pass folded into the first fused pass (op_power_pass_means; single rank, fp32, n_iter >= 3): planted data with a
+    LARGE mean (|mu| = 40 sigma_noise: what a centre of 0 would cancel against) and, second, rows SORTED by their leading score so
+    that the strided sample behind the provisional centre is what protects it; means, total variance, components and signs
+    against the oracle."""
+    rng = np.random.default_rng(seed)
+    x = po.synth_pca(n, d, k, seed=seed, dtype=np.float32)
+    x += (40.0 * rng.standard_normal(d)).astype(np.float32)
+    rpca_parity(ctx, n, d, k, n_iter, seed, x=x, device=device, tol=2e-5, tol_sigma=1e-5)
+    xs = x[np.argsort(x @ rng.standard_normal(d))].copy()     # sorted along a random direction: the first rows are far from the mean
+    rpca_parity(ctx, n, d, k, n_iter, seed + 1, x=xs, device=device, tol=2e-5, tol_sigma=1e-5)
+
+
 def pca_parity(ctx, n, d, k, seed, dtype=np.float64, tol=1e-9, thin_oracle=False):
     x = po.synth_pca(n, d, k, seed=seed, dtype=dtype)
     o = po.PcaOracle(k, thin=thin_oracle)

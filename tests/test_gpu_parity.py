@@ -126,6 +126,18 @@ def test_host_inputs_that_are_not_row_major(ctx, layout):
         assert time.perf_counter() - t0 < 0.1      # (upload + device gather + fit; the host gather alone took 0.3 s)
 
 
+def test_means_folded_into_the_first_fused_pass(ctx, monkeypatch):
+    """src/pca.rs:520-533 (means, centred copy, total variance: three passes in the crate, one here in round 4) inside the FIRST
+    fused power-iteration pass: centred about the means of a strided row sample, the exact column sums from an all-ones column of
+    z, sum (x - mu0)^2 from the splits, then a rank-one move to the true centre.  Data with |mu| = 40 sigma, and rows sorted so that
+    the head of the matrix is far from the mean; in fp32-MFMA mode the same cases run the separate means pass."""
+    monkeypatch.setenv("PETAL_MEANS_FOLD_ROWS", "0")       # (the product folds from 200000 rows on: see test_gpu_fullsize / bench)
+    pc.means_fold_case(ctx, 20000, 512, 64, device=True)
+    pc.means_fold_case(ctx, 9001, 512, 32, n_iter=7)
+    monkeypatch.delenv("PETAL_MEANS_FOLD_ROWS")
+    pc.means_fold_case(ctx, 200000, 512, 16, device=True)   # at the product's own threshold
+
+
 def test_components_beyond_a_ring_slot(ctx):
     """k d esz above the 8 MiB slot of the pinned result ring (rpca_fit's single result view threw there, e.g.
     k = 512 at d = 2048 fp64 or d = 4096 fp32): the components then leave by a copy of their own."""

@@ -58,6 +58,16 @@ def test_host_inputs_that_are_not_row_major(ctx, layout):
     pc.rpca_parity(ctx, 500, 24, 4, 4, seed=10, dtype=np.float64, tol=1e-9, host_layout=layout)
 
 
+def test_means_folded_into_the_first_fused_pass(ctx, monkeypatch):
+    monkeypatch.setenv("PETAL_MEANS_FOLD_ROWS", "0")       # (the product folds from 200000 rows on)
+    ctx.set_gemm_mode("bf16x3")
+    try:
+        pc.means_fold_case(ctx, 2500, 64, 6)
+        pc.rpca_parity(ctx, 2000, 48, 6, 5, seed=83)
+    finally:
+        ctx.set_gemm_mode("fp32")
+
+
 def test_power_pass_entry(ctx):
     """petal_power_pass through the host simulation: the fused form (split-product mode) and the K1 + K2 fall-back"""
     assert pc.power_pass_exact(ctx, 300, 48, 20, seed=1) is False
