@@ -25,7 +25,7 @@ BUDGETS = [
     (r"k_xp3<", 256, 0, "every K1 split-product instantiation: no scratch"),
     # (one 8-wave workgroup per CU, two waves per SIMD: 256 is the whole budget, and a spilled P fragment is reloaded BEHIND the
     # stage's X loads -- vmcnt retires in order -- which cost the first build 7300 cycles in a 1300-cycle phase)
-    (r"k_pow3<5, (true|false), (true|false)>$", 256, 0, "fused power-iteration pass, l = 74 (configs[1], the north-star point)"),
+    (r"k_pow3<5, (true|false), (true|false), (true|false)>$", 256, 0, "fused power-iteration pass, l = 74 (configs[1], the north-star point)"),
     (r"k_pow3<", 256, 0, "every fused-pass instantiation: no scratch"),
     (r"k_ica3<2>$", 128, 0, "FastICA step, 32 components: 4 waves/SIMD"),
     (r"k_ica3<4>$", 256, 0, "FastICA step, 64 components"),
