@@ -86,6 +86,11 @@ typedef struct petal_stats {
     double  stream_ms;         /* the other row-streaming kernels of a RandomizedPca fit (means pass, U = Z (T Uh)): with profiling at
                                   level 2, fit time - (xp + atb + pow + stream + allreduce) is the replicated small-matrix chain   */
     int64_t stream_launches;
+    /* FastIca: how the last fit ran */
+    int64_t ica_redo;          /* 0: the optimistic run stood (two-product subspace iteration; for fp32 data of >= 384 features the
+                                  covariance from the split-product Gram kernels); 1: redone with the residual-controlled iteration
+                                  on the fp64-MFMA covariance (failed residual verdict, or kept eigenvalues spread over > 2 decades) */
+    int64_t ica_gram_split;    /* 1: the covariance that reached the result came from the split-product Gram kernels              */
 } petal_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */

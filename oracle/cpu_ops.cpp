@@ -150,6 +150,12 @@ void op_gemm_atb(Dev*, int dt, const void* A, int64_t lda, int64_t M, const void
         }
     }
 }
+bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc) {
+    static const bool off = std::getenv("PETAL_NO_GRAM3") != nullptr;
+    if (off || d->gemm_mode == 1 || n < 64 || dd < 4) return false;   // (the simulation takes every shape the split-product modes would)
+    op_gemm_atb(d, F32, X, ldx, dp, mu, X, ldx, dp, mu, n, C, ldc, false);
+    return true;
+}
 void op_flip_key(Dev*, const double* t, double* key, int64_t L, const int* flag) {
     if (flag) key[L] = flag[0] != 0 ? 2.0 : (flag[1] != 0 ? 1.0 : 0.0);
     for (int64_t j = 0; j < L; ++j) {

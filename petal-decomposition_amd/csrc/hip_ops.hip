@@ -6686,6 +6686,168 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
     gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, M, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, true, nullptr, p_planes == 2);
 }
 
+// ---- split-product Gram matrix C = (X - mu)^T (X - mu) for FastICA's whitening (round 5) --------------------------------------
+// The fp64-MFMA Gram (k_atb_f64) is 60 % of a FastICA fit at the configs[4] share; the whitening only keeps the top eigenpairs of a
+// covariance whose wanted eigenvalues lie within a few decades, which fp32-accumulated exact products deliver (the fit checks the
+// spectrum it finds and falls back to the fp64 Gram otherwise: algo.cpp).  Two kernels:
+//  * k_presplit_t: X is centred and split ONCE into three bf16 planes, stored in MFMA fragment order, feature-major:
+//      Xpl[((b FT + ft) 3 + plane) 64 + lane][e] = plane of (X - mu)[32 b + 8 (lane >> 4) + e][16 ft + (lane & 15)]
+//    (rows beyond n and features beyond d are zeros) -- for a product that sums over ROWS this is the operand layout of both sides,
+//    and a 1-KB piece (one tile, one plane) is contiguous: it goes to LDS by LDS-DMA, lane-linear, no conversion anywhere else;
+//  * k_gram3: a 256 x 128 tile of C per 8-wave workgroup over a row chunk -- 32-row stages, the stage's 48 + 24 pieces double
+//    buffered in LDS (144 KB), every wave a 64 x 64 sub-tile: 24 fragment reads and 96 MFMAs (six piece products per tile pair,
+//    smallest first) per stage; only tiles that reach the upper triangle are launched, the tiles of one row chunk on one XCD (its L2
+//    serves the re-reads of the chunk's planes); fp32 slabs, combined and mirrored in fp64 by k_gram3_reduce.
+static inline int64_t round_up_i64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+template <bool CENTER>
+__global__ __launch_bounds__(256) void k_presplit_t(const float* __restrict__ X, int64_t n, int d, int64_t ldx, const float* __restrict__ mu,
+                                                    bf16x8* __restrict__ Xpl, int FT) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t b = blockIdx.x;
+    const int ft = blockIdx.y * 4 + wave;
+    if (ft >= FT) return;
+    const int f = 16 * ft + i;
+    f32x8 x;
+    const float m = (CENTER && f < d) ? mu[f] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int64_t r = 32 * b + 8 * q + e;
+        x[e] = (r < n && f < d) ? X[r * ldx + f] - m : 0.f;
+    }
+    bf16x8 h, mm, l;
+    split3(x, h, mm, l);
+    bf16x8* out = Xpl + ((b * FT + ft) * 3) * 64 + lane;
+    out[0] = h; out[64] = mm; out[128] = l;
+}
+__global__ __launch_bounds__(512) void k_gram3(const bf16x8* __restrict__ Xpl, int FT, int64_t nblocks, int64_t blocks_per_chunk, int ntiles,
+                                               const int* __restrict__ tile_mi, const int* __restrict__ tile_nj, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_g3[];   // [2][72 KB]: A pieces 0..47 (16 tiles x 3 planes), B pieces 48..71
+    constexpr int STAGE = 72 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves: rows 64 wm .. + 64 of the tile, columns 64 wn .. + 64
+    const int tile = blockIdx.x >> 3;
+    const int64_t chunk = (int64_t)blockIdx.y * 8 + (blockIdx.x & 7);
+    const int64_t b0 = chunk * blocks_per_chunk, b1 = min(nblocks, b0 + blocks_per_chunk);
+    if (b0 >= b1 || tile >= ntiles) return;                         // (uniform per workgroup)
+    const int mi = tile_mi[tile], nj = tile_nj[tile];
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this wave's nine pieces of a stage: piece p = wave + 8 j; p < 48: A (feature tile 16 mi + p / 3, plane p % 3), else B (8 nj + ..)
+    auto dma = [&](int64_t b, int buf) {
+        unsigned char* dst = sm_g3 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int p = wave + 8 * j;
+            const int ft = p < 48 ? 16 * mi + p / 3 : 8 * nj + (p - 48) / 3, pl = p < 48 ? p % 3 : (p - 48) % 3;
+            const bf16x8* src = Xpl + ((b * FT + ft) * 3 + pl) * 64 + lane;
+            __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(dst + p * 1024), 16, 0, 0);
+        }
+    };
+    dma(b0, 0);
+    for (int64_t b = b0; b < b1; ++b) {
+        const int buf = (int)((b - b0) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of stage b have landed
+        __builtin_amdgcn_s_barrier();                               // ... everybody's have; nobody still reads the other buffer
+        asm volatile("" ::: "memory");
+        if (b + 1 < b1) dma(b + 1, buf ^ 1);
+        const bf16x8* sA = reinterpret_cast<const bf16x8*>(sm_g3 + buf * STAGE) + (4 * wm) * 192 + lane;
+        const bf16x8* sB = reinterpret_cast<const bf16x8*>(sm_g3 + buf * STAGE + 48 * 1024) + (4 * wn) * 192 + lane;
+        bf16x8 bh[4], bm[4], bl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bh[c] = sB[c * 192]; bm[c] = sB[c * 192 + 64]; bl[c] = sB[c * 192 + 128]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const bf16x8 ah = sA[a * 192], am = sA[a * 192 + 64], al = sA[a * 192 + 128];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 c4 = acc[a][c];
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], c4, 0, 0, 0);   // smallest terms first
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], c4, 0, 0, 0);
+                acc[a][c] = c4;
+            }
+        }
+    }
+    // slab[(chunk ntiles + tile)][256][128]: D[row = 4 q + r][col = i] of tile (a, c) -> row 64 wm + 16 a + 4 q + r, column 64 wn + 16 c + i
+    float* out = slab + ((int64_t)chunk * ntiles + tile) * (256 * 128);
+    const int i = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* row = out + (64 * wm + 16 * a + 4 * q + r) * 128 + 64 * wn + i;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) row[16 * c] = acc[a][c][r];
+        }
+}
+// C[f][g] (and C[g][f]) = sum over the row chunks of the tile's slabs, fp64, fixed order; elements below the diagonal of a tile that
+// straddles it are left to the mirror
+__global__ __launch_bounds__(256) void k_gram3_reduce(const float* __restrict__ slab, int64_t nchunks, int ntiles, const int* __restrict__ tile_mi,
+                                                      const int* __restrict__ tile_nj, int d, double* __restrict__ C, int64_t ldc) {
+    const int tile = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;                   // element of the 256 x 128 tile
+    const int r = e >> 7, c = e & 127;
+    const int f = 256 * tile_mi[tile] + r, g = 128 * tile_nj[tile] + c;
+    if (f >= d || g >= d || g < f) return;
+    double sacc = 0;
+    const float* src = slab + (int64_t)tile * (256 * 128) + e;
+    for (int64_t k = 0; k < nchunks; ++k) sacc += (double)src[k * ntiles * (256 * 128)];
+    C[(int64_t)f * ldc + g] = sacc;
+    C[(int64_t)g * ldc + f] = sacc;
+}
+// C (d x d fp64, ldc; rows / columns d .. dp zero) = (X - mu)^T (X - mu), fp32 data; false: shape not covered, nothing done
+bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc) {
+    static const bool off = getenv("PETAL_NO_GRAM3") != nullptr;
+    if (off || d->gemm_mode == 1 || n < 4096 || dd < 64 || dp > 4096) return false;
+    const int FT = (int)(round_up_i64(dp, 256) / 16);              // feature tiles, padded to whole 256-feature tile rows
+    const int64_t nblocks = cdiv(n, 32);
+    bf16x8* Xpl = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * (size_t)nblocks * FT * 3 * 64);
+    {
+        const dim3 grid((unsigned)nblocks, (unsigned)cdiv(FT, 4));
+        if (mu) hipLaunchKernelGGL((k_presplit_t<true>), grid, dim3(256), 0, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, Xpl, FT);
+        else hipLaunchKernelGGL((k_presplit_t<false>), grid, dim3(256), 0, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, Xpl, FT);
+        launch_check();
+    }
+    // tiles that reach the upper triangle
+    std::vector<int> h;
+    const int MT = FT / 16, NTl = FT / 8;
+    std::vector<int> tmi, tnj;
+    for (int mi = 0; mi < MT; ++mi)
+        for (int nj = 0; nj < NTl; ++nj)
+            if (128 * nj + 128 > 256 * mi && 256 * mi < dd && 128 * nj < dd) { tmi.push_back(mi); tnj.push_back(nj); }
+    const int ntiles = (int)tmi.size();
+    // row chunks: one workgroup per CU (144 KB of LDS), about two rounds of them
+    const int ncu = num_cus(d);
+    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(2 * (int64_t)ncu, ntiles), nblocks / 8));
+    const int64_t bpc = cdiv(nblocks, nsplit);
+    nsplit = cdiv(nblocks, bpc);
+    int* tiles_dev = (int*)dev_alloc(d, sizeof(int) * 2 * ntiles);
+    h = tmi; h.insert(h.end(), tnj.begin(), tnj.end());
+    dev_h2d_async(d, tiles_dev, h.data(), sizeof(int) * h.size());
+    float* slab = (float*)dev_alloc(d, sizeof(float) * (size_t)nsplit * ntiles * 256 * 128);
+    set_max_lds(d, reinterpret_cast<const void*>(k_gram3));
+    {
+        TagScope ts(d);
+        hipLaunchKernelGGL(k_gram3, dim3(8 * ntiles, (unsigned)cdiv(nsplit, 8)), dim3(512), 144 * 1024, d->stream, Xpl, FT, nblocks, bpc, ntiles,
+                           tiles_dev, tiles_dev + ntiles, slab);
+        launch_check();
+        ts.stop();
+    }
+    HIP_CHECK(hipMemset2DAsync(C, ldc * sizeof(double), 0, dp * sizeof(double), dp, d->stream));
+    hipLaunchKernelGGL(k_gram3_reduce, dim3(128, ntiles), dim3(256), 0, d->stream, slab, nsplit, ntiles, tiles_dev, tiles_dev + ntiles, (int)dd, C, ldc);
+    launch_check();
+    dev_free(d, slab); dev_free(d, tiles_dev); dev_free(d, Xpl);
+    return true;
+}
+
 // ---- the fused power-iteration pass (k_pow3) ------------------------------------------------------------------------------
 static bool pow3_ok(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N, const void* Z, int64_t ldz) {
     static const bool off = getenv("PETAL_NO_POW3") != nullptr;

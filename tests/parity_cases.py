@@ -419,6 +419,31 @@ def ica_parity(ctx, n, d, nc, seed, dtype=np.float32, tol_src=5e-3, n_components
     return dev
 
 
+def ica_split_gram_case(ctx, n, d, nc):
+    """FastICA whitening from the split-product covariance (fp32 data, >= 384 features, optimistic run): parity as ica_parity on
+    well-conditioned mixing (the fast covariance stands: ica_gram_split = 1, no redo), and on a mixing matrix whose kept
+    eigenvalues spread over more than two decades, where the spectrum verdict must send the fit to the fp64 covariance."""
+    ica_parity(ctx, n, d, nc, seed=61, dtype=np.float32, n_components=nc)
+    st = ctx.stats()
+    assert st["ica_gram_split"] == 1 and st["ica_redo"] == 0, st
+    rng = np.random.default_rng(62)
+    s_ = rng.laplace(size=(n, nc))
+    a = rng.standard_normal((nc, d)) * np.logspace(0, -2.0, nc)[:, None]     # source amplitudes over two decades: lambda over four
+    x = (s_ @ a + 1e-4 * rng.standard_normal((n, d))).astype(np.float32)
+    w0 = rng.standard_normal((nc, nc)).astype(np.float32)
+    m = petal.FastIca(ctx=ctx, n_components=nc)
+    y = np.asarray(m.fit_transform(x, w_init=w0))
+    st = ctx.stats()
+    assert st["ica_redo"] == 1 and st["ica_gram_split"] == 0, st
+    o = po.FastIcaOracle(n_components=nc, whiten="eigh")
+    o.fit(x.astype(np.float64), w_init=w0.astype(np.float64))
+    yo = o.transform(x.astype(np.float64))
+    c = np.abs(y.astype(np.float64).T @ yo)
+    perm = c.argmax(axis=1)
+    assert sorted(perm.tolist()) == list(range(nc)), perm
+    assert np.abs(1.0 - c[np.arange(nc), perm]).max() <= 5e-3
+
+
 def ica_par_parity(ctx, n, nc, seed, dtype=np.float32, tol=1e-4):
     """ica_par fed the SAME whitened X1 and w_init as the oracle: W agrees elementwise"""
     x = po.synth_ica(n, nc, nc, seed=seed, dtype=np.float64)

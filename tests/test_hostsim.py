@@ -68,6 +68,14 @@ def test_means_folded_into_the_first_fused_pass(ctx, monkeypatch):
         ctx.set_gemm_mode("fp32")
 
 
+def test_fastica_whitening_from_the_split_product_covariance(ctx):
+    ctx.set_gemm_mode("bf16x3")
+    try:
+        pc.ica_split_gram_case(ctx, 3000, 384, 5)
+    finally:
+        ctx.set_gemm_mode("fp32")
+
+
 def test_power_pass_entry(ctx):
     """petal_power_pass through the host simulation: the fused form (split-product mode) and the K1 + K2 fall-back"""
     assert pc.power_pass_exact(ctx, 300, 48, 20, seed=1) is False
