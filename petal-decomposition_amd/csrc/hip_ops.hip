@@ -6737,12 +6737,18 @@ __global__ __launch_bounds__(512) void k_gram3(const bf16x8* __restrict__ Xpl, i
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // A tile on the diagonal (its 128 columns are features of its own 256 rows: nj = 2 mi or 2 mi + 1) has its B pieces among its A
+    // pieces: they are not fetched a second time (24 of the stage's 72 KB; four of the six tiles at d = 512 -- the kernel is bound by
+    // what L2 delivers to the LDS, 6 TB/s at this shape, not by its MFMAs)
+    const bool diag = (nj >> 1) == mi;
+    const int boff = diag ? (8 * (nj & 1)) * 3 * 1024 : 48 * 1024;   // where the B pieces of a stage sit, bytes from the stage's base
     // this wave's nine pieces of a stage: piece p = wave + 8 j; p < 48: A (feature tile 16 mi + p / 3, plane p % 3), else B (8 nj + ..)
     auto dma = [&](int64_t b, int buf) {
         unsigned char* dst = sm_g3 + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int p = wave + 8 * j;
+            if (diag && p >= 48) break;                             // (uniform)
             const int ft = p < 48 ? 16 * mi + p / 3 : 8 * nj + (p - 48) / 3, pl = p < 48 ? p % 3 : (p - 48) % 3;
             const bf16x8* src = Xpl + ((b * FT + ft) * 3 + pl) * 64 + lane;
             __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(dst + p * 1024), 16, 0, 0);
@@ -6756,7 +6762,7 @@ __global__ __launch_bounds__(512) void k_gram3(const bf16x8* __restrict__ Xpl, i
         asm volatile("" ::: "memory");
         if (b + 1 < b1) dma(b + 1, buf ^ 1);
         const bf16x8* sA = reinterpret_cast<const bf16x8*>(sm_g3 + buf * STAGE) + (4 * wm) * 192 + lane;
-        const bf16x8* sB = reinterpret_cast<const bf16x8*>(sm_g3 + buf * STAGE + 48 * 1024) + (4 * wn) * 192 + lane;
+        const bf16x8* sB = reinterpret_cast<const bf16x8*>(sm_g3 + buf * STAGE + boff) + (4 * wn) * 192 + lane;
         bf16x8 bh[4], bm[4], bl[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) { bh[c] = sB[c * 192]; bm[c] = sB[c * 192 + 64]; bl[c] = sB[c * 192 + 128]; }
@@ -6826,9 +6832,10 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
     const int ntiles = (int)tmi.size();
     // row chunks: one workgroup per CU (144 KB of LDS), about two rounds of them
     const int ncu = num_cus(d);
-    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(2 * (int64_t)ncu, ntiles), nblocks / 8));
+    // (whole rounds: 2 ncu / ntiles rounded DOWN -- 86 chunks x 6 tiles = 516 workgroups on 256 CUs ran a third round for four of them)
+    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>((2 * (int64_t)ncu) / ntiles, nblocks / 8));
     const int64_t bpc = cdiv(nblocks, nsplit);
-    nsplit = cdiv(nblocks, bpc);
+    nsplit = cdiv(nblocks, bpc);                                    // (never more than asked for)
     int* tiles_dev = (int*)dev_alloc(d, sizeof(int) * 2 * ntiles);
     h = tmi; h.insert(h.end(), tnj.begin(), tnj.end());
     dev_h2d_async(d, tiles_dev, h.data(), sizeof(int) * h.size());
