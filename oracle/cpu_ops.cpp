@@ -533,6 +533,7 @@ void op_tail_verdict(Dev*, const double* lam, int64_t L, int64_t k, const double
 }
 
 // ---- FastICA ---------------------------------------------------------------------------------
+void op_ica_prepare(Dev*, int, const void*, int64_t, int64_t, int64_t) {}
 void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode, int* zero2) {
     if (zero2) { zero2[0] = 0; zero2[1] = 0; }
     std::vector<double> S(size_t(nc) * nc), Z(size_t(nc) * nc), w(nc), M(size_t(nc) * nc);

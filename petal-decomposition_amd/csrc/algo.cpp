@@ -1143,6 +1143,7 @@ int64_t ica_loop(petal_ctx& c, int dt, const void* X1T, int64_t n, int64_t nc, i
     if (!prepared) { own = ica_prepare(c, nc, W, mode); prepared = &own; }
     DBuf& state = prepared->state;
     DBuf GX(c.dev, sizeof(double) * (nc * nc + nc));
+    op_ica_prepare(c.dev, dt, X1T, n, nc, ld);   // (what is constant over the loop: the bf16 planes of X1, made once)
     int hstate[2] = {0, 0};
     auto enqueue = [&](int64_t it, int* progress) {
         dev_set_tag(c.dev, TAG_ICA);

@@ -86,6 +86,10 @@ struct Dev {
     const double* ica_wpk3_for = nullptr;
     int64_t ica_wpk3_nc = 0;
     bool ica_wpk3_valid = false;
+    void* ica_x1pl = nullptr;             // the pre-split planes of the whitened data of the CURRENT fixed-point loop (op_ica_prepare)
+    size_t ica_x1pl_bytes = 0;
+    const void* ica_x1pl_for = nullptr;   // ... made from this X1T (nullptr: none)
+    int64_t ica_x1pl_n = 0, ica_x1pl_ld = 0;
     // accepted ||W W^T - I||_F^2 of the decorrelation inside the loop: 1e-7 relative for fp32 data (whose outputs are fp32),
     // fp64 round-off otherwise; set by op_ica_step from the data type it is handed
     double ica_ortho_tol2 = 1e-26;
@@ -2716,6 +2720,174 @@ __global__ __launch_bounds__(256, 2) void k_ica3(const float* __restrict__ X1T, 
     }
     __syncthreads();  // the slab aliases the transposition buffers
     ica_write_slab<NT>(dacc, gpa, sX, part);
+}
+// K7 on PRE-SPLIT whitened data (round 5).  X1 is constant over the 10 .. 200 iterations of a fit, and k_ica3 split it into bf16
+// planes twice per iteration (row fragments for the first product, transposed fragments for the second): a third or more of the
+// VALU instructions of a kernel that is paced by them (9.3 per MFMA, 16 % matrix-pipe busy: profiles/r04_pmc_fastica_*).  Here the
+// planes are made ONCE per fit (k_ica_planes), in fragment order:
+//     X1pl[(((b 2 + t) KCH + kc) 3 + plane) 64 + lane][e] = plane of X1[32 b + 16 t + (lane & 15)][32 kc + 8 (lane >> 4) + e]
+// -- a wave's load of one fragment is 1 KB contiguous -- and the step kernel loads them as they are: they ARE the first product's A
+// operand, and, parked in a wave-private row-major image (16-B chunks XOR-swizzled by the row, as k_pow3's), come back TRANSPOSED
+// through ds_read_b64_tr_b16 as the second product's B operand (k-slots declared to be the samples {4 q + r, 16 + 4 q + r}, which is
+// the first product's output layout: see k_ica3).  Only G = tanh(S) is split inside the loop.
+template <int KCH>
+__global__ __launch_bounds__(256) void k_ica_planes(const float* __restrict__ X1T, int64_t n, int64_t ld, int NCP, bf16x8* __restrict__ out,
+                                                    int64_t nfrag) {
+    const int64_t frag = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (b, t, kc)
+    if (frag >= nfrag) return;
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int kc = (int)(frag % KCH);
+    const int64_t bt = frag / KCH, row = 16 * bt + i;
+    f32x8 x = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < n && 32 * kc + 8 * q < NCP) {
+        const float* src = X1T + row * ld + 32 * kc + 8 * q;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+        x = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+    bf16x8 h, m, l;
+    split3(x, h, m, l);
+    bf16x8* o = out + (frag * 3) * 64 + lane;
+    o[0] = h; o[64] = m; o[128] = l;
+}
+// byte offset of 16-B chunk `ch` of row `row` in one plane of a wave's image: 128-B rows (64 components) as k_pow3's; 64-B rows (32
+// components): rows r and r + 4 share a 256-B bank row, so the upper four of each eight take the other half of it
+template <int NT>
+__device__ __forceinline__ int ica_xoff(int row, int ch) {
+    return NT == 4 ? pow3_xoff(row, ch) : row * 64 + 16 * (ch ^ (2 * ((row >> 2) & 1)));
+}
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_ica3p(const bf16x8* __restrict__ X1pl, int64_t n, const bf16x8* __restrict__ Wpk3,
+                                                  int64_t blocks_per_wave, float* __restrict__ part, const int* __restrict__ state) {
+    static_assert(NT == 2 || NT == 4, "whole 32-component chunks only");
+    if (state && state[0]) return;
+    constexpr int NCP = 16 * NT, KCH = NCP / 32, WITEMS = KCH * NT * 192;
+    constexpr int ROWB = NCP * 2, PLANE = 32 * ROWB, IMG = 3 * PLANE, SLAB = 2 * (NCP * NCP + NCP);
+    constexpr int SX = 4 * IMG > SLAB * 4 ? 4 * IMG : SLAB * 4;
+    __shared__ bf16x8 sW[WITEMS];
+    __shared__ __attribute__((aligned(16))) unsigned char sXb[SX];  // per wave [3 planes][32 samples][NCP bf16]; the slab at the end
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    for (int e = threadIdx.x; e < WITEMS; e += 256) sW[e] = Wpk3[e];
+    __syncthreads();
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    unsigned char* const img = sXb + wave * IMG;
+    f32x4 dacc[NT][NT];  // [component tile][x tile]
+    float gpa[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        gpa[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) dacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t b0 = wid * blocks_per_wave, b1 = min((n + 31) / 32, b0 + blocks_per_wave);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 xa[2][KCH][3];
+    auto load_a = [&](int64_t blk) {
+        const bf16x8* src = X1pl + (blk * 2 * KCH * 3) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xa[t][kc][pl] = src[((t * KCH + kc) * 3 + pl) * 64];
+    };
+    if (b0 < b1) load_a(b0);
+    const int trq = (lane >> 2) & 3, trp = lane & 3;
+    for (int64_t blk = b0; blk < b1; ++blk) {
+        const int64_t r0 = blk * 32;
+        // the planes go to the wave's image (row 16 t + i, chunk 4 kc + q), from which the second product reads them transposed
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+                unsigned char* a = img + ica_xoff<NT>(16 * t + i, 4 * kc + q);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(a + pl * PLANE) = xa[t][kc][pl];
+            }
+        bf16x8 nwh = sW[lane], nwm = sW[64 + lane], nwl = sW[128 + lane];
+        f32x4 sacc[2][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) sacc[t][u] = z4;
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const bf16x8 wh = nwh, wm = nwm, wl = nwl;
+                if (kc * NT + u + 1 < KCH * NT) {  // W's pieces are read one tile ahead (LDS latency off the MFMA path)
+                    const bf16x8* sw = sW + (kc * NT + u + 1) * 192 + lane;
+                    nwh = sw[0], nwm = sw[64], nwl = sw[128];
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 c4 = sacc[t][u];
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t][kc][2], wh, c4, 0, 0, 0);  // smallest terms first
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t][kc][1], wm, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t][kc][0], wl, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t][kc][1], wh, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t][kc][0], wm, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t][kc][0], wh, c4, 0, 0, 0);
+                    sacc[t][u] = c4;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk + 1 < b1) load_a(blk + 1);  // next pass's planes land behind tanh and the second product
+        // B operand of the second product: lane (j = i, q), slot e <- X1[r0 + (e < 4 ? 4 q + e : 16 + 4 q + e - 4)][16 b + j], transposed
+        // reads of the image (T10: lane 16 g + 4 q' + p supplies block row q', columns 4 p .. 4 p + 3)
+        bf16x8 bh[NT], bm[NT], bl[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const unsigned char* a0 = img + ica_xoff<NT>(4 * q + trq, 2 * b + (trp >> 1)) + 8 * (trp & 1);   // (row + 16: + 16 rows, same swizzle)
+            bh[b] = lds_tr2(a0, a0 + 16 * ROWB);
+            bm[b] = lds_tr2(a0 + PLANE, a0 + PLANE + 16 * ROWB);
+            bl[b] = lds_tr2(a0 + 2 * PLANE, a0 + 2 * PLANE + 16 * ROWB);
+        }
+        // sacc[t][u][r] = S[sample r0 + 16 t + 4 q + r][component 16 u + i].  Rows past n were stored as zero planes: S = 0
+        // and tanh(0) = 0 exactly, so only the g' sum needs masking (last pass).
+        const bool tail = r0 + 32 > n;
+        const float nvalid = tail ? (float)((n > r0 + 4 * q ? (int)min((int64_t)4, n - r0 - 4 * q) : 0) +
+                                            (n > r0 + 16 + 4 * q ? (int)min((int64_t)4, n - r0 - 16 - 4 * q) : 0))
+                                  : 8.0f;
+        bf16x8 gh, gm, gl;
+        auto make_g = [&](int u) {
+            f32x8 g8;
+            float gs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float g = tanh_fast(sacc[t][u][r]);
+                    g8[4 * t + r] = g;
+                    gs = fmaf(-g, g, gs);
+                }
+            gpa[u] += gs + nvalid;
+            split3(g8, gh, gm, gl);
+        };
+        make_g(0);
+        // D[component][x] += sum_samples G[sample][component] X1[sample][x]
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 fh = gh, fm = gm, fl = gl;
+            if (a + 1 < NT) make_g(a + 1);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                f32x4 c4 = dacc[a][b];
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, bh[b], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm, bm[b], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, bl[b], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm, bh[b], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, bm[b], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, bh[b], c4, 0, 0, 0);
+                dacc[a][b] = c4;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // the slab aliases the images
+    ica_write_slab<NT>(dacc, gpa, reinterpret_cast<float*>(sXb), part);
 }
 // combine the per-workgroup slabs in fp64 (fixed order) and drop the padding: GX_gp = [nc*nc | nc].
 // block = 32 outputs x 32 part-lanes (the reduction is latency-bound: many short independent load chains).
@@ -6352,6 +6524,26 @@ void op_logcosh_rows(Dev* d, int dt, const void* X, int64_t r, int64_t c, int64_
     launch_check();
 }
 
+// once per fixed-point loop: X1 is constant over its iterations, so its bf16 planes are made here (fp32 data, split-product modes,
+// 32 or 64 padded components) and every op_ica_step of the loop reads them instead of splitting X1 twice per iteration
+void op_ica_prepare(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t ld) {
+    static const bool off = getenv("PETAL_NO_ICA_PLANES") != nullptr;
+    d->ica_x1pl_for = nullptr;
+    const int NT = int((nc + 15) / 16);
+    if (off || dt != F32 || !gemm_split_product(d) || (NT != 2 && NT != 4) || n < 256 || ld % 4 != 0 || ld < 16 * NT || !aligned16(X1T)) return;
+    const int KCH = NT / 2;
+    const int64_t nfrag = cdiv(n, 32) * 2 * KCH;
+    const size_t need = sizeof(bf16x8) * (size_t)nfrag * 3 * 64;
+    if (!d->ica_x1pl || d->ica_x1pl_bytes < need) {
+        if (d->ica_x1pl) dev_free(d, d->ica_x1pl);
+        d->ica_x1pl = dev_alloc(d, need);
+        d->ica_x1pl_bytes = need;
+    }
+    if (KCH == 1) hipLaunchKernelGGL(k_ica_planes<1>, dim3((unsigned)cdiv(nfrag, 4)), dim3(256), 0, d->stream, (const float*)X1T, n, ld, 16 * NT, (bf16x8*)d->ica_x1pl, nfrag);
+    else hipLaunchKernelGGL(k_ica_planes<2>, dim3((unsigned)cdiv(nfrag, 4)), dim3(256), 0, d->stream, (const float*)X1T, n, ld, 16 * NT, (bf16x8*)d->ica_x1pl, nfrag);
+    launch_check();
+    d->ica_x1pl_for = X1T; d->ica_x1pl_n = n; d->ica_x1pl_ld = ld;
+}
 void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t ld, const double* W, double* GX_gp,
                  const int* state) {
     const int64_t cnt = nc * nc + nc;
@@ -6422,6 +6614,11 @@ void op_ica_step(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t
         const int blocks = cdiv(waves, 4);
         float* part = (float*)dev_alloc(d, sizeof(float) * blocks * slab);
         TagScope ts(d);
+        const bool pre = d->ica_x1pl_for == X1T && d->ica_x1pl_n == n && d->ica_x1pl_ld == ld && (NT == 2 || NT == 4);
+        if (pre) {
+            if (NT == 2) hipLaunchKernelGGL(k_ica3p<2>, dim3(blocks), dim3(256), 0, d->stream, (const bf16x8*)d->ica_x1pl, n, Wpk3, bpw, part, state);
+            else hipLaunchKernelGGL(k_ica3p<4>, dim3(blocks), dim3(256), 0, d->stream, (const bf16x8*)d->ica_x1pl, n, Wpk3, bpw, part, state);
+        } else
         switch (NT) {
             case 1: hipLaunchKernelGGL(k_ica3<1>, dim3(blocks), dim3(256), 0, d->stream, (const float*)X1T, n, ld, Wpk3, bpw, part, state); break;
             case 2: hipLaunchKernelGGL(k_ica3<2>, dim3(blocks), dim3(256), 0, d->stream, (const float*)X1T, n, ld, Wpk3, bpw, part, state); break;

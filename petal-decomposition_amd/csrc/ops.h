@@ -170,6 +170,9 @@ void op_logcosh_rows(Dev*, int dtype, const void* X, int64_t r, int64_t c, int64
 // X1T: n x nc (ld) whitened samples (sample-major).  W: nc x nc f64.
 // GX[i][j] = sum_s tanh(w_i . x_s) x_s[j];  gp[i] = sum_s (1 - tanh(w_i . x_s)^2)     (f64 out)
 // state[0] != 0 (converged) -> no-op.
+// Call once in front of a fixed-point loop over X1T (and again whenever X1T's CONTENTS change): lets the implementation prepare what
+// is constant over the loop's iterations (the device library: the bf16 planes of X1).  op_ica_step works without it.
+void op_ica_prepare(Dev*, int dtype, const void* X1T, int64_t n, int64_t nc, int64_t ld);
 void op_ica_step(Dev*, int dtype, const void* X1T, int64_t n, int64_t nc, int64_t ld,
                  const double* W, double* GX_gp /* nc*nc + nc contiguous */, const int* state);
 // ica.rs:334-358 on one workgroup: D = GX/n_total - gp/n_total (.) W; W1 = symdecorr(D); lim; update.
