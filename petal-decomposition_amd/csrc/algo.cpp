@@ -294,6 +294,8 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
     };
     auto deliver = [&] {};
     double h3[3], prev_rel = -1.0;
+    int bad_rates = 0;   // consecutive checks whose measured rate said "cannot get there" (one transient stall must not
+                         // send a spectrum that converges a few checks later to the full eigen-solve)
     for (int it = 0; it < 40; ++it) {
         if (it == 0) op_dgemm(dv, false, false, dp, p, dp, 1.0, C, dp, seed, p, 0.0, Y.f64(), p);   // (the start block is read-only)
         orth(Y, Q, it % 2 == 1 ? 2 : 1);   // (the Rayleigh-Ritz step of the odd iterations needs the orthonormal basis)
@@ -316,8 +318,11 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
             if (rel < 0) return false;
             if (prev_rel > 0) {
                 const double rate = rel / prev_rel;
-                if (!(rate < 1.0)) return false;
-                if (std::log(verdict_tol / rel) / std::log(rate) > 8.0) return false;
+                const bool hopeless = !(rate < 1.0) || std::log(verdict_tol / rel) / std::log(rate) > 8.0;
+                bad_rates = hopeless ? bad_rates + 1 : 0;
+                // (sharded fits: C is the all-reduced covariance and every kernel here is replicated, so all ranks take the same
+                // branch, as they do for the convergence verdict above)
+                if (bad_rates >= 2 || (hopeless && it >= 9)) return false;
             }
             prev_rel = rel;
         }
