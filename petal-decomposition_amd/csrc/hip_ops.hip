@@ -1103,16 +1103,35 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // one v_cv
 }
 // written pair-wise so hipcc emits packed converts (12), shifts / masks (16) and packed subtracts (8) per 8 elements;
 // the generic vector conversion costs one convert per ELEMENT
+#ifndef PETAL_SPLIT_DOT2
+#define PETAL_SPLIT_DOT2 1
+#endif
+// x - bf16 piece, for the two elements of a packed pair: one v_dot2c_f32_bf16 each ({h0, h1} . {-1, 0} + x0 and {h0, h1} . {0, -1} + x1;
+// the products and the sum are exact, dev/micro_dot2.hip) instead of a shift or mask to unpack the piece and a packed subtract:
+// 28 VALU instructions per eight elements instead of 36.  The selector constants sit in SGPRs (laundered: an inline constant on a
+// packed-bf16 operand would have to mean the same to the assembler and to the hardware).
+__device__ __forceinline__ void sub_pk_bf16(float& x0, float& x1, unsigned pk) {
+#if PETAL_SPLIT_DOT2
+    unsigned c0u, c1u;   // (not volatile: no inputs, so the two moves are common to every call site of a kernel and leave its loops)
+    asm("s_mov_b32 %0, 0xbf80" : "=s"(c0u));
+    asm("s_mov_b32 %0, 0xbf800000" : "=s"(c1u));
+    x0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, c0u), x0, false);
+    x1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, c1u), x1, false);
+#else
+    x0 -= __uint_as_float(pk << 16);
+    x1 -= __uint_as_float(pk & 0xffff0000u);
+#endif
+}
 __device__ __forceinline__ void split3(const f32x8 x, bf16x8& h, bf16x8& m, bf16x8& l) {
     u32x4 hh, mm, ll;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float x0 = x[2 * e], x1 = x[2 * e + 1];
-        hh[e] = cvt_pk_bf16(x0, x1);
-        const float r0 = x0 - __uint_as_float(hh[e] << 16), r1 = x1 - __uint_as_float(hh[e] & 0xffff0000u);
+        float r0 = x[2 * e], r1 = x[2 * e + 1];
+        hh[e] = cvt_pk_bf16(r0, r1);
+        sub_pk_bf16(r0, r1, hh[e]);
         mm[e] = cvt_pk_bf16(r0, r1);
-        const float s0 = r0 - __uint_as_float(mm[e] << 16), s1 = r1 - __uint_as_float(mm[e] & 0xffff0000u);
-        ll[e] = cvt_pk_bf16(s0, s1);
+        sub_pk_bf16(r0, r1, mm[e]);
+        ll[e] = cvt_pk_bf16(r0, r1);
     }
     h = __builtin_bit_cast(bf16x8, hh);
     m = __builtin_bit_cast(bf16x8, mm);
@@ -1927,6 +1946,12 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
     // some thirty loop-invariant LDS offsets and pointers into registers of their own and spills P fragments to pay for them
     // (each reload then waits behind the stage's X loads: vmcnt retires in order -- 7300 cycles for a 1300-cycle phase, measured).
 #define POW3_LANE(ln) int ln = threadIdx.x & 63; asm volatile("" : "+v"(ln))
+#ifndef PETAL_POW3_ZPF
+#define PETAL_POW3_ZPF 0
+#endif
+#ifndef PETAL_POW3_DEPHASE
+#define PETAL_POW3_DEPHASE 0
+#endif
     if (CENTER)
         for (int k = threadIdx.x; k < K; k += 64 * WV) sMu[k] = mu[k];
     // this wave's slice of P: chunk c <-> features 64 wave + 32 c .. + 32, B-operand fragments of the packed planes (k_pack_p3's
@@ -2117,25 +2142,29 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
         {
             POW3_LANE(ln);
             const int trq = (ln >> 2) & 3, trp = ln & 3, lq = ln >> 4;
+            // the twelve MFMAs per column tile of one pair of feature tiles (one set of z fragments; with ZPF the next tile's set is
+            // fetched under them -- the raw registers of the pieces already split are free by then)
+            auto mfma_pair = [&](const bf16x8(&ax)[2][3], int mp) {
+#if PETAL_POW3_ZPF
+                bf16x8 zc[3];
 #pragma unroll
-            for (int mp = 0; mp < 2; ++mp) {     // feature tiles in PAIRS: one set of z fragments feeds twelve MFMAs
-                bf16x8 ax[2][3];
-#pragma unroll
-                for (int mm = 0; mm < 2; ++mm) {
-                    const unsigned char* a0 = myX + pow3_xoff(4 * lq + trq, 2 * (2 * mp + mm) + (trp >> 1)) + 8 * (trp & 1);   // (row + 16: + 2048, same swizzle)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) ax[mm][pl] = lds_tr2(a0 + pl * 4096, a0 + pl * 4096 + 2048);
-                }
-                if (s + 1 < s1) {                // this half of the image has been read for the last time: the next stage's pieces
-                    __builtin_amdgcn_sched_barrier(0);
-                    split_park(mp, s + 1);
-                }
+                for (int pl = 0; pl < 3; ++pl) zc[pl] = sZB[(0 * 3 + pl) * 64 + ln];
+#endif
 #pragma unroll
                 for (int u = 0; u < NT; ++u) {
-                    // (ONE set of z fragments, re-read for each pair of feature tiles: its latency is covered by the twelve MFMAs of the
-                    // other wave of the SIMD; kept across the pairs, or fetched a tile ahead, it costs registers the kernel does not have)
                     __builtin_amdgcn_sched_barrier(0);
+#if PETAL_POW3_ZPF
+                    const bf16x8 zh = zc[0], zm = zc[1], zl = zc[2];
+                    if (u + 1 < NT) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) zc[pl] = sZB[((u + 1) * 3 + pl) * 64 + ln];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#else
+                    // (ONE set of z fragments, re-read for each pair of feature tiles: its latency is covered by the twelve MFMAs of the
+                    // other wave of the SIMD)
                     const bf16x8 zh = sZB[(u * 3 + 0) * 64 + ln], zm = sZB[(u * 3 + 1) * 64 + ln], zl = sZB[(u * 3 + 2) * 64 + ln];
+#endif
 #pragma unroll
                     for (int mm = 0; mm < 2; ++mm) {
                         f32x4 c4 = acc2[2 * mp + mm][u];
@@ -2147,6 +2176,34 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
                         c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][0], zh, c4, 0, 0, 0);
                         acc2[2 * mp + mm][u] = c4;
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+#pragma unroll
+            for (int mp = 0; mp < 2; ++mp) {     // feature tiles in PAIRS: one set of z fragments feeds twelve MFMAs
+                bf16x8 ax[2][3];
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    const unsigned char* a0 = myX + pow3_xoff(4 * lq + trq, 2 * (2 * mp + mm) + (trp >> 1)) + 8 * (trp & 1);   // (row + 16: + 2048, same swizzle)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) ax[mm][pl] = lds_tr2(a0 + pl * 4096, a0 + pl * 4096 + 2048);
+                }
+                // this half of the image has been read for the last time: the next stage's pieces go there.  The two waves of a SIMD
+                // (w, w + 4) take the split and the MFMAs in OPPOSITE order (DEPHASE), so that one's VALU run meets the other's MFMAs
+                // instead of its VALU run
+#if PETAL_POW3_DEPHASE
+                const bool split_first = wave < 4;
+#else
+                const bool split_first = true;
+#endif
+                if (split_first && s + 1 < s1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    split_park(mp, s + 1);
+                }
+                mfma_pair(ax, mp);
+                if (!split_first && s + 1 < s1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    split_park(mp, s + 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
