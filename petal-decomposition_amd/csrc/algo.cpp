@@ -1265,10 +1265,10 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         // whitening (ica.rs:189-208): left singular vectors / values of Xc^T == eigenpairs of Xc^T Xc
         DBuf C(c.dev, sizeof(double) * dp * dp), U(c.dev, sizeof(double) * dp * dp), lam(c.dev, sizeof(double) * dp), r3(c.dev, sizeof(double) * 3);
         // The covariance of fp32 data on the OPTIMISTIC run: exact bf16-piece products with fp32 accumulation over row chunks
-        // (op_gram_split: 1.7 instead of 2.7 ms at 500000 x 512, good to ~2e-6 of the largest entry) -- enough for a whitening whose
-        // kept eigenvalues lie within two decades, which the verdict below checks on the spectrum found; wider spectra, the redo and
-        // fp64 data take the fp64-MFMA Gram matrix.  (From 384 features on: below, the two cost the same.)
-        gram_fast = optimistic && dt == F32 && dp >= 384 && op_gram_split(c.dev, X.p, n, d, dp, X.ld, muT.p, C.f64(), dp);
+        // (op_gram_split: 1.35 instead of 2.7 ms at 500000 x 512, 0.14 instead of 0.34 ms at 200000 x 256, good to ~2e-6 of the largest
+        // entry) -- enough for a whitening whose kept eigenvalues lie within two decades, which the verdict below checks on the spectrum
+        // found; wider spectra, the redo and fp64 data take the fp64-MFMA Gram matrix.  (From 256 features on: one full tile.)
+        gram_fast = optimistic && dt == F32 && dp >= 256 && op_gram_split(c.dev, X.p, n, d, dp, X.ld, muT.p, C.f64(), dp);
         if (!gram_fast) op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
         allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
         // w_init and its symmetric decorrelation (ica.rs:210-216, 329) need nothing from the data: they go to the side stream and run

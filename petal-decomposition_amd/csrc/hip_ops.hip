@@ -7063,14 +7063,257 @@ __global__ __launch_bounds__(256) void k_gram3_reduce(const float* __restrict__ 
     C[(int64_t)f * ldc + g] = sacc;
     C[(int64_t)g * ldc + f] = sacc;
 }
+// ---- k_gram4: the same product on 256 x 256 tiles (late round 5).  k_gram3 is bound by what a CU takes in (72 KB of pieces per
+// 3072 matrix-pipe cycles: 23 B/clk asked of a path that delivers ~12), so the lever is bytes per flop: a 256 x 256 tile needs 96 KB
+// per 6144 cycles (16 B/clk; a tile ON the diagonal -- two of the three at d = 512, the only one at d = 256 -- 48 KB: its B pieces are
+// its A pieces), and the chunk's planes are fetched 2 x (d = 512) instead of 3.5 x.  A stage's 96 KB cannot be double buffered, so only A
+// is (2 x 48 KB) and B has ONE buffer (144 KB in all): every wave takes its twelve B fragments of the stage into registers first (it
+// needs them for all eight of its row tiles anyway), a barrier later the B buffer is free and the next stage's B pieces follow the A
+// pieces into flight, under this stage's MFMAs.  Waves 2 x 4: rows 128 wm .. + 128 (eight tiles, fragments streamed), columns 64 wn .. + 64.
+__global__ __launch_bounds__(512) void k_gram4(const bf16x8* __restrict__ Xpl, int FT, int64_t nblocks, int64_t blocks_per_chunk, int ntiles,
+                                               const int* __restrict__ tile_mi, const int* __restrict__ tile_nj, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_g4[];   // A[2][48 KB] (16 feature tiles x 3 planes), B[48 KB]
+    constexpr int PANEL = 48 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tile = blockIdx.x >> 3;
+    const int64_t chunk = (int64_t)blockIdx.y * 8 + (blockIdx.x & 7);
+    const int64_t b0 = chunk * blocks_per_chunk, b1 = min(nblocks, b0 + blocks_per_chunk);
+    if (b0 >= b1 || tile >= ntiles) return;                         // (uniform per workgroup)
+    const int mi = tile_mi[tile], nj = tile_nj[tile];
+    const bool diag = mi == nj;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this wave's six pieces of a panel: piece p = wave + 8 j (feature tile p / 3 of the panel's sixteen, plane p % 3)
+    auto dma = [&](int64_t b, int blk, unsigned char* dst) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int pc = wave + 8 * j;
+            const bf16x8* src = Xpl + ((b * FT + 16 * blk + pc / 3) * 3 + pc % 3) * 64 + lane;
+            __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+    unsigned char* const sBp = sm_g4 + 2 * PANEL;
+    dma(b0, mi, sm_g4);
+    if (!diag) dma(b0, nj, sBp);
+    for (int64_t b = b0; b < b1; ++b) {
+        unsigned char* const sAp = sm_g4 + (int)((b - b0) & 1) * PANEL;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of stage b have landed
+        __builtin_amdgcn_s_barrier();                               // ... everybody's have; nobody still reads the other A buffer
+        asm volatile("" ::: "memory");
+        const bf16x8* sB = reinterpret_cast<const bf16x8*>(diag ? sAp : sBp) + (4 * wn) * 192 + lane;
+        bf16x8 bh[4], bm[4], bl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bh[c] = sB[c * 192]; bm[c] = sB[c * 192 + 64]; bl[c] = sB[c * 192 + 128]; }
+        if (b + 1 < b1) dma(b + 1, mi, sm_g4 + (int)(((b - b0) & 1) ^ 1) * PANEL);
+        if (!diag) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the DMA above counts on vmcnt only)
+            __builtin_amdgcn_s_barrier();                           // every wave holds its B fragments: the B buffer is free
+            asm volatile("" ::: "memory");
+            if (b + 1 < b1) dma(b + 1, nj, sBp);
+        }
+        const bf16x8* sA = reinterpret_cast<const bf16x8*>(sAp) + (8 * wm) * 192 + lane;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const bf16x8 ah = sA[a * 192], am = sA[a * 192 + 64], al = sA[a * 192 + 128];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 c4 = acc[a][c];
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], c4, 0, 0, 0);   // smallest terms first
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], c4, 0, 0, 0);
+                acc[a][c] = c4;
+            }
+        }
+    }
+    // slab[(chunk ntiles + tile)][256][256]: D[row = 4 q + r][col = i] of tile (a, c) -> row 128 wm + 16 a + 4 q + r, column 64 wn + 16 c + i
+    float* out = slab + ((int64_t)chunk * ntiles + tile) * (256 * 256);
+    const int i = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* row = out + (128 * wm + 16 * a + 4 * q + r) * 256 + 64 * wn + i;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) row[16 * c] = acc[a][c][r];
+        }
+}
+// ---- k_gram5: k_gram4 WITHOUT the pre-split pass.  The planes were a third of the Gram path (0.5 ms of 1.65 at 500000 x 512: 1 GB
+// read, 1.5 GB written, then read 2 x) for a split that costs a workgroup ~110 VALU instructions per wave and stage beside 192 MFMAs.
+// Here every wave fetches its two feature tiles of the next stage's panels as fp32 straight in fragment order (lane (i, q): feature
+// 16 ft + i, samples 8 q .. + 7: eight dword loads per fragment, 64-B segments, both halves of a line by the same wave), centres and
+// splits them under this stage's MFMAs and stores the planes into the LDS panels k_gram4 filled by DMA: the A panel of stage b + 1 into
+// the other A buffer at any time, the B panel once the barrier behind the B-fragment reads has passed.  X is read d / 256 times
+// (tiles above the diagonal read two panels, tiles on it one) and nothing is written but the slabs.
+template <bool CENTER>
+__global__ __launch_bounds__(512) void k_gram5(const float* __restrict__ X, int64_t n, int d, int64_t ldx, const float* __restrict__ mu,
+                                               int64_t nblocks, const int* __restrict__ tile_bpc, int ntiles, const int* __restrict__ tile_mi,
+                                               const int* __restrict__ tile_nj, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_g5[];   // A[2][48 KB] (16 feature tiles x 3 planes), B[48 KB]
+    constexpr int PANEL = 48 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tile = blockIdx.x >> 3;
+    const int64_t chunk = (int64_t)blockIdx.y * 8 + (blockIdx.x & 7);
+    if (tile >= ntiles) return;                                     // (uniform per workgroup)
+    const int64_t blocks_per_chunk = tile_bpc[tile];                // (per tile: a tile above the diagonal costs more per stage, so its chunks are shorter)
+    const int64_t b0 = chunk * blocks_per_chunk, b1 = min(nblocks, b0 + blocks_per_chunk);
+    if (b0 >= b1) return;
+    const int mi = tile_mi[tile], nj = tile_nj[tile];
+    const bool diag = mi == nj;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this wave's two feature tiles (2 wave, 2 wave + 1) of a panel: raw fragments of one stage, and where their planes go.
+    // Addresses: a wave-uniform base per stage and panel (scalar registers) + a 32-bit per-lane offset that is re-derived at every use
+    // from a laundered lane index -- kept live across the stage, the sixteen 64-bit row pointers of the two panels cost 20 spilled
+    // registers beside the 128 accumulators.
+    const int ldxi = (int)ldx;
+    float muA[2], muB[2];
+    {
+        const int li = lane & 15;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int fa = 256 * mi + 32 * wave + 16 * t + li, fb = 256 * nj + 32 * wave + 16 * t + li;
+            muA[t] = (CENTER && fa < d) ? mu[fa] : 0.f;
+            muB[t] = (CENTER && fb < d) ? mu[fb] : 0.f;
+        }
+    }
+    auto fetch = [&](int64_t b, int blk, f32x8(&raw)[2]) {
+        int ln = threadIdx.x & 63;
+        asm volatile("" : "+v"(ln));
+        const int li = ln & 15, lq = ln >> 4;
+        const float* Xb = X + 32 * b * ldx;                          // (uniform)
+        const int left = (int)min((int64_t)32, n - 32 * b);         // valid rows of the stage (uniform)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int f = 256 * blk + 32 * wave + 16 * t + li;
+            const int o = 8 * lq * ldxi + min(f, d - 1);
+            if (left == 32) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) raw[t][e] = Xb[o + e * ldxi];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) raw[t][e] = 8 * lq + e < left ? Xb[o + e * ldxi] : 0.f;
+            }
+        }
+    };
+    auto park = [&](const f32x8(&raw)[2], int blk, const float(&m2)[2], unsigned char* panel, int64_t b) {
+        int ln = threadIdx.x & 63;
+        asm volatile("" : "+v"(ln));
+        const int li = ln & 15, lq = ln >> 4;
+        const int left = (int)min((int64_t)32, n - 32 * b);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x8 x = raw[t];
+            const bool live = 256 * blk + 32 * wave + 16 * t + li < d;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (live && 8 * lq + e < left) ? x[e] - m2[t] : 0.f;
+            bf16x8 h, m, l;
+            split3(x, h, m, l);
+            bf16x8* dst = reinterpret_cast<bf16x8*>(panel) + ((2 * wave + t) * 3) * 64 + ln;
+            dst[0] = h; dst[64] = m; dst[128] = l;
+        }
+    };
+    unsigned char* const sBp = sm_g5 + 2 * PANEL;
+    f32x8 rawA[2], rawB[2];
+    fetch(b0, mi, rawA);
+    if (!diag) fetch(b0, nj, rawB);
+    park(rawA, mi, muA, sm_g5, b0);
+    if (!diag) park(rawB, nj, muB, sBp, b0);
+    if (b0 + 1 < b1) { fetch(b0 + 1, mi, rawA); if (!diag) fetch(b0 + 1, nj, rawB); }
+    for (int64_t b = b0; b < b1; ++b) {
+        unsigned char* const sAp = sm_g5 + (int)((b - b0) & 1) * PANEL;
+        unsigned char* const sAn = sm_g5 + (int)(((b - b0) & 1) ^ 1) * PANEL;
+        __syncthreads();                                            // stage b's planes are in LDS; nobody still reads the other A buffer
+        const bool more = b + 1 < b1;
+        const bf16x8* sB = reinterpret_cast<const bf16x8*>(diag ? sAp : sBp) + (4 * wn) * 192 + lane;
+        const bf16x8* sA = reinterpret_cast<const bf16x8*>(sAp) + (8 * wm) * 192 + lane;
+        // the wave's four column tiles in two PAIRS (all four sets of B fragments at once, beside the raw stage in flight, do not fit the
+        // registers): the A fragments are read twice, and the B buffer is free once the second pair's fragments are in registers
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { bh[c] = sB[(2 * cp + c) * 192]; bm[c] = sB[(2 * cp + c) * 192 + 64]; bl[c] = sB[(2 * cp + c) * 192 + 128]; }
+            if (cp == 1 && !diag) __syncthreads();                  // every wave holds the last of its B fragments
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const bf16x8 ah = sA[a * 192], am = sA[a * 192 + 64], al = sA[a * 192 + 128];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    f32x4 c4 = acc[a][2 * cp + c];
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], c4, 0, 0, 0);   // smallest terms first
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], c4, 0, 0, 0);
+                    acc[a][2 * cp + c] = c4;
+                }
+                // the next stage's planes, under this pair's MFMAs -- at a different row tile in the two waves of a SIMD (w, w + 4), so
+                // that one's ~100 VALU instructions meet the other's MFMAs and not its VALU run (in step, both park with the pipe idle:
+                // 2300 cycles per stage measured)
+                if (a == (wave < 4 ? 1 : 5) && more && (cp == 0 || !diag)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    // (... and the raw registers go straight back into flight for the stage after it: a whole stage of slack for HBM)
+                    if (cp == 0) { park(rawA, mi, muA, sAn, b + 1); if (b + 2 < b1) fetch(b + 2, mi, rawA); }
+                    else { park(rawB, nj, muB, sBp, b + 1); if (b + 2 < b1) fetch(b + 2, nj, rawB); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    float* out = slab + ((int64_t)chunk * ntiles + tile) * (256 * 256);
+    const int i = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* row = out + (128 * wm + 16 * a + 4 * q + r) * 256 + 64 * wn + i;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) row[16 * c] = acc[a][c][r];
+        }
+}
+__global__ __launch_bounds__(256) void k_gram4_reduce(const float* __restrict__ slab, const int* __restrict__ tile_nch, int ntiles,
+                                                      const int* __restrict__ tile_mi, const int* __restrict__ tile_nj, int d,
+                                                      double* __restrict__ C, int64_t ldc) {
+    const int tile = blockIdx.y;
+    const int64_t nchunks = tile_nch[tile];
+    const int e = blockIdx.x * 256 + threadIdx.x;                   // element of the 256 x 256 tile
+    const int r = e >> 8, c = e & 255;
+    const int f = 256 * tile_mi[tile] + r, g = 256 * tile_nj[tile] + c;
+    if (f >= d || g >= d || g < f) return;
+    double sacc = 0;
+    const float* src = slab + (int64_t)tile * (256 * 256) + e;
+#pragma unroll 8
+    for (int64_t k = 0; k < nchunks; ++k) sacc += (double)src[k * ntiles * (256 * 256)];   // (fixed order; eight loads in flight)
+    C[(int64_t)f * ldc + g] = sacc;
+    C[(int64_t)g * ldc + f] = sacc;
+}
 // C (d x d fp64, ldc; rows / columns d .. dp zero) = (X - mu)^T (X - mu), fp32 data; false: shape not covered, nothing done
 bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc) {
     static const bool off = getenv("PETAL_NO_GRAM3") != nullptr;
     if (off || d->gemm_mode == 1 || n < 4096 || dd < 64 || dp > 4096) return false;
+    // form: 5 = 256 x 256 tiles, split on the fly (k_gram5, the default); 4 = 256 x 256 tiles on pre-split planes (k_gram4); 3 = 256 x 128
+    // tiles on pre-split planes (k_gram3, the first round-5 form).  PETAL_GRAM_FORM selects (A/B measurements, tests).
+    static const int form = [] { const char* e = getenv("PETAL_GRAM_FORM"); const int f = e ? atoi(e) : 5; return (f >= 3 && f <= 5) ? f : 5; }();
+    const bool wide = form != 3;
     const int FT = (int)(round_up_i64(dp, 256) / 16);              // feature tiles, padded to whole 256-feature tile rows
     const int64_t nblocks = cdiv(n, 32);
-    bf16x8* Xpl = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * (size_t)nblocks * FT * 3 * 64);
-    {
+    bf16x8* Xpl = nullptr;
+    if (form != 5) {
+        Xpl = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * (size_t)nblocks * FT * 3 * 64);
         const dim3 grid((unsigned)nblocks, (unsigned)cdiv(FT, 4));
         if (mu) hipLaunchKernelGGL((k_presplit_t<true>), grid, dim3(256), 0, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, Xpl, FT);
         else hipLaunchKernelGGL((k_presplit_t<false>), grid, dim3(256), 0, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, Xpl, FT);
@@ -7078,34 +7321,78 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
     }
     // tiles that reach the upper triangle
     std::vector<int> h;
-    const int MT = FT / 16, NTl = FT / 8;
+    const int MT = FT / 16, NTl = wide ? FT / 16 : FT / 8, TN = wide ? 256 : 128;
     std::vector<int> tmi, tnj;
     for (int mi = 0; mi < MT; ++mi)
         for (int nj = 0; nj < NTl; ++nj)
-            if (128 * nj + 128 > 256 * mi && 256 * mi < dd && 128 * nj < dd) { tmi.push_back(mi); tnj.push_back(nj); }
+            if (TN * nj + TN > 256 * mi && 256 * mi < dd && TN * nj < dd) { tmi.push_back(mi); tnj.push_back(nj); }
     const int ntiles = (int)tmi.size();
     // row chunks: one workgroup per CU (144 KB of LDS), about two rounds of them
     const int ncu = num_cus(d);
-    // (whole rounds: 2 ncu / ntiles rounded DOWN -- 86 chunks x 6 tiles = 516 workgroups on 256 CUs ran a third round for four of them)
-    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>((2 * (int64_t)ncu) / ntiles, nblocks / 8));
+    // (whole rounds: 2 ncu / ntiles rounded DOWN -- 86 chunks x 6 tiles = 516 workgroups on 256 CUs ran a third round for four of them;
+    // a chunk of at least 16 stages: a workgroup's 128 / 256 KB slab is written once and read once per chunk)
+    static const int rounds = [] { const char* e = getenv("PETAL_GRAM_ROUNDS"); return e ? atoi(e) : 2; }();
+    // (... and WHOLE rounds where the chunks would get shorter than that: 368 chunks of one tile on 256 CUs take as long as 512)
+    const int64_t min_stages = wide ? 16 : 8;
+    int64_t nsplit = (rounds * (int64_t)ncu) / ntiles;
+    for (int r = rounds - 1; r >= 1 && nsplit > nblocks / min_stages; --r) nsplit = (r * (int64_t)ncu) / ntiles;
+    nsplit = std::max<int64_t>(1, std::min<int64_t>(nsplit, nblocks / min_stages));
     const int64_t bpc = cdiv(nblocks, nsplit);
     nsplit = cdiv(nblocks, bpc);                                    // (never more than asked for)
-    int* tiles_dev = (int*)dev_alloc(d, sizeof(int) * 2 * ntiles);
-    h = tmi; h.insert(h.end(), tnj.begin(), tnj.end());
+    // k_gram5: a tile above the diagonal fetches and splits two panels per stage where a diagonal one handles one (7.2 against 5.3 us per
+    // stage measured): its chunks are shorter by that ratio, so that the workgroups of a round end together (equal chunks lost 18 %
+    // of the kernel to the CUs that drew two off-diagonal chunks)
+    std::vector<int> tbpc(ntiles, (int)bpc), tnch(ntiles, (int)nsplit);
+    int64_t max_split = nsplit;
+    if (form == 5 && ntiles > 1 && nsplit > 1) {
+        static const double w_off = [] { const char* e = getenv("PETAL_GRAM_OFFDIAG_COST"); return e ? atof(e) : 1.36; }();
+        double wsum = 0;
+        for (int t = 0; t < ntiles; ++t) wsum += tmi[t] == tnj[t] ? 1.0 : w_off;
+        const double total = double(nsplit) * ntiles;
+        for (int t = 0; t < ntiles; ++t) {
+            int64_t ns = std::max<int64_t>(1, (int64_t)(total * (tmi[t] == tnj[t] ? 1.0 : w_off) / wsum));
+            ns = std::min<int64_t>(ns, std::max<int64_t>(1, nblocks / min_stages));
+            tbpc[t] = (int)cdiv(nblocks, ns);
+            tnch[t] = (int)cdiv(nblocks, (int64_t)tbpc[t]);
+            max_split = std::max<int64_t>(max_split, tnch[t]);
+        }
+    }
+    int* tiles_dev = (int*)dev_alloc(d, sizeof(int) * 4 * ntiles);
+    h = tmi; h.insert(h.end(), tnj.begin(), tnj.end()); h.insert(h.end(), tbpc.begin(), tbpc.end()); h.insert(h.end(), tnch.begin(), tnch.end());
     dev_h2d_async(d, tiles_dev, h.data(), sizeof(int) * h.size());
-    float* slab = (float*)dev_alloc(d, sizeof(float) * (size_t)nsplit * ntiles * 256 * 128);
-    set_max_lds(d, reinterpret_cast<const void*>(k_gram3));
+    float* slab = (float*)dev_alloc(d, sizeof(float) * (size_t)max_split * ntiles * 256 * TN);
+    const dim3 grid(8 * ntiles, (unsigned)cdiv(max_split, 8));
     {
         TagScope ts(d);
-        hipLaunchKernelGGL(k_gram3, dim3(8 * ntiles, (unsigned)cdiv(nsplit, 8)), dim3(512), 144 * 1024, d->stream, Xpl, FT, nblocks, bpc, ntiles,
-                           tiles_dev, tiles_dev + ntiles, slab);
+        if (form == 5) {
+            if (mu) {
+                set_max_lds(d, reinterpret_cast<const void*>(k_gram5<true>));
+                hipLaunchKernelGGL(k_gram5<true>, grid, dim3(512), 144 * 1024, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, nblocks,
+                                   tiles_dev + 2 * ntiles, ntiles, tiles_dev, tiles_dev + ntiles, slab);
+            } else {
+                set_max_lds(d, reinterpret_cast<const void*>(k_gram5<false>));
+                hipLaunchKernelGGL(k_gram5<false>, grid, dim3(512), 144 * 1024, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, nblocks,
+                                   tiles_dev + 2 * ntiles, ntiles, tiles_dev, tiles_dev + ntiles, slab);
+            }
+        } else if (form == 4) {
+            set_max_lds(d, reinterpret_cast<const void*>(k_gram4));
+            hipLaunchKernelGGL(k_gram4, grid, dim3(512), 144 * 1024, d->stream, Xpl, FT, nblocks, bpc, ntiles, tiles_dev, tiles_dev + ntiles, slab);
+        } else {
+            set_max_lds(d, reinterpret_cast<const void*>(k_gram3));
+            hipLaunchKernelGGL(k_gram3, grid, dim3(512), 144 * 1024, d->stream, Xpl, FT, nblocks, bpc, ntiles, tiles_dev, tiles_dev + ntiles, slab);
+        }
         launch_check();
         ts.stop();
     }
     HIP_CHECK(hipMemset2DAsync(C, ldc * sizeof(double), 0, dp * sizeof(double), dp, d->stream));
-    hipLaunchKernelGGL(k_gram3_reduce, dim3(128, ntiles), dim3(256), 0, d->stream, slab, nsplit, ntiles, tiles_dev, tiles_dev + ntiles, (int)dd, C, ldc);
+    if (wide)
+        hipLaunchKernelGGL(k_gram4_reduce, dim3(256, ntiles), dim3(256), 0, d->stream, slab, tiles_dev + 3 * ntiles, ntiles, tiles_dev, tiles_dev + ntiles,
+                           (int)dd, C, ldc);
+    else
+        hipLaunchKernelGGL(k_gram3_reduce, dim3(128, ntiles), dim3(256), 0, d->stream, slab, nsplit, ntiles, tiles_dev, tiles_dev + ntiles, (int)dd, C, ldc);
     launch_check();
-    dev_free(d, slab); dev_free(d, tiles_dev); dev_free(d, Xpl);
+    dev_free(d, slab); dev_free(d, tiles_dev);
+    if (Xpl) dev_free(d, Xpl);
     return true;
 }
 
