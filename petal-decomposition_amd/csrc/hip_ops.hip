@@ -7152,23 +7152,18 @@ __global__ __launch_bounds__(512) void k_gram4(const bf16x8* __restrict__ Xpl, i
 // splits them under this stage's MFMAs and stores the planes into the LDS panels k_gram4 filled by DMA: the A panel of stage b + 1 into
 // the other A buffer at any time, the B panel once the barrier behind the B-fragment reads has passed.  X is read d / 256 times
 // (tiles above the diagonal read two panels, tiles on it one) and nothing is written but the slabs.
-template <bool CENTER>
-__global__ __launch_bounds__(512) void k_gram5(const float* __restrict__ X, int64_t n, int d, int64_t ldx, const float* __restrict__ mu,
-                                               int64_t nblocks, const int* __restrict__ tile_bpc, int ntiles, const int* __restrict__ tile_mi,
-                                               const int* __restrict__ tile_nj, float* __restrict__ slab) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm_g5[];   // A[2][48 KB] (16 feature tiles x 3 planes), B[48 KB]
+// DIAG: a tile ON the diagonal.  Its B panel is its A panel (one fetch, one park, one barrier per stage, room for all four sets of B
+// fragments), and of its 256 16 x 16 sub-tiles only the 136 that reach the upper triangle are computed: the sub-tiles are dealt out
+// CYCLICALLY (wave (wm, wn): row tiles wm + 2 a, column tiles wn + 4 c) and the waves paired on the SIMDs so that every SIMD gets
+// 32 - 36 of them (contiguous 128 x 64 blocks would leave one SIMD with 58 of its 64 and two waves with nothing).
+template <bool CENTER, bool DIAG>
+__device__ __forceinline__ void gram5_body(unsigned char* sm_g5, const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                           const float* __restrict__ mu, int mi, int nj, int64_t b0, int64_t b1, float* __restrict__ out) {
     constexpr int PANEL = 48 * 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int tile = blockIdx.x >> 3;
-    const int64_t chunk = (int64_t)blockIdx.y * 8 + (blockIdx.x & 7);
-    if (tile >= ntiles) return;                                     // (uniform per workgroup)
-    const int64_t blocks_per_chunk = tile_bpc[tile];                // (per tile: a tile above the diagonal costs more per stage, so its chunks are shorter)
-    const int64_t b0 = chunk * blocks_per_chunk, b1 = min(nblocks, b0 + blocks_per_chunk);
-    if (b0 >= b1) return;
-    const int mi = tile_mi[tile], nj = tile_nj[tile];
-    const bool diag = mi == nj;
+    // (DIAG: the pairing (0,2)+(1,0), (0,3)+(1,1), (1,3)+(0,0), (0,1)+(1,2) of waves w, w + 4)
+    const int wm = DIAG ? (180 >> wave) & 1 : wave >> 2, wn = DIAG ? (33918 >> (2 * wave)) & 3 : wave & 3;
     f32x4 acc[8][4];
 #pragma unroll
     for (int a = 0; a < 8; ++a)
@@ -7186,7 +7181,7 @@ __global__ __launch_bounds__(512) void k_gram5(const float* __restrict__ X, int6
         for (int t = 0; t < 2; ++t) {
             const int fa = 256 * mi + 32 * wave + 16 * t + li, fb = 256 * nj + 32 * wave + 16 * t + li;
             muA[t] = (CENTER && fa < d) ? mu[fa] : 0.f;
-            muB[t] = (CENTER && fb < d) ? mu[fb] : 0.f;
+            muB[t] = (CENTER && !DIAG && fb < d) ? mu[fb] : 0.f;
         }
     }
     auto fetch = [&](int64_t b, int blk, f32x8(&raw)[2]) {
@@ -7225,65 +7220,107 @@ __global__ __launch_bounds__(512) void k_gram5(const float* __restrict__ X, int6
             dst[0] = h; dst[64] = m; dst[128] = l;
         }
     };
+    auto mfma6 = [&](f32x4& c4, const bf16x8 ah, const bf16x8 am, const bf16x8 al, const bf16x8 bh, const bf16x8 bm, const bf16x8 bl) {
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c4, 0, 0, 0);   // smallest terms first
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c4, 0, 0, 0);
+    };
     unsigned char* const sBp = sm_g5 + 2 * PANEL;
     f32x8 rawA[2], rawB[2];
     fetch(b0, mi, rawA);
-    if (!diag) fetch(b0, nj, rawB);
+    if (!DIAG) fetch(b0, nj, rawB);
     park(rawA, mi, muA, sm_g5, b0);
-    if (!diag) park(rawB, nj, muB, sBp, b0);
-    if (b0 + 1 < b1) { fetch(b0 + 1, mi, rawA); if (!diag) fetch(b0 + 1, nj, rawB); }
+    if (!DIAG) park(rawB, nj, muB, sBp, b0);
+    if (b0 + 1 < b1) { fetch(b0 + 1, mi, rawA); if (!DIAG) fetch(b0 + 1, nj, rawB); }
+    const int park_at = wave < 4 ? 1 : 5;   // (a different row tile in the two waves of a SIMD: one's ~100 VALU instructions meet the
+                                            // other's MFMAs and not its VALU run -- in step, both park with the pipe idle: 2300 cycles per stage)
     for (int64_t b = b0; b < b1; ++b) {
         unsigned char* const sAp = sm_g5 + (int)((b - b0) & 1) * PANEL;
         unsigned char* const sAn = sm_g5 + (int)(((b - b0) & 1) ^ 1) * PANEL;
         __syncthreads();                                            // stage b's planes are in LDS; nobody still reads the other A buffer
         const bool more = b + 1 < b1;
-        const bf16x8* sB = reinterpret_cast<const bf16x8*>(diag ? sAp : sBp) + (4 * wn) * 192 + lane;
-        const bf16x8* sA = reinterpret_cast<const bf16x8*>(sAp) + (8 * wm) * 192 + lane;
-        // the wave's four column tiles in two PAIRS (all four sets of B fragments at once, beside the raw stage in flight, do not fit the
-        // registers): the A fragments are read twice, and the B buffer is free once the second pair's fragments are in registers
+        if constexpr (DIAG) {
+            const bf16x8* sB = reinterpret_cast<const bf16x8*>(sAp) + lane;
+            const bf16x8* sA = reinterpret_cast<const bf16x8*>(sAp) + lane;
+            bf16x8 bh[4], bm[4], bl[4];
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
-            bf16x8 bh[2], bm[2], bl[2];
+            for (int c = 0; c < 4; ++c) { const bf16x8* q = sB + (wn + 4 * c) * 192; bh[c] = q[0]; bm[c] = q[64]; bl[c] = q[128]; }
 #pragma unroll
-            for (int c = 0; c < 2; ++c) { bh[c] = sB[(2 * cp + c) * 192]; bm[c] = sB[(2 * cp + c) * 192 + 64]; bl[c] = sB[(2 * cp + c) * 192 + 128]; }
-            if (cp == 1 && !diag) __syncthreads();                  // every wave holds the last of its B fragments
+            for (int a = 0; a < 8; ++a) {
+                const bf16x8* q = sA + (wm + 2 * a) * 192;
+                const bf16x8 ah = q[0], am = q[64], al = q[128];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (wm + 2 * a <= wn + 4 * c) mfma6(acc[a][c], ah, am, al, bh[c], bm[c], bl[c]);   // (uniform: sub-tiles below the diagonal are skipped)
+                if (a == park_at && more) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    // (... and the raw registers go straight back into flight for the stage after it: a whole stage of slack for HBM)
+                    park(rawA, mi, muA, sAn, b + 1);
+                    if (b + 2 < b1) fetch(b + 2, mi, rawA);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            const bf16x8* sB = reinterpret_cast<const bf16x8*>(sBp) + (4 * wn) * 192 + lane;
+            const bf16x8* sA = reinterpret_cast<const bf16x8*>(sAp) + (8 * wm) * 192 + lane;
+            bf16x8 bh[4], bm[4], bl[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { bh[c] = sB[c * 192]; bm[c] = sB[c * 192 + 64]; bl[c] = sB[c * 192 + 128]; }
+            __syncthreads();                                        // every wave holds its B fragments: the B buffer is free
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
                 const bf16x8 ah = sA[a * 192], am = sA[a * 192 + 64], al = sA[a * 192 + 128];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    f32x4 c4 = acc[a][2 * cp + c];
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], c4, 0, 0, 0);   // smallest terms first
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], c4, 0, 0, 0);
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], c4, 0, 0, 0);
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], c4, 0, 0, 0);
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], c4, 0, 0, 0);
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], c4, 0, 0, 0);
-                    acc[a][2 * cp + c] = c4;
-                }
-                // the next stage's planes, under this pair's MFMAs -- at a different row tile in the two waves of a SIMD (w, w + 4), so
-                // that one's ~100 VALU instructions meet the other's MFMAs and not its VALU run (in step, both park with the pipe idle:
-                // 2300 cycles per stage measured)
-                if (a == (wave < 4 ? 1 : 5) && more && (cp == 0 || !diag)) {
+                for (int c = 0; c < 4; ++c) mfma6(acc[a][c], ah, am, al, bh[c], bm[c], bl[c]);
+                // the next stage's two panels at two different row tiles, and at different ones in the two waves of a SIMD
+                if (a == (park_at >> 1) && more) {                  // a = 0 / 2
                     __builtin_amdgcn_sched_barrier(0);
-                    // (... and the raw registers go straight back into flight for the stage after it: a whole stage of slack for HBM)
-                    if (cp == 0) { park(rawA, mi, muA, sAn, b + 1); if (b + 2 < b1) fetch(b + 2, mi, rawA); }
-                    else { park(rawB, nj, muB, sBp, b + 1); if (b + 2 < b1) fetch(b + 2, nj, rawB); }
+                    park(rawA, mi, muA, sAn, b + 1);
+                    if (b + 2 < b1) fetch(b + 2, mi, rawA);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (a == 4 + (park_at >> 1) && more) {              // a = 4 / 6
+                    __builtin_amdgcn_sched_barrier(0);
+                    park(rawB, nj, muB, sBp, b + 1);
+                    if (b + 2 < b1) fetch(b + 2, nj, rawB);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
     }
-    float* out = slab + ((int64_t)chunk * ntiles + tile) * (256 * 256);
+    // slab [256][256]: D[row = 4 q + r][col = i] of sub-tile (R, C) -> row 16 R + 4 q + r, column 16 C + i
     const int i = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float* row = out + (128 * wm + 16 * a + 4 * q + r) * 256 + 64 * wn + i;
+            const int R = DIAG ? wm + 2 * a : 8 * wm + a;
+            float* row = out + (16 * R + 4 * q + r) * 256 + i;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) row[16 * c] = acc[a][c][r];
+            for (int c = 0; c < 4; ++c) {
+                const int C = DIAG ? wn + 4 * c : 4 * wn + c;
+                if (!DIAG || R <= C) row[16 * C] = acc[a][c][r];
+            }
         }
+}
+template <bool CENTER>
+__global__ __launch_bounds__(512) void k_gram5(const float* __restrict__ X, int64_t n, int d, int64_t ldx, const float* __restrict__ mu,
+                                               int64_t nblocks, const int* __restrict__ tile_bpc, int ntiles, const int* __restrict__ tile_mi,
+                                               const int* __restrict__ tile_nj, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_g5[];   // A[2][48 KB] (16 feature tiles x 3 planes), B[48 KB]
+    const int tile = blockIdx.x >> 3;
+    const int64_t chunk = (int64_t)blockIdx.y * 8 + (blockIdx.x & 7);
+    if (tile >= ntiles) return;                                     // (uniform per workgroup)
+    const int64_t blocks_per_chunk = tile_bpc[tile];                // (per tile: a tile above the diagonal costs more per stage, so its chunks are shorter)
+    const int64_t b0 = chunk * blocks_per_chunk, b1 = min(nblocks, b0 + blocks_per_chunk);
+    if (b0 >= b1) return;
+    const int mi = tile_mi[tile], nj = tile_nj[tile];
+    float* out = slab + ((int64_t)chunk * ntiles + tile) * (256 * 256);
+    if (mi == nj) gram5_body<CENTER, true>(sm_g5, X, n, d, ldx, mu, mi, nj, b0, b1, out);
+    else gram5_body<CENTER, false>(sm_g5, X, n, d, ldx, mu, mi, nj, b0, b1, out);
 }
 __global__ __launch_bounds__(256) void k_gram4_reduce(const float* __restrict__ slab, const int* __restrict__ tile_nch, int ntiles,
                                                       const int* __restrict__ tile_mi, const int* __restrict__ tile_nj, int d,
@@ -7339,13 +7376,14 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
     nsplit = std::max<int64_t>(1, std::min<int64_t>(nsplit, nblocks / min_stages));
     const int64_t bpc = cdiv(nblocks, nsplit);
     nsplit = cdiv(nblocks, bpc);                                    // (never more than asked for)
-    // k_gram5: a tile above the diagonal fetches and splits two panels per stage where a diagonal one handles one (7.2 against 5.3 us per
-    // stage measured): its chunks are shorter by that ratio, so that the workgroups of a round end together (equal chunks lost 18 %
-    // of the kernel to the CUs that drew two off-diagonal chunks)
+    // k_gram5: a tile above the diagonal computes 256 sub-tiles and fetches two panels per stage where a diagonal one computes 136 and
+    // fetches one (launched alone at 500000 x 512: 390 us for the one tile above the diagonal, 215 us for each of the two on it).  Its
+    // chunks are shorter -- by more than that ratio: the sweep 1.36 / 2.0 / 2.6 / 3.0 / 3.6 / 4.5 / 6 gave 1079 / 1102 / 968 / 926 / 885 /
+    // 914 / 984 us for the whole kernel, i.e. the workgroups that start last should be the short diagonal ones
     std::vector<int> tbpc(ntiles, (int)bpc), tnch(ntiles, (int)nsplit);
     int64_t max_split = nsplit;
     if (form == 5 && ntiles > 1 && nsplit > 1) {
-        static const double w_off = [] { const char* e = getenv("PETAL_GRAM_OFFDIAG_COST"); return e ? atof(e) : 1.36; }();
+        static const double w_off = [] { const char* e = getenv("PETAL_GRAM_OFFDIAG_COST"); return e ? atof(e) : 3.6; }();
         double wsum = 0;
         for (int t = 0; t < ntiles; ++t) wsum += tmi[t] == tnj[t] ? 1.0 : w_off;
         const double total = double(nsplit) * ntiles;
