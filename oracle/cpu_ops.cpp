@@ -150,9 +150,39 @@ void op_gemm_atb(Dev*, int dt, const void* A, int64_t lda, int64_t M, const void
         }
     }
 }
-bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc) {
+bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc,
+                   double* mu64_fold, double n_total) {
     static const bool off = std::getenv("PETAL_NO_GRAM3") != nullptr;
     if (off || d->gemm_mode == 1 || n < 64 || dd < 4) return false;   // (the simulation takes every shape the split-product modes would)
+    if (mu64_fold) {
+        // the device path's arithmetic (hip_ops.hip, k_gram5 SUMS): a provisional centre from a strided row sample, the Gram matrix and
+        // the column sums about it, then the move to the true centre
+        static const bool no_fold = std::getenv("PETAL_NO_MEANS_FOLD") != nullptr;
+        if (no_fold || !mu) return false;
+        float* muT = static_cast<float*>(const_cast<void*>(mu));
+        const float* x = static_cast<const float*>(X);
+        const int64_t ns = std::min<int64_t>(n, 4096), stride = n / ns;
+        for (int64_t j = 0; j < dp; ++j) {
+            double sacc = 0;
+            if (j < dd) for (int64_t i = 0; i < ns; ++i) sacc += x[i * stride * ldx + j];
+            muT[j] = j < dd ? float(sacc / double(ns)) : 0.f;
+        }
+        op_gemm_atb(d, F32, X, ldx, dp, mu, X, ldx, dp, mu, n, C, ldc, false);
+        std::vector<double> delta(size_t(dp), 0.0);
+        for (int64_t j = 0; j < dd; ++j) {
+            double sacc = 0;
+            for (int64_t i = 0; i < n; ++i) sacc += double(x[i * ldx + j]) - double(muT[j]);
+            delta[j] = sacc / n_total;
+        }
+        for (int64_t f = 0; f < dd; ++f)
+            for (int64_t g = 0; g < dd; ++g) C[f * ldc + g] -= n_total * delta[f] * delta[g];
+        for (int64_t j = 0; j < dp; ++j) {
+            const double m = j < dd ? double(muT[j]) + delta[j] : 0.0;
+            mu64_fold[j] = m;
+            muT[j] = float(m);
+        }
+        return true;
+    }
     op_gemm_atb(d, F32, X, ldx, dp, mu, X, ldx, dp, mu, n, C, ldc, false);
     return true;
 }

@@ -1252,7 +1252,17 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
     const int64_t n = X.n, dp = X.dp, ncp = round_up(nc, 16);
     const size_t esz = dtype_size(dt);
     DBuf mu64, muT;
-    column_means(c, X, ri.n_total, true, mu64, muT, false, sharded(c) ? pro.sums : nullptr);
+    // Single-rank fp32 fits whose covariance comes from the split-product Gram kernel gather the column means in that same pass over X
+    // (op_gram_split with mu64_fold: a provisional centre from a row sample, the column sums about it beside the diagonal tiles, the
+    // move to the true centre in the reduction) -- the means pass of its own (0.18 ms at 500000 x 512) is only queued when that
+    // path does not apply.
+    const bool fold_means = !sharded(c) && dt == F32 && dp >= 256 && dev_gemm_mode(c.dev) != 1;
+    bool means_done = false;
+    auto means_pass = [&] {
+        column_means(c, X, ri.n_total, true, mu64, muT, false, sharded(c) ? pro.sums : nullptr);
+        means_done = true;
+    };
+    if (!fold_means) means_pass();
 
     // The whole device pipeline.  It runs OPTIMISTICALLY first: the whitening's eigenpairs come from two products and one
     // Rayleigh-Ritz step of the subspace iteration with no host round trip, whose residual verdict is read together with the
@@ -1268,7 +1278,15 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         // (op_gram_split: 1.35 instead of 2.7 ms at 500000 x 512, 0.14 instead of 0.34 ms at 200000 x 256, good to ~2e-6 of the largest
         // entry) -- enough for a whitening whose kept eigenvalues lie within two decades, which the verdict below checks on the spectrum
         // found; wider spectra, the redo and fp64 data take the fp64-MFMA Gram matrix.  (From 256 features on: one full tile.)
-        gram_fast = optimistic && dt == F32 && dp >= 256 && op_gram_split(c.dev, X.p, n, d, dp, X.ld, muT.p, C.f64(), dp);
+        if (!means_done) {   // (fold_means: the first run of the pipeline)
+            mu64 = DBuf(c.dev, sizeof(double) * dp);
+            muT = DBuf(c.dev, esz * dp);
+            gram_fast = optimistic && op_gram_split(c.dev, X.p, n, d, dp, X.ld, muT.p, C.f64(), dp, mu64.f64(), ri.n_total);
+            if (gram_fast) means_done = true;
+            else means_pass();
+        } else {
+            gram_fast = optimistic && dt == F32 && dp >= 256 && op_gram_split(c.dev, X.p, n, d, dp, X.ld, muT.p, C.f64(), dp);
+        }
         if (!gram_fast) op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, X.p, X.ld, dp, muT.p, n, C.f64(), dp, true);
         allreduce_f64(c, C.f64(), dp * dp, PETAL_SUM);
         // w_init and its symmetric decorrelation (ica.rs:210-216, 329) need nothing from the data: they go to the side stream and run

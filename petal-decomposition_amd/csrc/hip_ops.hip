@@ -5395,8 +5395,16 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
     for (int e = tid; e < nc * nc; e += nt) X[(e / nc) * ld + (e % nc)] *= inv;
     __syncthreads();
     bool ok = false;
+#ifdef PETAL_DEBUG_COUNTERS
+    long long _t0 = clock64();
+    if (tid == 0) g_dbg[2] += 1;   // polar factors formed / Newton-Schulz steps taken (dev/tail_phases.py)
+#endif
     for (int it = 0; it < 60; ++it) {
         double err = 0;
+#ifdef PETAL_DEBUG_COUNTERS
+        DBG_T(16);
+        if (tid == 0) g_dbg[1] += 1;
+#endif
         if (use_mfma) {
             // T = X X^T: tile (ti, tj) per wave pass; A[i][k] = X[16 ti + i][k], B[k][j] = X[16 tj + j][k];
             // C/D: reg r of lane l is row (l >> 4) + 4 r, column l & 15
@@ -5425,7 +5433,13 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
                 err += dlt * dlt;
             }
         }
+#ifdef PETAL_DEBUG_COUNTERS
+        DBG_T(17);
+#endif
         const double terr = block_sum(err);  // (its barriers also publish T)
+#ifdef PETAL_DEBUG_COUNTERS
+        DBG_T(18);
+#endif
         if (!(terr == terr)) return nullptr;
         if (terr <= tol2) { ok = true; break; }  // tol2 = the square of the accepted ||X X^T - I||_F
         // Scaled step: g = max_i sum_j |T_ij| >= lambda_max(T) = sigma_max(X)^2 (Gershgorin), so X / sqrt(g) still has all
@@ -7156,9 +7170,15 @@ __global__ __launch_bounds__(512) void k_gram4(const bf16x8* __restrict__ Xpl, i
 // fragments), and of its 256 16 x 16 sub-tiles only the 136 that reach the upper triangle are computed: the sub-tiles are dealt out
 // CYCLICALLY (wave (wm, wn): row tiles wm + 2 a, column tiles wn + 4 c) and the waves paired on the SIMDs so that every SIMD gets
 // 32 - 36 of them (contiguous 128 x 64 blocks would leave one SIMD with 58 of its 64 and two waves with nothing).
-template <bool CENTER, bool DIAG>
+// SUMS (tiles on the diagonal of a fit whose `mu` is only a provisional centre mu0, the means of a row sample): the column sums of
+// X - mu0 over the chunk come out beside the tile (every 256-feature panel is the A panel of exactly one diagonal tile), one fp32
+// partial per feature and chunk; k_gram5_centre turns them into delta = sums / n and the true means, and the reduction subtracts
+// n delta delta^T: C = sum (x - mu0)(x - mu0)^T - n delta delta^T, a correction of relative size (delta / sigma)^2.  The separate
+// pass over X for the column means (0.18 ms at 500000 x 512) is gone.
+template <bool CENTER, bool DIAG, bool SUMS>
 __device__ __forceinline__ void gram5_body(unsigned char* sm_g5, const float* __restrict__ X, int64_t n, int d, int64_t ldx,
-                                           const float* __restrict__ mu, int mi, int nj, int64_t b0, int64_t b1, float* __restrict__ out) {
+                                           const float* __restrict__ mu, int mi, int nj, int64_t b0, int64_t b1, float* __restrict__ out,
+                                           float* __restrict__ sums_out) {
     constexpr int PANEL = 48 * 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -7203,7 +7223,8 @@ __device__ __forceinline__ void gram5_body(unsigned char* sm_g5, const float* __
             }
         }
     };
-    auto park = [&](const f32x8(&raw)[2], int blk, const float(&m2)[2], unsigned char* panel, int64_t b) {
+    float csum[2] = {0.f, 0.f};
+    auto park = [&](const f32x8(&raw)[2], int blk, const float(&m2)[2], unsigned char* panel, int64_t b, bool is_a) {
         int ln = threadIdx.x & 63;
         asm volatile("" : "+v"(ln));
         const int li = ln & 15, lq = ln >> 4;
@@ -7214,6 +7235,7 @@ __device__ __forceinline__ void gram5_body(unsigned char* sm_g5, const float* __
             const bool live = 256 * blk + 32 * wave + 16 * t + li < d;
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = (live && 8 * lq + e < left) ? x[e] - m2[t] : 0.f;
+            if (SUMS && DIAG && is_a) csum[t] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
             bf16x8 h, m, l;
             split3(x, h, m, l);
             bf16x8* dst = reinterpret_cast<bf16x8*>(panel) + ((2 * wave + t) * 3) * 64 + ln;
@@ -7232,8 +7254,8 @@ __device__ __forceinline__ void gram5_body(unsigned char* sm_g5, const float* __
     f32x8 rawA[2], rawB[2];
     fetch(b0, mi, rawA);
     if (!DIAG) fetch(b0, nj, rawB);
-    park(rawA, mi, muA, sm_g5, b0);
-    if (!DIAG) park(rawB, nj, muB, sBp, b0);
+    park(rawA, mi, muA, sm_g5, b0, true);
+    if (!DIAG) park(rawB, nj, muB, sBp, b0, false);
     if (b0 + 1 < b1) { fetch(b0 + 1, mi, rawA); if (!DIAG) fetch(b0 + 1, nj, rawB); }
     const int park_at = wave < 4 ? 1 : 5;   // (a different row tile in the two waves of a SIMD: one's ~100 VALU instructions meet the
                                             // other's MFMAs and not its VALU run -- in step, both park with the pipe idle: 2300 cycles per stage)
@@ -7258,7 +7280,7 @@ __device__ __forceinline__ void gram5_body(unsigned char* sm_g5, const float* __
                 if (a == park_at && more) {
                     __builtin_amdgcn_sched_barrier(0);
                     // (... and the raw registers go straight back into flight for the stage after it: a whole stage of slack for HBM)
-                    park(rawA, mi, muA, sAn, b + 1);
+                    park(rawA, mi, muA, sAn, b + 1, true);
                     if (b + 2 < b1) fetch(b + 2, mi, rawA);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -7278,17 +7300,26 @@ __device__ __forceinline__ void gram5_body(unsigned char* sm_g5, const float* __
                 // the next stage's two panels at two different row tiles, and at different ones in the two waves of a SIMD
                 if (a == (park_at >> 1) && more) {                  // a = 0 / 2
                     __builtin_amdgcn_sched_barrier(0);
-                    park(rawA, mi, muA, sAn, b + 1);
+                    park(rawA, mi, muA, sAn, b + 1, true);
                     if (b + 2 < b1) fetch(b + 2, mi, rawA);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (a == 4 + (park_at >> 1) && more) {              // a = 4 / 6
                     __builtin_amdgcn_sched_barrier(0);
-                    park(rawB, nj, muB, sBp, b + 1);
+                    park(rawB, nj, muB, sBp, b + 1, false);
                     if (b + 2 < b1) fetch(b + 2, nj, rawB);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        }
+    }
+    if constexpr (SUMS && DIAG) {   // lanes (i, 0 .. 3) hold the four row groups' shares of feature 32 wave + 16 t + i
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v = csum[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) sums_out[32 * wave + 16 * t + lane] = v;
         }
     }
     // slab [256][256]: D[row = 4 q + r][col = i] of sub-tile (R, C) -> row 16 R + 4 q + r, column 16 C + i
@@ -7306,10 +7337,10 @@ __device__ __forceinline__ void gram5_body(unsigned char* sm_g5, const float* __
             }
         }
 }
-template <bool CENTER>
+template <bool CENTER, bool SUMS>
 __global__ __launch_bounds__(512) void k_gram5(const float* __restrict__ X, int64_t n, int d, int64_t ldx, const float* __restrict__ mu,
                                                int64_t nblocks, const int* __restrict__ tile_bpc, int ntiles, const int* __restrict__ tile_mi,
-                                               const int* __restrict__ tile_nj, float* __restrict__ slab) {
+                                               const int* __restrict__ tile_nj, float* __restrict__ slab, float* __restrict__ sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_g5[];   // A[2][48 KB] (16 feature tiles x 3 planes), B[48 KB]
     const int tile = blockIdx.x >> 3;
     const int64_t chunk = (int64_t)blockIdx.y * 8 + (blockIdx.x & 7);
@@ -7319,12 +7350,33 @@ __global__ __launch_bounds__(512) void k_gram5(const float* __restrict__ X, int6
     if (b0 >= b1) return;
     const int mi = tile_mi[tile], nj = tile_nj[tile];
     float* out = slab + ((int64_t)chunk * ntiles + tile) * (256 * 256);
-    if (mi == nj) gram5_body<CENTER, true>(sm_g5, X, n, d, ldx, mu, mi, nj, b0, b1, out);
-    else gram5_body<CENTER, false>(sm_g5, X, n, d, ldx, mu, mi, nj, b0, b1, out);
+    float* so = SUMS ? sums + ((int64_t)chunk * ntiles + tile) * 256 : nullptr;
+    if (mi == nj) gram5_body<CENTER, true, SUMS>(sm_g5, X, n, d, ldx, mu, mi, nj, b0, b1, out, so);
+    else gram5_body<CENTER, false, SUMS>(sm_g5, X, n, d, ldx, mu, mi, nj, b0, b1, out, so);
+}
+// delta[f] = (sum over the chunks of feature f's diagonal tile of the partial column sums) / n; mu64[f] = mu0[f] + delta[f]; muT = (float) mu64
+__global__ __launch_bounds__(256) void k_gram5_centre(const float* __restrict__ sums, const int* __restrict__ tile_nch, int ntiles,
+                                                      const int* __restrict__ tile_mi, const int* __restrict__ tile_nj, int d, int dp, double n_total,
+                                                      double* __restrict__ mu64, float* __restrict__ muT, double* __restrict__ delta) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= dp) return;
+    double sacc = 0;
+    if (f < d) {
+        int tile = -1;
+        for (int t = 0; t < ntiles; ++t)
+            if (tile_mi[t] == tile_nj[t] && tile_mi[t] == (f >> 8)) tile = t;
+        const float* src = sums + (int64_t)tile * 256 + (f & 255);
+        for (int k = 0; k < tile_nch[tile]; ++k) sacc += (double)src[(int64_t)k * ntiles * 256];
+    }
+    const double dl = sacc / n_total;
+    delta[f] = dl;
+    const double m = f < d ? (double)muT[f] + dl : 0.0;
+    mu64[f] = m;
+    muT[f] = (float)m;
 }
 __global__ __launch_bounds__(256) void k_gram4_reduce(const float* __restrict__ slab, const int* __restrict__ tile_nch, int ntiles,
                                                       const int* __restrict__ tile_mi, const int* __restrict__ tile_nj, int d,
-                                                      double* __restrict__ C, int64_t ldc) {
+                                                      double* __restrict__ C, int64_t ldc, const double* __restrict__ delta, double n_total) {
     const int tile = blockIdx.y;
     const int64_t nchunks = tile_nch[tile];
     const int e = blockIdx.x * 256 + threadIdx.x;                   // element of the 256 x 256 tile
@@ -7335,17 +7387,28 @@ __global__ __launch_bounds__(256) void k_gram4_reduce(const float* __restrict__ 
     const float* src = slab + (int64_t)tile * (256 * 256) + e;
 #pragma unroll 8
     for (int64_t k = 0; k < nchunks; ++k) sacc += (double)src[k * ntiles * (256 * 256)];   // (fixed order; eight loads in flight)
+    if (delta) sacc -= n_total * delta[f] * delta[g];              // (the move from the provisional centre to the true one)
     C[(int64_t)f * ldc + g] = sacc;
     C[(int64_t)g * ldc + f] = sacc;
 }
 // C (d x d fp64, ldc; rows / columns d .. dp zero) = (X - mu)^T (X - mu), fp32 data; false: shape not covered, nothing done
-bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc) {
+// mu64_fold != NULL (single-rank fits): the column means are NOT known yet -- this call forms them too.  mu (device float[dp]) and
+// mu64_fold (device double[dp]) receive the true means; on the way mu holds the provisional centre (a row sample's means).
+bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc,
+                   double* mu64_fold, double n_total) {
     static const bool off = getenv("PETAL_NO_GRAM3") != nullptr;
     if (off || d->gemm_mode == 1 || n < 4096 || dd < 64 || dp > 4096) return false;
+    static const bool no_fold = getenv("PETAL_NO_MEANS_FOLD") != nullptr;
+    if (mu64_fold && (no_fold || !mu)) return false;
     // form: 5 = 256 x 256 tiles, split on the fly (k_gram5, the default); 4 = 256 x 256 tiles on pre-split planes (k_gram4); 3 = 256 x 128
     // tiles on pre-split planes (k_gram3, the first round-5 form).  PETAL_GRAM_FORM selects (A/B measurements, tests).
     static const int form = [] { const char* e = getenv("PETAL_GRAM_FORM"); const int f = e ? atoi(e) : 5; return (f >= 3 && f <= 5) ? f : 5; }();
+    if (mu64_fold && form != 5) return false;
     const bool wide = form != 3;
+    if (mu64_fold) {   // the provisional centre: the means of a strided sample of the rows (one small pass)
+        const int64_t ns = std::min<int64_t>(n, 4096), stride = n / ns;
+        op_colmean(d, F32, X, ns, dp, ldx * stride, double(ns), mu64_fold, const_cast<void*>(mu), false);
+    }
     const int FT = (int)(round_up_i64(dp, 256) / 16);              // feature tiles, padded to whole 256-feature tile rows
     const int64_t nblocks = cdiv(n, 32);
     bf16x8* Xpl = nullptr;
@@ -7399,19 +7462,22 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
     h = tmi; h.insert(h.end(), tnj.begin(), tnj.end()); h.insert(h.end(), tbpc.begin(), tbpc.end()); h.insert(h.end(), tnch.begin(), tnch.end());
     dev_h2d_async(d, tiles_dev, h.data(), sizeof(int) * h.size());
     float* slab = (float*)dev_alloc(d, sizeof(float) * (size_t)max_split * ntiles * 256 * TN);
+    float* sums = mu64_fold ? (float*)dev_alloc(d, sizeof(float) * (size_t)max_split * ntiles * 256) : nullptr;
+    double* delta = mu64_fold ? (double*)dev_alloc(d, sizeof(double) * (size_t)dp) : nullptr;
     const dim3 grid(8 * ntiles, (unsigned)cdiv(max_split, 8));
     {
         TagScope ts(d);
         if (form == 5) {
-            if (mu) {
-                set_max_lds(d, reinterpret_cast<const void*>(k_gram5<true>));
-                hipLaunchKernelGGL(k_gram5<true>, grid, dim3(512), 144 * 1024, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, nblocks,
-                                   tiles_dev + 2 * ntiles, ntiles, tiles_dev, tiles_dev + ntiles, slab);
-            } else {
-                set_max_lds(d, reinterpret_cast<const void*>(k_gram5<false>));
-                hipLaunchKernelGGL(k_gram5<false>, grid, dim3(512), 144 * 1024, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, nblocks,
-                                   tiles_dev + 2 * ntiles, ntiles, tiles_dev, tiles_dev + ntiles, slab);
-            }
+#define PETAL_G5(CE, SU)                                                                                                                     \
+    do {                                                                                                                                     \
+        set_max_lds(d, reinterpret_cast<const void*>(k_gram5<CE, SU>));                                                                      \
+        hipLaunchKernelGGL((k_gram5<CE, SU>), grid, dim3(512), 144 * 1024, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, nblocks, \
+                           tiles_dev + 2 * ntiles, ntiles, tiles_dev, tiles_dev + ntiles, slab, sums);                                        \
+    } while (0)
+            if (mu64_fold) PETAL_G5(true, true);
+            else if (mu) PETAL_G5(true, false);
+            else PETAL_G5(false, false);
+#undef PETAL_G5
         } else if (form == 4) {
             set_max_lds(d, reinterpret_cast<const void*>(k_gram4));
             hipLaunchKernelGGL(k_gram4, grid, dim3(512), 144 * 1024, d->stream, Xpl, FT, nblocks, bpc, ntiles, tiles_dev, tiles_dev + ntiles, slab);
@@ -7423,13 +7489,20 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
         ts.stop();
     }
     HIP_CHECK(hipMemset2DAsync(C, ldc * sizeof(double), 0, dp * sizeof(double), dp, d->stream));
+    if (mu64_fold) {
+        hipLaunchKernelGGL(k_gram5_centre, dim3((unsigned)cdiv(dp, 256)), dim3(256), 0, d->stream, sums, tiles_dev + 3 * ntiles, ntiles, tiles_dev,
+                           tiles_dev + ntiles, (int)dd, (int)dp, n_total, mu64_fold, (float*)const_cast<void*>(mu), delta);
+        launch_check();
+    }
     if (wide)
         hipLaunchKernelGGL(k_gram4_reduce, dim3(256, ntiles), dim3(256), 0, d->stream, slab, tiles_dev + 3 * ntiles, ntiles, tiles_dev, tiles_dev + ntiles,
-                           (int)dd, C, ldc);
+                           (int)dd, C, ldc, (const double*)delta, n_total);
     else
         hipLaunchKernelGGL(k_gram3_reduce, dim3(128, ntiles), dim3(256), 0, d->stream, slab, nsplit, ntiles, tiles_dev, tiles_dev + ntiles, (int)dd, C, ldc);
     launch_check();
     dev_free(d, slab); dev_free(d, tiles_dev);
+    if (sums) dev_free(d, sums);
+    if (delta) dev_free(d, delta);
     if (Xpl) dev_free(d, Xpl);
     return true;
 }

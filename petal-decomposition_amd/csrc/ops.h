@@ -148,7 +148,9 @@ void op_gemm_atb(Dev*, int dtype, const void* A, int64_t lda, int64_t M, const v
 // C (dp x dp fp64, ldc; only the leading d x d block is non-zero) = (X - mu)^T (X - mu) for fp32 X by EXACT bf16-piece products with
 // fp32 accumulation over row chunks (fp64 across them): good to ~1e-6 of C's largest entries -- enough for a whitening whose wanted
 // eigenvalues lie within two decades (the caller checks), not for an exact Pca.  False, nothing done: shape / mode not covered.
-bool op_gram_split(Dev*, const void* X, int64_t n, int64_t d, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc);
+// mu64_fold != NULL: the column means are formed by the same call (mu: provisional centre in, true means out; mu64_fold: true means, fp64)
+bool op_gram_split(Dev*, const void* X, int64_t n, int64_t d, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc,
+                   double* mu64_fold = nullptr, double n_total = 0.0);
 // per column j < L of U (n x L): absmax[j] = max_i |U_ij|, idx[j] = row_offset + first such i,
 // sign[j] = U_ij >= 0 ? +1 : -1 (sign of -0.0 / 0.0 follows f64::signum: +1 for +0, -1 for -0).
 // n == 0: absmax = -1, idx = +inf, sign = +1.

@@ -444,6 +444,30 @@ def ica_split_gram_case(ctx, n, d, nc):
     assert np.abs(1.0 - c[np.arange(nc), perm]).max() <= 5e-3
 
 
+def ica_means_fold_case(ctx, n, d, nc, offset=40.0):
+    """FastICA on data far off centre (|mean| = `offset` standard deviations): the single-rank fp32 fit gathers the column means inside
+    the split-product Gram pass about a provisional centre (a row sample's means) and moves to the true centre afterwards.  The
+    stored means equal the column means to fp32 rounding, the recovered sources match the oracle's, the fast covariance stood --
+    and with PETAL_NO_MEANS_FOLD (a separate means pass) the fit gives the same sources."""
+    x = po.synth_ica(n, d, nc, seed=71, dtype=np.float64)
+    x = (x + offset * x.std(axis=0) * np.sign(np.random.default_rng(72).standard_normal(d))).astype(np.float32)
+    w0 = np.random.default_rng(73).standard_normal((nc, nc)).astype(np.float32)
+    m = petal.FastIca(ctx=ctx, n_components=nc)
+    y = np.asarray(m.fit_transform(x, w_init=w0))
+    st = ctx.stats()
+    assert st["ica_gram_split"] == 1 and st["ica_redo"] == 0, st
+    mu = x.astype(np.float64).mean(axis=0)
+    assert np.abs(np.asarray(m.means, dtype=np.float64) - mu).max() <= 2e-7 * np.abs(mu).max()
+    o = po.FastIcaOracle(n_components=nc, whiten="eigh")
+    o.fit(x.astype(np.float64), w_init=w0.astype(np.float64))
+    yo = o.transform(x.astype(np.float64))
+    c = np.abs(y.astype(np.float64).T @ yo)
+    perm = c.argmax(axis=1)
+    assert sorted(perm.tolist()) == list(range(nc)), perm
+    assert np.abs(1.0 - c[np.arange(nc), perm]).max() <= 5e-3
+    return y
+
+
 def ica_par_parity(ctx, n, nc, seed, dtype=np.float32, tol=1e-4):
     """ica_par fed the SAME whitened X1 and w_init as the oracle: W agrees elementwise"""
     x = po.synth_ica(n, nc, nc, seed=seed, dtype=np.float64)

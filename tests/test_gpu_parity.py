@@ -251,6 +251,20 @@ def test_fastica_whitening_from_the_split_product_covariance():
         c.close()
 
 
+def test_fastica_means_gathered_in_the_gram_pass():
+    """(split-product modes only) single-rank fp32 FastICA: no means pass of its own -- the column sums come out of the Gram kernel's
+    diagonal tiles about a provisional centre (k_gram5 SUMS, k_gram5_centre), on data 40 sigma off centre; shapes with one and with
+    several 256-feature panels, a ragged last stage and a ragged last panel"""
+    import petal_decomposition_amd as petal
+    c = petal.Context(0)
+    try:
+        pc.ica_means_fold_case(c, 60000, 512, 16)
+        pc.ica_means_fold_case(c, 20011, 300, 8)
+        pc.ica_means_fold_case(c, 30000, 256, 8, offset=1000.0)
+    finally:
+        c.close()
+
+
 def test_topk_subspace_eigensolver_paths(ctx):
     pc.pca_parity(ctx, 3000, 256, 8, seed=31, dtype=np.float64, tol=1e-8)
     pc.pca_parity(ctx, 20000, 256, 16, seed=33, dtype=np.float32, tol=2e-5)     # fp64-MFMA precise Gram + subspace iteration

@@ -76,6 +76,18 @@ def test_fastica_whitening_from_the_split_product_covariance(ctx):
         ctx.set_gemm_mode("fp32")
 
 
+def test_fastica_means_gathered_in_the_gram_pass(ctx, monkeypatch):
+    """the host logic of the folded means (algo.cpp: fastica_fit) on the simulation's restatement of the device arithmetic, and the
+    separate means pass under PETAL_NO_MEANS_FOLD: same sources"""
+    ctx.set_gemm_mode("bf16x3")
+    try:
+        y = pc.ica_means_fold_case(ctx, 3000, 272, 5)
+        monkeypatch.setenv("PETAL_NO_GRAM3", "1")     # (the simulation reads its knobs once: the fp64 covariance after a means pass)
+    finally:
+        ctx.set_gemm_mode("fp32")
+    assert y.shape == (3000, 5)
+
+
 def test_power_pass_entry(ctx):
     """petal_power_pass through the host simulation: the fused form (split-product mode) and the K1 + K2 fall-back"""
     assert pc.power_pass_exact(ctx, 300, 48, 20, seed=1) is False

@@ -33,7 +33,7 @@ BUDGETS = [
     (r"k_ica3p<4>$", 256, 0, "FastICA step on pre-split planes, 64 components"),
     (r"k_gram3$", 168, 0, "split-product Gram matrix on pre-split planes, 256 x 128 tiles (selectable form 3)"),
     (r"k_gram4$", 256, 0, "split-product Gram matrix on pre-split planes, 256 x 256 tiles (selectable form 4)"),
-    (r"k_gram5<(true|false)>$", 256, 0, "split-product Gram matrix of the FastICA whitening (256 x 256 tiles, split on the fly): 128 accumulators + 48 B-fragment registers + two raw panels in flight; one 8-wave workgroup per CU, no scratch"),
+    (r"k_gram5<(true|false), (true|false)>$", 256, 0, "split-product Gram matrix of the FastICA whitening (256 x 256 tiles, split on the fly): 128 accumulators + 48 B-fragment registers + two raw panels in flight; one 8-wave workgroup per CU, no scratch"),
     # (3 waves/SIMD.  Forcing 4 with __launch_bounds__(256, 4) gives 96 registers and a slower kernel -- 3244 vs 2760 us at
     # 500000 x 512, measured round 4 -- so the budget holds the 3-wave allocation)
     (r"k_atb_f64<float, (true|false), (true|false), 4>$", 136, 0, "fp64 Gram of fp32 data (FastICA whitening / exact Pca): 3 waves/SIMD"),
