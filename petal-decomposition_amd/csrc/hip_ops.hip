@@ -5367,9 +5367,19 @@ __device__ void wg_symdecorr(const double* Win, double* Wout, int nc, int mode, 
 // quadratically once the singular values are O(1); returns false (caller falls back to the eigen-solver) if D is
 // singular / non-finite or 60 steps do not reach ||X X^T - I||_F <= 1e-13.
 // On entry X (LDS, leading dimension nc | 1) holds D; returns the LDS buffer holding the polar factor, or nullptr.
-__device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* s_red, double tol2 = 1e-26) {
+// Leading dimension of the three LDS matrices of the iteration.  The fp64 MFMA operands are read as 16 rows x 4 consecutive doubles per
+// instruction (lane (i, k): row i, column k0 + k): with the odd pitch of the Jacobi solvers (nc | 1: 130 dwords = 2 mod 64 banks) the
+// lanes (i, k) and (i + 1, k - 1) share a bank pair -- every operand read of X X^T a 2- to 4-way conflict, and the products are LDS time,
+// not matrix time (7400 clock ticks for 32 MFMAs per wave at nc = 64).  nc + 2 puts a row 4 (mod 8) dwords on: conflict-free for
+// the row-wise operands (both of X X^T, T of T X).
+__host__ __device__ constexpr int polar_ld(int nc) { return (nc & 15) ? (nc | 1) : nc + 2; }
+// NTC: the number of 16-wide tiles per side when it is known at compile time (nc = 16 NTC: the products' k loops unroll completely and
+// a tile's operand reads are all in flight before its first MFMA -- a 4-deep unroll exposed the LDS latency four times per tile), 0 otherwise.
+template <int NTC>
+__device__ double* wg_polar_ns(int nc_rt, double* X, double* T, double* Y, double* s_red, double tol2 = 1e-26) {
+    const int nc = NTC ? 16 * NTC : nc_rt;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
-    const int ld = nc | 1;
+    const int ld = polar_ld(nc);
     // nc a multiple of 16: the two nc^3 products of a step run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, operands
     // straight from LDS); the scalar loops below are LDS-bound -- two reads per FMA -- and cost 20 us per product at nc = 64
     const bool use_mfma = (nc & 15) == 0;
@@ -5383,8 +5393,13 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
         sum_slot ^= 1;
         if (lane == 0) slot[wv] = v;
         __syncthreads();
-        double t = 0;
-        for (int w = 0; w < nw; ++w) t += slot[w];
+        // (ONE LDS read per lane and four DPP steps inside each row of 16 lanes -- every row forms the same sum, the same bits in
+        // every lane -- instead of nw dependent reads: 8 x ~130 cycles, once per step)
+        double t = (lane & 15) < nw ? slot[lane & 15] : 0.0;
+        t += dpp_f64<0xB1>(t);
+        t += dpp_f64<0x4E>(t);
+        t += dpp_f64<0x141>(t);
+        t += dpp_f64<0x140>(t);
         return t;
     };
     double ss = 0;
@@ -5413,8 +5428,13 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
                 const double* pa = X + (16 * ti + (lane & 15)) * ld + (lane >> 4);
                 const double* pb = X + (16 * tj + (lane & 15)) * ld + (lane >> 4);
                 f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+                if constexpr (NTC > 0) {
+#pragma unroll
+                    for (int k0 = 0; k0 < 16 * NTC; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
+                } else {
 #pragma unroll 4
-                for (int k0 = 0; k0 < nc; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
+                    for (int k0 = 0; k0 < nc; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * ti + (lane >> 4) + 4 * r, j = 16 * tj + (lane & 15);
@@ -5496,8 +5516,13 @@ __device__ double* wg_polar_ns(int nc, double* X, double* T, double* Y, double* 
                 const double* pa = T + (16 * ti + (lane & 15)) * ld + (lane >> 4);
                 const double* pb = X + (lane >> 4) * ld + 16 * tj + (lane & 15);
                 f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+                if constexpr (NTC > 0) {
+#pragma unroll
+                    for (int k0 = 0; k0 < 16 * NTC; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0 * ld], acc, 0, 0, 0);
+                } else {
 #pragma unroll 4
-                for (int k0 = 0; k0 < nc; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0 * ld], acc, 0, 0, 0);
+                    for (int k0 = 0; k0 < nc; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0 * ld], acc, 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * ti + (lane >> 4) + 4 * r, j = 16 * tj + (lane & 15);
@@ -5531,10 +5556,12 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_symdecorr(const double* Wi
     // textbook (W W^T)^(-1/2) W is the orthogonal polar factor of W: scaled Newton-Schulz first, eigen-solver as fallback
     if constexpr (MB > 0) {
         if (mode == 0 || nc <= 2) {
-            const int ld = nc | 1;
+            const int ld = polar_ld(nc);
+            double* const P1 = S + nc * ld;   // (the polar iteration's own carving of the matrices' space: its pitch is not the solver's)
             for (int e = threadIdx.x; e < nc * nc; e += blockDim.x) S[(e / nc) * ld + (e % nc)] = Win[e];
             __syncthreads();
-            const double* res = wg_polar_ns(nc, S, Zt, Zt + nc * ld, ws.red);
+            constexpr int NTS = MB <= 4 ? MB : 0;   // (80 / 96 components: the unrolled products spill)
+            const double* res = nc == 16 * NTS ? wg_polar_ns<NTS>(nc, S, P1, P1 + nc * ld, ws.red) : wg_polar_ns<0>(nc, S, P1, P1 + nc * ld, ws.red);
             if (res) {
                 for (int e = threadIdx.x; e < nc * nc; e += blockDim.x) Wout[e] = res[(e / nc) * ld + (e % nc)];
                 return;
@@ -5560,12 +5587,13 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
     if (use_lds) { S = sm_tail + jac_ws_doubles(nc, nt); Zt = S + nc * (nc | 1); }
     const double* GX = GX_gp; const double* gp = GX_gp + nc * nc;
     const double pinv = 1.0 / n_total;
-    const int ldl = nc | 1;
+    const int ldl = polar_ld(nc);
+    double* const P1 = S + nc * ldl;   // (the polar iteration's own carving of the matrices' space)
     double* Wl = nullptr;        // LDS copy of W (fast path): one global read of W, none of W1
     const double* res = nullptr; // LDS result of the polar iteration
     if constexpr (MB > 0) {
         if (mode == 0 || nc <= 2) {
-            Wl = Zt + 2 * nc * ldl;
+            Wl = P1 + 2 * nc * ldl;
             // D = GX / n - diag(g') W / n (ica.rs:334-342), straight into LDS; the loads of four trips are in flight together (a
             // load -> LDS-store loop pays a memory round trip per trip: eight in a row at nc = 64)
             for (int e0 = tid; e0 < nc * nc; e0 += 4 * nt) {
@@ -5586,14 +5614,18 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
                 }
             }
             __syncthreads();
-            res = wg_polar_ns(nc, S, Zt, Zt + nc * ldl, ws.red, ortho_tol2);  // ica.rs:343
+            constexpr int NTS = MB <= 4 ? MB : 0;   // (80 / 96 components: the unrolled products spill)
+            res = nc == 16 * NTS ? wg_polar_ns<NTS>(nc, S, P1, P1 + nc * ldl, ws.red, ortho_tol2)
+                                 : wg_polar_ns<0>(nc, S, P1, P1 + nc * ldl, ws.red, ortho_tol2);  // ica.rs:343
         }
     }
     double lim = 0;  // ica.rs:344-354
     if (res) {
-        for (int i = tid; i < nc; i += nt) {
+        // (eight lanes per row: one thread per row walked nc dependent LDS reads, ~4 us at 64 components)
+        for (int i = tid >> 3; i < nc; i += nt >> 3) {
             double dot = 0;
-            for (int j = 0; j < nc; ++j) dot += res[i * ldl + j] * (mode == 1 ? Wl[j * ldl + i] : Wl[i * ldl + j]);  // ica.rs:345-349
+            for (int j = tid & 7; j < nc; j += 8) dot += res[i * ldl + j] * (mode == 1 ? Wl[j * ldl + i] : Wl[i * ldl + j]);  // ica.rs:345-349
+            dot = oct_sum_f64(dot);
             lim = fmax(lim, fabs(fabs(dot) - 1.0));
         }
     } else {
@@ -6746,7 +6778,7 @@ void op_ica_tail(Dev* d, int64_t nc, double n_total, double* W, const double* GX
     // refresh the step kernel's planes of W if the last step used them for this W
     bf16x8* wpk3 = (d->ica_wpk3 && d->ica_wpk3_for == W && d->ica_wpk3_nc == nc) ? (bf16x8*)d->ica_wpk3 : nullptr;
     const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
-    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 4 * nc * (nc | 1) : 0));
+    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 4 * nc * polar_ld((int)nc) : 0));
     MB_DISPATCH(mb, {
         set_max_lds(d, reinterpret_cast<const void*>(k_ica_tail<MBv>));
         hipLaunchKernelGGL(k_ica_tail<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, (int)nc, n_total, W, GX_gp, mode, tol,
@@ -6760,7 +6792,7 @@ void op_symdecorr(Dev* d, int64_t nc, const double* Win, double* Wout, int mode,
     d->ica_wpk3_valid = false;
     double* scratch = (double*)dev_alloc(d, sizeof(double) * (4 * nc * nc + nc));
     const int mb = nc <= 64 ? (int)((nc + 15) / 16) : 0;
-    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 3 * nc * (nc | 1) : 0));
+    const size_t lds = sizeof(double) * (jac_ws_doubles((int)nc, ICA_TAIL_THREADS) + (mb ? 3 * nc * polar_ld((int)nc) : 0));
     MB_DISPATCH(mb, {
         set_max_lds(d, reinterpret_cast<const void*>(k_symdecorr<MBv>));
         hipLaunchKernelGGL(k_symdecorr<MBv>, dim3(1), dim3(ICA_TAIL_THREADS), lds, d->stream, Win, Wout, (int)nc, mode, scratch, zero2);
@@ -7354,21 +7386,32 @@ __global__ __launch_bounds__(512) void k_gram5(const float* __restrict__ X, int6
     if (mi == nj) gram5_body<CENTER, true, SUMS>(sm_g5, X, n, d, ldx, mu, mi, nj, b0, b1, out, so);
     else gram5_body<CENTER, false, SUMS>(sm_g5, X, n, d, ldx, mu, mi, nj, b0, b1, out, so);
 }
-// delta[f] = (sum over the chunks of feature f's diagonal tile of the partial column sums) / n; mu64[f] = mu0[f] + delta[f]; muT = (float) mu64
+// delta[f] = (sum over the chunks of feature f's diagonal tile of the partial column sums) / n; mu64[f] = mu0[f] + delta[f]; muT = (float) mu64.
+// One workgroup per 16 features, sixteen threads per feature (thread p adds the chunks p, p + 16, ...: one thread per feature walked
+// 256 dependent-latency loads, 57 us at d = 256), combined in a fixed order.
 __global__ __launch_bounds__(256) void k_gram5_centre(const float* __restrict__ sums, const int* __restrict__ tile_nch, int ntiles,
                                                       const int* __restrict__ tile_mi, const int* __restrict__ tile_nj, int d, int dp, double n_total,
                                                       double* __restrict__ mu64, float* __restrict__ muT, double* __restrict__ delta) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= dp) return;
+    __shared__ double sp[16][17];
+    const int fl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int f = blockIdx.x * 16 + fl;
     double sacc = 0;
     if (f < d) {
         int tile = -1;
         for (int t = 0; t < ntiles; ++t)
             if (tile_mi[t] == tile_nj[t] && tile_mi[t] == (f >> 8)) tile = t;
         const float* src = sums + (int64_t)tile * 256 + (f & 255);
-        for (int k = 0; k < tile_nch[tile]; ++k) sacc += (double)src[(int64_t)k * ntiles * 256];
+        const int nch = tile_nch[tile];
+#pragma unroll 4
+        for (int k = part; k < nch; k += 16) sacc += (double)src[(int64_t)k * ntiles * 256];
     }
-    const double dl = sacc / n_total;
+    sp[part][fl] = sacc;
+    __syncthreads();
+    if (part != 0 || f >= dp) return;
+    double tot = 0;
+#pragma unroll
+    for (int p2 = 0; p2 < 16; ++p2) tot += sp[p2][fl];
+    const double dl = tot / n_total;
     delta[f] = dl;
     const double m = f < d ? (double)muT[f] + dl : 0.0;
     mu64[f] = m;
@@ -7490,7 +7533,7 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
     }
     HIP_CHECK(hipMemset2DAsync(C, ldc * sizeof(double), 0, dp * sizeof(double), dp, d->stream));
     if (mu64_fold) {
-        hipLaunchKernelGGL(k_gram5_centre, dim3((unsigned)cdiv(dp, 256)), dim3(256), 0, d->stream, sums, tiles_dev + 3 * ntiles, ntiles, tiles_dev,
+        hipLaunchKernelGGL(k_gram5_centre, dim3((unsigned)cdiv(dp, 16)), dim3(256), 0, d->stream, sums, tiles_dev + 3 * ntiles, ntiles, tiles_dev,
                            tiles_dev + ntiles, (int)dd, (int)dp, n_total, mu64_fold, (float*)const_cast<void*>(mu), delta);
         launch_check();
     }
