@@ -5376,7 +5376,16 @@ __host__ __device__ constexpr int polar_ld(int nc) { return (nc & 15) ? (nc | 1)
 // NTC: the number of 16-wide tiles per side when it is known at compile time (nc = 16 NTC: the products' k loops unroll completely and
 // a tile's operand reads are all in flight before its first MFMA -- a 4-deep unroll exposed the LDS latency four times per tile), 0 otherwise.
 template <int NTC>
-__device__ double* wg_polar_ns(int nc_rt, double* X, double* T, double* Y, double* s_red, double tol2 = 1e-26) {
+__device__ double* wg_polar_ns(int nc_rt, double* X_, double* T_, double* Y_, double* s_red_, double tol2 = 1e-26) {
+    // The four buffers are LDS.  Through generic pointers -- this function is not inlined into its callers -- every access was a FLAT
+    // instruction (165 of them at nc = 64, each waiting on vmcnt AND lgkmcnt; the products looked like LDS-latency chains whatever was
+    // done to them): the address space is stated here.  64 components: 48.8 -> 32.7 us per FastICA iteration's tail.
+    typedef __attribute__((address_space(3))) double lds_f64;
+    typedef __attribute__((address_space(3))) float lds_f32;
+    lds_f64* X = (lds_f64*)X_;
+    lds_f64* T = (lds_f64*)T_;
+    lds_f64* Y = (lds_f64*)Y_;
+    lds_f64* const s_red = (lds_f64*)s_red_;
     const int nc = NTC ? 16 * NTC : nc_rt;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
     const int ld = polar_ld(nc);
@@ -5389,7 +5398,7 @@ __device__ double* wg_polar_ns(int nc_rt, double* X, double* T, double* Y, doubl
     int sum_slot = 0;
     auto block_sum = [&](double v) {
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        double* slot = s_red + 16 * sum_slot;
+        lds_f64* slot = s_red + 16 * sum_slot;
         sum_slot ^= 1;
         if (lane == 0) slot[wv] = v;
         __syncthreads();
@@ -5425,8 +5434,8 @@ __device__ double* wg_polar_ns(int nc_rt, double* X, double* T, double* Y, doubl
             // C/D: reg r of lane l is row (l >> 4) + 4 r, column l & 15
             for (int tile = wv; tile < ntile * ntile; tile += nw) {
                 const int ti = tile / ntile, tj = tile - ti * ntile;
-                const double* pa = X + (16 * ti + (lane & 15)) * ld + (lane >> 4);
-                const double* pb = X + (16 * tj + (lane & 15)) * ld + (lane >> 4);
+                const lds_f64* pa = X + (16 * ti + (lane & 15)) * ld + (lane >> 4);
+                const lds_f64* pb = X + (16 * tj + (lane & 15)) * ld + (lane >> 4);
                 f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
                 if constexpr (NTC > 0) {
 #pragma unroll
@@ -5473,7 +5482,7 @@ __device__ double* wg_polar_ns(int nc_rt, double* X, double* T, double* Y, doubl
         // over T and a barrier per step -- would only reproduce a ~ 1, g ~ 1.
         double ca = 1.5, cb = 0.5;
         if (terr > 0.09) {
-        float* s_rs = reinterpret_cast<float*>(s_red + 64);
+        lds_f32* s_rs = (lds_f32*)(s_red + 64);
         for (int row = tid >> 3; row < nc; row += nt >> 3) {
             float rs = 0.f;
             for (int j = tid & 7; j < nc; j += 8) rs += (float)fabs(T[row * ld + j]);
@@ -5513,8 +5522,8 @@ __device__ double* wg_polar_ns(int nc_rt, double* X, double* T, double* Y, doubl
             // Y = ca X - cb T X: A[i][k] = T[16 ti + i][k], B[k][j] = X[k][16 tj + j]
             for (int tile = wv; tile < ntile * ntile; tile += nw) {
                 const int ti = tile / ntile, tj = tile - ti * ntile;
-                const double* pa = T + (16 * ti + (lane & 15)) * ld + (lane >> 4);
-                const double* pb = X + (lane >> 4) * ld + 16 * tj + (lane & 15);
+                const lds_f64* pa = T + (16 * ti + (lane & 15)) * ld + (lane >> 4);
+                const lds_f64* pb = X + (lane >> 4) * ld + 16 * tj + (lane & 15);
                 f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
                 if constexpr (NTC > 0) {
 #pragma unroll
@@ -5538,9 +5547,9 @@ __device__ double* wg_polar_ns(int nc_rt, double* X, double* T, double* Y, doubl
             }
         }
         __syncthreads();
-        double* sw = X; X = Y; Y = sw;
+        lds_f64* sw = X; X = Y; Y = sw;
     }
-    return ok ? X : nullptr;
+    return ok ? (double*)X : nullptr;
 }
 
 constexpr int ICA_TAIL_THREADS = 512;
@@ -5619,12 +5628,15 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
                                  : wg_polar_ns<0>(nc, S, P1, P1 + nc * ldl, ws.red, ortho_tol2);  // ica.rs:343
         }
     }
+    typedef __attribute__((address_space(3))) double lds_f64;   // (the polar factor and the copy of W are LDS: no FLAT accesses)
+    const lds_f64* const resl = (const lds_f64*)res;
+    const lds_f64* const Wll = (const lds_f64*)Wl;
     double lim = 0;  // ica.rs:344-354
     if (res) {
         // (eight lanes per row: one thread per row walked nc dependent LDS reads, ~4 us at 64 components)
         for (int i = tid >> 3; i < nc; i += nt >> 3) {
             double dot = 0;
-            for (int j = tid & 7; j < nc; j += 8) dot += res[i * ldl + j] * (mode == 1 ? Wl[j * ldl + i] : Wl[i * ldl + j]);  // ica.rs:345-349
+            for (int j = tid & 7; j < nc; j += 8) dot += resl[i * ldl + j] * (mode == 1 ? Wll[j * ldl + i] : Wll[i * ldl + j]);  // ica.rs:345-349
             dot = oct_sum_f64(dot);
             lim = fmax(lim, fabs(fabs(dot) - 1.0));
         }
@@ -5648,7 +5660,7 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
     double tl = 0;
     for (int w = 0; w < (nt >> 6); ++w) tl = fmax(tl, ws.red[w]);
     if (done) return;                                             // (uniform)
-    if (res) { for (int e = tid; e < nc * nc; e += nt) W[e] = res[(e / nc) * ldl + (e % nc)]; }
+    if (res) { for (int e = tid; e < nc * nc; e += nt) W[e] = resl[(e / nc) * ldl + (e % nc)]; }
     else { for (int e = tid; e < nc * nc; e += nt) W[e] = W1[e]; }
     if (wpk3) {  // the next step kernel's operand planes (k_pack_w3's layout), straight from the new W
         const int NT = (nc + 15) >> 4, KCH = (16 * NT + 31) >> 5;
@@ -5658,7 +5670,7 @@ __global__ __launch_bounds__(ICA_TAIL_THREADS) void k_ica_tail(int nc, double n_
             f32x8 x;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                x[e] = (comp < nc && k0 + e < nc) ? (float)(res ? res[comp * ldl + k0 + e] : W1[comp * nc + k0 + e]) : 0.f;
+                x[e] = (comp < nc && k0 + e < nc) ? (float)(res ? resl[comp * ldl + k0 + e] : W1[comp * nc + k0 + e]) : 0.f;
             bf16x8 h, m, l;
             split3(x, h, m, l);
             wpk3[(tile * 3 + 0) * 64 + lane] = h;
