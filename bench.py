@@ -728,6 +728,28 @@ def bench_fastica(args, cfg, petal, ctx, torch, dist, dev, rank, world, collecti
         elapsed = float(t.item())
     avg = step_ms / max(step_cnt, 1)
     tf = st["ica_step_flops"] / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+    if args.gemm == "fp32":
+        roofline = {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
+                    "traffic": None, "kernel": "K7 fused FastICA step (fp32 MFMA)", "avg_launch_ms": round(avg, 5),
+                    "flops_per_launch": st["ica_step_flops"], "bytes_per_launch": st["ica_step_bytes"]}
+    else:
+        # split-product step on pre-split planes (k_ica3p): both products form six bf16 piece products per fp32 product, and X1 is read
+        # as three bf16 planes (6 B per value where the fp32 data had 4): priced like K1 - K3, against whichever roof gives the larger floor
+        ncp = -(-nc // 16) * 16
+        plane_bytes = 6.0 * ncp * n
+        floors = {"hbm": plane_bytes / (HBM_PEAK_GBS * 1e9), "mfma-bf16": 6.0 * st["ica_step_flops"] / (BF16_MFMA_PEAK_TF * 1e12)}
+        pipe = max(floors, key=floors.get)
+        common = {"pipe": pipe, "candidate_floors_us": {k: round(v * 1e6, 2) for k, v in floors.items()}, "traffic": None,
+                  "kernel": "K7 fused FastICA step on pre-split planes, k_ica3p (bf16x3 split-product, fp32 accumulate)", "piece_products": 6,
+                  "avg_launch_ms": round(avg, 5), "flops_per_launch": st["ica_step_flops"], "bytes_per_launch": plane_bytes,
+                  "fp32_equivalent_TFLOP/s": round(tf, 3),
+                  "note": "the step kernel is 10 launches of a fit whose largest single launch is the split-product Gram kernel k_gram5 (timelines in profiles/)"}
+        if pipe == "hbm":
+            gbs = plane_bytes / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+            roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **common}
+        else:
+            btf = 6.0 * tf
+            roofline = {"bound": "mfma", "achieved": round(btf, 2), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(btf / BF16_MFMA_PEAK_TF, 4), **common}
     return {
         "metric": "samples/sec for FastIca.fit() on n x d fp32", "value": round(world * n * args.steps / elapsed, 1),
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -737,9 +759,7 @@ def bench_fastica(args, cfg, petal, ctx, torch, dist, dev, rank, world, collecti
                                f"in HBM, {m.n_iter} iterations", "rows_per_gpu": n, "features": d, "n_components": nc,
                    "n_iter": m.n_iter, "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU",
                    "collective": collective},
-        "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "traffic": None, "kernel": "K7 fused FastICA step (fp32-equivalent flops)",
-                     "avg_launch_ms": round(avg, 5), "flops_per_launch": st["ica_step_flops"], "bytes_per_launch": st["ica_step_bytes"]},
+        "roofline": roofline,
     }
 
 

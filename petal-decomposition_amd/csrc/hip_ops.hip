@@ -7321,7 +7321,10 @@ __device__ __forceinline__ void gram5_body(unsigned char* sm_g5, const float* __
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (wm + 2 * a <= wn + 4 * c) mfma6(acc[a][c], ah, am, al, bh[c], bm[c], bl[c]);   // (uniform: sub-tiles below the diagonal are skipped)
-                if (a == park_at && more) {
+#ifndef PETAL_G5_NOPARK   // (timing experiment: the MFMA / LDS-read structure alone, on stale planes)
+#define PETAL_G5_NOPARK 0
+#endif
+                if (a == park_at && more && !PETAL_G5_NOPARK) {
                     __builtin_amdgcn_sched_barrier(0);
                     // (... and the raw registers go straight back into flight for the stage after it: a whole stage of slack for HBM)
                     park(rawA, mi, muA, sAn, b + 1, true);
