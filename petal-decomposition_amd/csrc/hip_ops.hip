@@ -7214,6 +7214,9 @@ __global__ __launch_bounds__(512) void k_gram4(const bf16x8* __restrict__ Xpl, i
 // fragments), and of its 256 16 x 16 sub-tiles only the 136 that reach the upper triangle are computed: the sub-tiles are dealt out
 // CYCLICALLY (wave (wm, wn): row tiles wm + 2 a, column tiles wn + 4 c) and the waves paired on the SIMDs so that every SIMD gets
 // 32 - 36 of them (contiguous 128 x 64 blocks would leave one SIMD with 58 of its 64 and two waves with nothing).
+#ifndef PETAL_G5_NOPARK   // (timing experiment, never a product build: the diagonal tiles' MFMA / LDS-read structure alone, on stale planes --
+#define PETAL_G5_NOPARK 0  //  200000 x 256: 70.5 against 90.7 us, i.e. fetch + split + park cost 22 % and the rest runs at 0.53 of the matrix pipe)
+#endif
 // SUMS (tiles on the diagonal of a fit whose `mu` is only a provisional centre mu0, the means of a row sample): the column sums of
 // X - mu0 over the chunk come out beside the tile (every 256-feature panel is the A panel of exactly one diagonal tile), one fp32
 // partial per feature and chunk; k_gram5_centre turns them into delta = sums / n and the true means, and the reduction subtracts
@@ -7321,9 +7324,6 @@ __device__ __forceinline__ void gram5_body(unsigned char* sm_g5, const float* __
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (wm + 2 * a <= wn + 4 * c) mfma6(acc[a][c], ah, am, al, bh[c], bm[c], bl[c]);   // (uniform: sub-tiles below the diagonal are skipped)
-#ifndef PETAL_G5_NOPARK   // (timing experiment: the MFMA / LDS-read structure alone, on stale planes)
-#define PETAL_G5_NOPARK 0
-#endif
                 if (a == park_at && more && !PETAL_G5_NOPARK) {
                     __builtin_amdgcn_sched_barrier(0);
                     // (... and the raw registers go straight back into flight for the stage after it: a whole stage of slack for HBM)
@@ -7415,8 +7415,8 @@ __global__ __launch_bounds__(256) void k_gram5_centre(const float* __restrict__ 
         int tile = -1;
         for (int t = 0; t < ntiles; ++t)
             if (tile_mi[t] == tile_nj[t] && tile_mi[t] == (f >> 8)) tile = t;
-        const float* src = sums + (int64_t)tile * 256 + (f & 255);
-        const int nch = tile_nch[tile];
+        const float* src = sums + (int64_t)max(tile, 0) * 256 + (f & 255);
+        const int nch = tile >= 0 ? tile_nch[tile] : 0;   // (every 256-feature panel below d has its diagonal tile in the list)
 #pragma unroll 4
         for (int k = part; k < nch; k += 16) sacc += (double)src[(int64_t)k * ntiles * 256];
     }
