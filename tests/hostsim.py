@@ -16,6 +16,8 @@ HDRS = [os.path.join(ROOT, "petal-decomposition_amd", "csrc", h) for h in ("ops.
 
 
 def build() -> str:
+    if os.environ.get("PETAL_HOSTSIM_LIBRARY"):   # (a sanitizer build of the same sources: dev/asan_hostsim.sh)
+        return os.environ["PETAL_HOSTSIM_LIBRARY"]
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     newest = max(os.path.getmtime(p) for p in SRCS + HDRS)
     if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
