@@ -1,15 +1,22 @@
 // hip_ops.hip -- gfx950 (MI355X / CDNA4) implementation of the device-operation layer (ops.h).
 //
-// Kernel inventory (DESIGN.md has the roofline of each):
-//   k_xp_mfma     K1  Z = (X - mu) . P        tall-skinny fp32 MFMA (v_mfma_f32_16x16x4_f32); X streamed
-//                                             straight into MFMA A-fragments with 16-B loads, P pre-packed
-//                                             in fragment order; fused centring, bias and sum((X-mu)^2)
-//   k_atb_mfma    K2  C = (A - muA)^T . B     split-K fp32 MFMA over row chunks -> fp32 partial slabs,
-//                                             combined in fp64 by k_reduce_partials (deterministic, no atomics)
-//   k_ica_mfma    K7  fused FastICA step      W.X1 -> tanh -> G.X1^T + sum(1-g^2) per 16-sample tile, S tile
-//                                             never leaves the accumulators
-//   k_chol_inv / k_eigh / k_symdecorr / k_ica_tail   one-workgroup fp64 small-matrix kernels
-//   *_simple      generic (any shape, f32/f64, fp64 accumulate) kernels for small / unaligned / f64 inputs
+// Kernel inventory (DESIGN.md section 4 has the layout and the roofline of each; EXPERIMENTS.md what was tried on it):
+//   split-product kernels (default GEMM mode "bf16x3": every fp32 operand split exactly into three bf16 planes, five or six piece
+//   products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation)
+//     k_xp3        K1  Z = (X - mu) . P        X streamed into A fragments, centred and split in registers, P planes through LDS
+//     k_atb3       K2  Y = (X - mu)^T . Z      row chunks -> fp32 slabs, combined in fp64 in a fixed order (k_sum_parts*)
+//     k_pow3       K3  Y' = Xc^T (Xc P)        the FUSED power iteration: one pass over X, P and Y' in registers, X planes through a
+//                                              swizzled LDS image read back transposed (ds_read_b64_tr_b16); 512 features, l <= 80
+//     k_gram5          C = Xc^T Xc (+ means)   256 x 256 tiles over row chunks, panels fetched in fragment order and split under the
+//                                              MFMAs, upper sub-tiles only (k_gram4 / k_gram3 + k_presplit_t: earlier forms, selectable)
+//     k_ica3p      K7  fused FastICA step      on planes of X1 made once per loop (k_ica_planes); k_ica3: splits X1 every iteration
+//   fp32 MFMA kernels (GEMM mode "fp32": v_mfma_f32_16x16x4_f32): k_xp_mfma / k_xp_pers (K1), k_atb_mfma (K2), k_ica_mfma (K7)
+//   fp64 MFMA kernels (v_mfma_f64_16x16x4_f64): k_xp_f64, k_atb_f64 (K1 / K2 for fp64 data; the precise Gram matrix), k_syrk_f64,
+//     k_trsm_pack, k_dgemm / k_gemm_nn_f64
+//   one-workgroup fp64 small-matrix kernels: k_chol_inv2 (blocked Cholesky + inverse / RT form), k_tridiag_r / k_tridiag_w +
+//     k_trieig_r (symmetric eigenproblem up to order 138), k_jacobi_* (fallbacks and one-sided SVD), k_symdecorr / k_ica_tail
+//     (symmetric decorrelation: scaled Newton-Schulz polar factor in LDS)
+//   *_simple     generic (any shape, f32 / f64, fp64 accumulate) kernels for small / unaligned / f64 inputs
 //
 // wave = 64 lanes everywhere.  MFMA 16x16x4 f32 fragment maps (cdna_hip_programming.md section 3):
 //   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15];
