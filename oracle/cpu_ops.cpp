@@ -499,8 +499,33 @@ bool op_power_pass_applies(Dev* d, int dt, const void*, int64_t n, int64_t K, in
     return !off && dt == F32 && d->gemm_mode == 0 && n >= 64 && K % 16 == 0 && N % 16 == 0 && N <= 80;
 }
 bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
-                   void* Z, int64_t ldz, double* Y, int64_t ldy) {
+                   void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering) {
     if (!op_power_pass_applies(d, dt, X, n, K, ldx, mu, N)) return false;
+    static const bool no_fast = std::getenv("PETAL_NO_POW3_FAST") != nullptr;
+    if (steering && !Z && !no_fast) {
+        // the device's steering pass (k_pow3f): the centred X, the iterate and z each rounded to two bf16 planes
+        std::vector<double> xc(size_t(n) * K), z(size_t(n) * N, 0.0), p2(size_t(K) * N);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t f = 0; f < K; ++f) xc[i * K + f] = two_plane(double(float(centred(X, dt, i * ldx + f, mu, f))));
+        for (int64_t f = 0; f < K; ++f)
+            for (int64_t j = 0; j < N; ++j) p2[f * N + j] = two_plane(P[f * ldp + j]);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t f = 0; f < K; ++f) {
+                const double a = xc[i * K + f];
+                if (a == 0.0) continue;
+                for (int64_t j = 0; j < N; ++j) z[i * N + j] += a * p2[f * N + j];
+            }
+        for (auto& v : z) v = two_plane(double(float(v)));
+        for (int64_t f = 0; f < K; ++f)
+            for (int64_t j = 0; j < N; ++j) Y[f * ldy + j] = 0.0;
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t f = 0; f < K; ++f) {
+                const double a = xc[i * K + f];
+                if (a == 0.0) continue;
+                for (int64_t j = 0; j < N; ++j) Y[f * ldy + j] += a * z[i * N + j];
+            }
+        return true;
+    }
     std::vector<float> ztmp;
     if (!Z) { ztmp.resize(size_t(n) * N); Z = ztmp.data(); ldz = N; }
     op_gemm_xp(d, dt, X, n, K, ldx, mu, P, N, ldp, nullptr, Z, ldz, nullptr, 2);
@@ -518,7 +543,7 @@ bool op_power_pass_means(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
     double ssq = 0;
     for (int64_t i = 0; i < n; ++i)
         for (int64_t f = 0; f < K; ++f) { const double v = centred(X, dt, i * ldx + f, muT, f); sums[f] += v; ssq += v * v; }
-    if (!op_power_pass(d, dt, X, n, K, ldx, muT, P, N, ldp, nullptr, 0, Y, ldy)) return false;
+    if (!op_power_pass(d, dt, X, n, K, ldx, muT, P, N, ldp, nullptr, 0, Y, ldy, false)) return false;
     std::vector<double> t(N, 0.0);
     double q = 0;
     for (int64_t f = 0; f < K; ++f) {
@@ -538,13 +563,13 @@ bool op_power_pass_means(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
 }
 bool op_rebase_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                           int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
-                          double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy) {
+                          double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering) {
     if (!op_power_pass_applies(d, dt, X, n, K, ldx, mu, M) || L == 0 || P_out == nullptr) return false;
     op_chol_inv(d, G, L, ldg, T, ldt, rel_tol, ndead, M);
     op_dgemm(d, false, false, K, M, M, 1.0, A, lda, T, ldt, 0.0, P_out, ldpo);
     for (int64_t k = 0; k < K; ++k)
         for (int64_t j = 0; j < M; ++j) P_out[k * ldpo + j] = two_plane(P_out[k * ldpo + j]);
-    return op_power_pass(d, dt, X, n, K, ldx, mu, P_out, M, ldpo, Z, ldz, Y, ldy);
+    return op_power_pass(d, dt, X, n, K, ldx, mu, P_out, M, ldpo, Z, ldz, Y, ldy, steering);
 }
 void op_tail_verdict(Dev*, const double* lam, int64_t L, int64_t k, const double* mu_sq, int64_t dp, int64_t d, double n_total,
                      const double* tv, double eps2, double thr, int* flag2) {

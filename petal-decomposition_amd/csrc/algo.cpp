@@ -647,7 +647,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     }
     if (!have_yp && use_pow && n_iter >= 3 && tv_from_sq) {
         dev_set_tag(c.dev, TAG_POW);
-        have_yp = op_power_pass(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, LP, Yp, LP);   // pca.rs:707 + 711
+        have_yp = op_power_pass(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, LP, Yp, LP, /*steering=*/true);   // pca.rs:707 + 711
         dev_set_tag(c.dev, TAG_NONE);
         if (have_yp) allreduce_f64(c, Yp, dp * LP, PETAL_SUM);
     }
@@ -698,7 +698,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
                 const bool last = it + 1 == n_iter;
                 dev_set_tag(c.dev, TAG_POW);
                 have_yp = op_rebase_power_pass(c.dev, dt, X.p, n, dp, X.ld, muT.p, G, L, LP, 1e-15, ndead, Yp, LP, LP, T.f64(), LP, Y.f64(), LP,
-                                               last ? Z.p : nullptr, LP, Yp, LP);   // pca.rs:714 + 711
+                                               last ? Z.p : nullptr, LP, Yp, LP, /*steering=*/!last);   // pca.rs:714 + 711
                 dev_set_tag(c.dev, TAG_NONE);
                 if (have_yp) allreduce_f64(c, Yp, dp * LP + (last ? 1 : 0), PETAL_SUM);   // (the last one: [ Xc^T Z | sum Xc^2 ])
             }
@@ -788,7 +788,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // (the two-plane verdict, from the spectrum just found)
     if (!robust && !exact && two_plane_applies)
         op_tail_verdict(c.dev, lam, L, std::max<int64_t>(k, 1), (tv_from_sq && !tv_direct) ? mu64 : nullptr, dp, d, ri.n_total,
-                        tv_direct ? mu64 + dp : tvp, 4e-6, p2_thr, ndead);
+                        tv_direct ? mu64 + dp : tvp, use_pow ? 4e-6 * 1.7320508 : 4e-6, p2_thr, ndead);   // (steering passes round P, Xc and z: three sources)
     // rows of V^T: v_j = B^T u_j / sigma_j, sigma_j = sqrt(lam_j) (the host takes the same square roots of lam)
     op_components_out(c.dev, dt, Bt.f64(), LP, Uh.f64(), LP, lam, dt == F32 ? 1e-7 : 1e-12, d, L, k, comp_dev);
 

@@ -2248,6 +2248,218 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
 #undef POW3_LANE
 }
 
+// ---- k_pow3f: the fused pass for the INTERMEDIATE power iterations (late round 5).  A pass whose result only steers the iteration --
+// every pass but the last one of a fit, whose Y' and Z become B and Q -- may round its operands like the iterate already is: X (after
+// centring) and z to 16 significant bits, two bf16 planes each.  That is a perturbation of the same kind and size as the two-plane P
+// (numpy model dev/x2_model.py: component errors against the oracle 1.1e-7 -> 3.8e-7 on planted spectra, unchanged on the slowly decaying
+// ones, where the spectral verdict sends the fit to the exact pipeline anyway), and it changes the kernel's budget: FOUR piece
+// products per tile in both products instead of five and six (160 MFMAs per wave and stage instead of 220), a third less split work, an
+// X image of 64 KB instead of 96 -- which leaves room for the partial z of BOTH 16-row halves (80 KB), so a stage has TWO barriers
+// instead of four: product 1 of both halves, park, barrier, add + publish z, barrier, product 2.
+#define POW3_LANE(ln) int ln = threadIdx.x & 63; asm volatile("" : "+v"(ln))
+__device__ __forceinline__ void split2(const f32x8 x, bf16x8& h, bf16x8& m) {
+    u32x4 hh, mm;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float r0 = x[2 * e], r1 = x[2 * e + 1];
+        hh[e] = cvt_pk_bf16(r0, r1);
+        sub_pk_bf16(r0, r1, hh[e]);
+        mm[e] = cvt_pk_bf16(r0, r1);
+    }
+    h = __builtin_bit_cast(bf16x8, hh);
+    m = __builtin_bit_cast(bf16x8, mm);
+}
+template <int NT, bool CENTER>
+__global__ __launch_bounds__(512) void k_pow3f(const float* __restrict__ X, int64_t n, int64_t ldx, const float* __restrict__ mu,
+                                               const bf16x8* __restrict__ Ppk3, int NTtot, float* __restrict__ part, int64_t nstages) {
+    constexpr int WV = 8, K = 512, XIMG = 2 * 32 * 128;          // bytes of one wave's two-plane image
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_pow3[];
+    unsigned char* const sX = sm_pow3;                                           // [WV][2][32][128 B]
+    f32x4* const sZp = reinterpret_cast<f32x4*>(sm_pow3 + WV * XIMG);            // [2][WV][NT][64]
+    bf16x8* const sZB = reinterpret_cast<bf16x8*>(sm_pow3 + WV * XIMG + 2 * WV * NT * 1024);   // [NT][2][64]
+    float* const sMu = reinterpret_cast<float*>(sm_pow3 + WV * XIMG + 2 * WV * NT * 1024 + NT * 2048);   // [K]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (CENTER)
+        for (int k = threadIdx.x; k < K; k += 64 * WV) sMu[k] = mu[k];
+    bf16x8 ph[2][NT], pm[2][NT];
+    {
+        POW3_LANE(ln);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const bf16x8* src = Ppk3 + (((int64_t)(2 * wave + c) * NTtot + u) * 3) * 64 + ln;
+                ph[c][u] = src[0];
+                pm[c][u] = src[64];
+            }
+    }
+    f32x4 acc2[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc2[m][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t s0 = (int64_t)blockIdx.x * nstages / gridDim.x, s1 = (int64_t)(blockIdx.x + 1) * nstages / gridDim.x;
+    f32x8 xa[2][2];
+    auto load_x = [&](int64_t s) {
+        POW3_LANE(ln);
+        const int li = ln & 15, lq = ln >> 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t r = min(s * 32 + 16 * t + li, n - 1);   // rows beyond n: the last row (finite); their z is zeroed below
+            const float* p = X + r * ldx + 64 * wave + 8 * lq;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f32x4 lo = ld_stream(p + 32 * c), hi = ld_stream(p + 32 * c + 4);
+                xa[t][c] = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        }
+    };
+    if (s0 < s1) load_x(s0);
+    unsigned char* const myX = sX + wave * XIMG;
+    auto prod1 = [&](f32x4(&acc1)[NT], int h) {
+        POW3_LANE(ln);
+        const int li = ln & 15, lq = ln >> 4;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const unsigned char* a = myX + pow3_xoff(16 * h + li, 4 * c + lq);
+            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(a), xm = *reinterpret_cast<const bf16x8*>(a + 4096);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                f32x4 c4 = acc1[u];
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, pm[c][u], c4, 0, 0, 0);   // smallest terms first
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, ph[c][u], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, pm[c][u], c4, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, ph[c][u], c4, 0, 0, 0);
+                acc1[u] = c4;
+            }
+        }
+    };
+    auto park_partials = [&](const f32x4(&acc1)[NT], int h) {
+        POW3_LANE(ln);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) sZp[((h * WV + wave) * NT + u) * 64 + ln] = acc1[u];
+    };
+    auto add_partials = [&](int h) {     // wave u < NT adds the eight partials of column tile u (fixed order)
+        POW3_LANE(ln);
+        f32x4 zs = sZp[((h * WV + 0) * NT + wave) * 64 + ln];
+#pragma unroll
+        for (int w = 1; w < WV; ++w) zs += sZp[((h * WV + w) * NT + wave) * 64 + ln];
+        return zs;
+    };
+    auto split_park = [&](int c) {
+        POW3_LANE(ln);
+        const int li = ln & 15, lq = ln >> 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x8 x = xa[t][c];
+            if (CENTER) {
+                const float* mp = sMu + 64 * wave + 32 * c + 8 * lq;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(mp), hi = *reinterpret_cast<const f32x4*>(mp + 4);
+                x -= f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            bf16x8 xh, xm;
+            split2(x, xh, xm);
+            unsigned char* a = myX + pow3_xoff(16 * t + li, 4 * c + lq);
+            *reinterpret_cast<bf16x8*>(a) = xh;
+            *reinterpret_cast<bf16x8*>(a + 4096) = xm;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    __syncthreads();   // mu
+    if (s0 < s1) {
+        split_park(0);
+        split_park(1);
+        if (s0 + 1 < s1) load_x(s0 + 1);
+    }
+    for (int64_t s = s0; s < s1; ++s) {
+        {
+            f32x4 acc1[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            prod1(acc1, 0);
+            park_partials(acc1, 0);              // (ordered behind the previous stage's adders by that stage's second barrier)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            prod1(acc1, 1);
+            park_partials(acc1, 1);
+        }
+        __syncthreads();
+        if (wave < NT) {
+            POW3_LANE(ln);
+            const int lq = ln >> 4;
+            const int64_t rb = s * 32 + 4 * lq;
+            f32x8 z8;
+            {
+                const f32x4 zlo = add_partials(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z8[r] = rb + r < n ? zlo[r] : 0.f;
+            }
+            {
+                const f32x4 zhi = add_partials(1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z8[4 + r] = rb + 16 + r < n ? zhi[r] : 0.f;
+            }
+            bf16x8 zh, zm;
+            split2(z8, zh, zm);
+            sZB[(wave * 2 + 0) * 64 + ln] = zh;
+            sZB[(wave * 2 + 1) * 64 + ln] = zm;
+        }
+        __syncthreads();                         // the z fragments of this stage are published
+        {
+            POW3_LANE(ln);
+            const int trq = (ln >> 2) & 3, trp = ln & 3, lq = ln >> 4;
+            auto mfma_pair = [&](const bf16x8(&ax)[2][2], int mp) {
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 zh = sZB[(u * 2 + 0) * 64 + ln], zm = sZB[(u * 2 + 1) * 64 + ln];
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) {
+                        f32x4 c4 = acc2[2 * mp + mm][u];
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][1], zm, c4, 0, 0, 0);   // smallest terms first
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][1], zh, c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][0], zm, c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][0], zh, c4, 0, 0, 0);
+                        acc2[2 * mp + mm][u] = c4;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+#pragma unroll
+            for (int mp = 0; mp < 2; ++mp) {
+                bf16x8 ax[2][2];
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    const unsigned char* a0 = myX + pow3_xoff(4 * lq + trq, 2 * (2 * mp + mm) + (trp >> 1)) + 8 * (trp & 1);
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) ax[mm][pl] = lds_tr2(a0 + pl * 4096, a0 + pl * 4096 + 2048);
+                }
+                if (s + 1 < s1) {                // this half of the image has been read for the last time: the next stage's pieces
+                    __builtin_amdgcn_sched_barrier(0);
+                    split_park(mp);
+                }
+                mfma_pair(ax, mp);
+            }
+        }
+        if (s + 2 < s1) load_x(s + 2);
+    }
+    // this workgroup's slab: D[row = 4 q + r][col = i] of tile (m, u) is Y'[64 wave + 16 m + 4 q + r][16 u + i]
+    {
+        POW3_LANE(ln);
+        const int li = ln & 15, lq = ln >> 4;
+        float* out = part + (int64_t)blockIdx.x * K * (16 * NT);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* row = out + (int64_t)(64 * wave + 16 * m + 4 * lq + r) * (16 * NT);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) row[16 * u + li] = acc2[m][u][r];
+            }
+    }
+#undef POW3_LANE
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2p: the `precise` form of C = (A - muA)^T (B - muB): every product and the whole accumulation in fp64 on
 // v_mfma_f64_16x16x4_f64 (exact Pca and FastICA whitening need the small eigenvalues of the Gram matrix, which an fp32
@@ -7587,9 +7799,42 @@ bool op_power_pass_applies(Dev* d, int dt, const void* X, int64_t n, int64_t K, 
 // Ppk3: the packed planes of the K x N small operand (k_pack_p3's layout; planes 0 and 1 are read)
 // ssq_parts_out (nullable; needs mu and no Z): the MEANS form -- mu is a provisional centre, Y's last column comes back as the column
 // sums about it and *ssq_parts_out as a device array of *nparts_out partials of sum (x - mu)^2 (see k_pow3)
+// `steering`: the pass only steers the iteration (not the last one of a fit): it may take the four-piece kernel k_pow3f
 static void launch_pow3(Dev* d, const float* X, int64_t n, int64_t ldx, const float* mu, const bf16x8* Ppk3, int64_t N, float* Z, int64_t ldz,
-                        double* Y, int64_t ldy, double** ssq_parts_out = nullptr, int* nparts_out = nullptr) {
+                        double* Y, int64_t ldy, double** ssq_parts_out = nullptr, int* nparts_out = nullptr, bool steering = false) {
     const bool ssq_out = ssq_parts_out != nullptr;
+    static const bool no_fast = getenv("PETAL_NO_POW3_FAST") != nullptr;
+    if (steering && !no_fast && !Z && !ssq_out) {
+        const int NT = (int)(N / 16);
+        const int64_t nstages = cdiv(n, 32);
+        const int grid = (int)std::min<int64_t>(num_cus(d), nstages);
+        float* part = (float*)dev_alloc(d, sizeof(float) * (size_t)grid * 512 * N);
+        const size_t lds = (size_t)8 * 8192 + (size_t)2 * 8 * NT * 1024 + (size_t)NT * 2048 + 2048;
+#define POW3F_GO(NTv, CE)                                                                                                          \
+    do {                                                                                                                           \
+        set_max_lds(d, reinterpret_cast<const void*>(k_pow3f<NTv, CE>));                                                           \
+        hipLaunchKernelGGL((k_pow3f<NTv, CE>), dim3(grid), dim3(512), lds, d->stream, X, n, ldx, mu, Ppk3, NT, part, nstages);      \
+    } while (0)
+#define POW3F_NT(NTv) do { if (mu) POW3F_GO(NTv, true); else POW3F_GO(NTv, false); } while (0)
+        {
+            TagScope ts(d);
+            switch (NT) {
+                case 5: POW3F_NT(5); break;
+                case 4: POW3F_NT(4); break;
+                case 3: POW3F_NT(3); break;
+                case 2: POW3F_NT(2); break;
+                default: POW3F_NT(1); break;
+            }
+            launch_check();
+            ts.stop();
+        }
+#undef POW3F_NT
+#undef POW3F_GO
+        hipLaunchKernelGGL(k_sum_parts4, dim3(cdiv(512 * N, 128)), dim3(256), 0, d->stream, part, (int64_t)grid, (int64_t)512 * N, Y, N, ldy);
+        launch_check();
+        dev_free(d, part);
+        return;
+    }
     const int NT = (int)(N / 16);
     const int64_t nstages = cdiv(n, 32);
     const int grid = (int)std::min<int64_t>(num_cus(d), nstages);
@@ -7706,20 +7951,20 @@ bool op_power_pass_means(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
     return true;
 }
 bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
-                   void* Z, int64_t ldz, double* Y, int64_t ldy) {
+                   void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering) {
     static const bool knob = pow3_knob_off("PETAL_NO_P2_OMEGA");
     if (knob || !pow3_ok(d, dt, X, n, K, ldx, mu, N, Z, ldz)) return false;
     const int64_t total = (K / 32) * (N / 16) * 64;
     bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
     hipLaunchKernelGGL(k_pack_p3, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk3, (int)(N / 16), total);
     launch_check();
-    launch_pow3(d, (const float*)X, n, ldx, (const float*)mu, Ppk3, N, (float*)Z, ldz, Y, ldy);
+    launch_pow3(d, (const float*)X, n, ldx, (const float*)mu, Ppk3, N, (float*)Z, ldz, Y, ldy, nullptr, nullptr, steering && Z == nullptr);
     dev_free(d, Ppk3);
     return true;
 }
 bool op_rebase_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                           int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
-                          double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy) {
+                          double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering) {
     static const bool no_rt = getenv("PETAL_NO_TRSM") != nullptr || pow3_knob_off("PETAL_NO_P2_ITERATE");
     if (!pow3_ok(d, dt, X, n, K, ldx, mu, M, Z, ldz) || no_rt || L == 0 || L > CHOL2_MAXL || M > TRSM_MAXM || M < L || P_out == nullptr) return false;
     set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
@@ -7740,7 +7985,7 @@ bool op_rebase_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, i
         default: throw std::runtime_error("op_rebase_power_pass: order out of range");
     }
     launch_check();
-    launch_pow3(d, (const float*)X, n, ldx, (const float*)mu, Ppk3, M, (float*)Z, ldz, Y, ldy);
+    launch_pow3(d, (const float*)X, n, ldx, (const float*)mu, Ppk3, M, (float*)Z, ldz, Y, ldy, nullptr, nullptr, steering && Z == nullptr);
     dev_free(d, Ppk3);
     return true;
 }

@@ -117,8 +117,11 @@ void op_rebase_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t 
 // with P rounded to the sum of its two leading bf16 pieces (a caller that needs P to fp32 accuracy uses op_gemm_xp + op_gemm_atb).
 // Returns false, NOTHING done, where no fused kernel exists for the shape / mode (op_power_pass_applies says so up front).
 bool op_power_pass_applies(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N);
+// steering: the pass only STEERS a power iteration (its Y feeds the next re-basing, nothing else; Z == NULL): the kernel may then also
+// round Xc and z to two bf16 planes -- four piece products per tile in both products, two barriers per stage (k_pow3f).  The caller
+// owns the consequences: rpca_fit runs such passes on its optimistic path only, under the spectral verdict.
 bool op_power_pass(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
-                   void* Z, int64_t ldz, double* Y, int64_t ldy);
+                   void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering = false);
 // The FIRST fused pass of a fit with the means pass folded in (single rank, fp32, centring; L < N: a padding column is free):
 // mu64 / muT come back as the column means of X (d real columns of K), *tv as sum (X - mean)^2, and Y = Xc^T (Xc P) about that
 // mean -- X is read once, not twice: the kernel centres about the means of a row SAMPLE, gathers the exact column sums and the sum
@@ -129,7 +132,7 @@ bool op_power_pass_means(Dev*, int dtype, const void* X, int64_t n, int64_t K, i
 // the same behind one re-basing step (arguments as op_rebase_xp, p_planes = 2): P_out = A R^-1 rounded, then the fused pass with it
 bool op_rebase_power_pass(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                           int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
-                          double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy);
+                          double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering = false);
 // Was a 16-bit (two-plane) rounding of the sketch matrix and of the re-based iterates harmless for the spectrum this fit found?
 // A rounding E of the basis P (|E_ij| <= eps2 |P_ij|) reaches the next iterate as C E, C = Xc^T Xc: directions the block already
 // spans are harmless, the part from BEYOND the block -- sum_{i > L} sigma_i^2 v_i (v_i^T E), of size eps2 T with
