@@ -311,7 +311,8 @@ def main():
         # (level-1 profiling samples ONE launch per fit, the kind rotating: the SUMS over a few steps say which kind was sampled
         # more often, not which is slower.  The dominant kernel is the kind a fit spends most of its time in: the fused pass where
         # it runs -- n_iter + 1 launches per fit, K1 / K2 then do not run in the loop at all -- else the longer of K1 / K2)
-        kinds = kind_table(n, d, l, args.gemm, two_plane=(redo == 0 and n_iter > 0))
+        steer = steering_passes(n, d, l, n_iter, args.gemm, redo, world)
+        kinds = kind_table(n, d, l, args.gemm, two_plane=(redo == 0 and n_iter > 0), k3_pieces_avg=k3_pieces(n_iter, steer))
         dom = "K3 (Y' = Xc^T.(Xc.P), fused)" if per["K3 (Y' = Xc^T.(Xc.P), fused)"] > 0 else max(per, key=per.get)
         roofline = roofline_entry(dom, per, kinds, args.gemm, args.pmc_traffic, n, d, l)
         out = {
@@ -336,7 +337,7 @@ def main():
                        "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU",
                        "collective": collective, "clock_ramp_s": args.clock_ramp_s},
             "roofline": roofline,
-            "fit_roofline": fit_roofline(n, d, l, n_iter, 4, args.gemm, elapsed / args.steps * 1e3),
+            "fit_roofline": fit_roofline(n, d, l, n_iter, 4, args.gemm, elapsed / args.steps * 1e3, steer),
             "rpca_redo": redo,   # 0: every timed fit stood on its optimistic (two-plane, fused) run
             # what went through the collective per fit (sharded runs; zeros on one GPU).  The stream time is sampled: one
             # bracketed all-reduce per fit, the index rotating from fit to fit -> average call time x calls per fit
@@ -484,16 +485,29 @@ def pass_bound(pass_flops, pass_bytes, mode, pieces=6.0):
     return {"bound": "hbm" if pipe == "hbm" else "mfma", "pipe": pipe, "floor_s": times[pipe], "times_s": times}
 
 
-def kind_table(n, d, l, mode, two_plane):
+def steering_passes(n, d, l, n_iter, mode, redo=0, world=1):
+    """How many of a fit's n_iter + 1 fused passes are STEERING passes (k_pow3f: Xc, z and P on two bf16 planes each, FOUR piece products
+    per tile in both products) -- every fused pass but the last one of the fit, which stores Z and keeps its five / six piece products."""
+    if not (mode == "bf16x3" and d == 512 and l <= 80 and n_iter >= 3 and redo == 0) or os.environ.get("PETAL_NO_POW3_FAST"):
+        return 0
+    return n_iter   # (the first pass too, with or without the means gathered in it)
+
+
+def k3_pieces(n_iter, steering):
+    """bf16 piece products per fp32 product, averaged over the n_iter + 1 fused passes of a fit: 4 in a steering pass, 5.5 in the others"""
+    return (4.0 * steering + 5.5 * (n_iter + 1 - steering)) / (n_iter + 1)
+
+
+def kind_table(n, d, l, mode, two_plane, k3_pieces_avg=5.5):
     """algorithmic work of ONE launch of each kernel kind: (flops, bytes, bf16 piece products per fp32 product)"""
     gemm = (2.0 * n * d * l, 4.0 * (n * d + n * l + d * l))
     return {"K1 (Z = Xc.P)": gemm + (5.0 if two_plane and mode == "bf16x3" else 6.0,),
             "K2 (Y = Xc^T.Z)": gemm + (6.0,),
             # both products of a power iteration in ONE pass: X is read once, Z is neither written nor read
-            "K3 (Y' = Xc^T.(Xc.P), fused)": (4.0 * n * d * l, 4.0 * (n * d + 2 * d * l), 5.5)}
+            "K3 (Y' = Xc^T.(Xc.P), fused)": (4.0 * n * d * l, 4.0 * (n * d + 2 * d * l), k3_pieces_avg)}
 
 
-KERNEL_NAMES = {"K1": "k_xp3", "K2": "k_atb3", "K3": "k_pow3"}
+KERNEL_NAMES = {"K1": "k_xp3", "K2": "k_atb3", "K3": "k_pow3f / k_pow3"}
 
 
 def roofline_entry(dom, per, kinds, mode, traffic_override, n, d, l):
@@ -540,7 +554,7 @@ def roofline_entry(dom, per, kinds, mode, traffic_override, n, d, l):
             "frac": round(tf / FP32_MFMA_PEAK_TF, 4), **common}
 
 
-def fit_roofline(n, d, l, n_iter, esz, mode, ms_per_step):
+def fit_roofline(n, d, l, n_iter, esz, mode, ms_per_step, steering=0):
     """Whole-fit fraction: the algorithmic floor of one RandomizedPca.fit over the measured time per fit.  The floor is that of
     the cheapest pass structure the product has: n_iter + 1 FUSED passes Y' = Xc^T (Xc P) (one read of X each; 5 + 6 bf16 piece
     products) where the fused kernel exists (bf16x3 mode, d = 512, l <= 80), (2 n_iter + 2) separate GEMM passes otherwise --
@@ -548,15 +562,19 @@ def fit_roofline(n, d, l, n_iter, esz, mode, ms_per_step):
     fused = mode == "bf16x3" and d == 512 and l <= 80 and n_iter >= 1
     if fused:
         b = pass_bound(4.0 * n * d * l, float(esz) * (n * d + 2 * d * l), mode, 5.5)
+        bs = pass_bound(4.0 * n * d * l, float(esz) * (n * d + 2 * d * l), mode, 4.0)   # (a steering pass: four piece products)
         passes = n_iter + 1
+        passes_s = (passes - steering) * b["floor_s"] + steering * bs["floor_s"]
     else:
         b = pass_bound(2.0 * n * d * l, float(esz) * (n * d + n * l + d * l), mode)
         passes = 2 * n_iter + 2
+        passes_s = passes * b["floor_s"]
     means_s = esz * n * d / (HBM_PEAK_GBS * 1e9)
     u_s = pass_bound(2.0 * n * l * l, float(esz) * 2 * n * l, mode)["floor_s"]
-    floor_ms = (passes * b["floor_s"] + means_s + u_s) * 1e3
+    floor_ms = (passes_s + means_s + u_s) * 1e3
     return {"floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ms_per_step, 4) if ms_per_step > 0 else 0.0,
-            "passes": passes, "pass_kind": "fused (one read of X per power iteration)" if fused else "K1 + K2",
+            "passes": passes, "steering_passes": steering if fused else 0,
+            "pass_kind": "fused (one read of X per power iteration)" if fused else "K1 + K2",
             "pass_floor_us": round(b["floor_s"] * 1e6, 2), "pass_pipe": b["pipe"],
             "note": "floor = the passes over X at their binding roofline + the means pass + U = Q.Uh; the serial small-matrix "
                     "steps between the passes have no floor of their own here (serial_chain_ms reports them)"}
@@ -693,7 +711,7 @@ def northstar_fit(petal, ctx, torch, dev, gemm, n=1_000_000, d=512, k=64, reps=5
             "ms_per_fit": round(ms, 4), "samples_per_s": round(n / (ms * 1e-3), 1),
             "K1_avg_launch_ms": round(acc["xp_ms"] / max(acc["xp_launches"], 1), 4),
             "K2_avg_launch_ms": round(acc["atb_ms"] / max(acc["atb_launches"], 1), 4),
-            "fit_roofline": fit_roofline(n, d, l, n_iter, 4, gemm, ms)}
+            "fit_roofline": fit_roofline(n, d, l, n_iter, 4, gemm, ms, steering_passes(n, d, l, n_iter, gemm))}
     del x
     torch.cuda.empty_cache()
     return res

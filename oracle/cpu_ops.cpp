@@ -501,7 +501,7 @@ bool op_power_pass_applies(Dev* d, int dt, const void*, int64_t n, int64_t K, in
 bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
                    void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering) {
     if (!op_power_pass_applies(d, dt, X, n, K, ldx, mu, N)) return false;
-    static const bool no_fast = std::getenv("PETAL_NO_POW3_FAST") != nullptr;
+    const bool no_fast = std::getenv("PETAL_NO_POW3_FAST") != nullptr;
     if (steering && !Z && !no_fast) {
         // the device's steering pass (k_pow3f): the centred X, the iterate and z each rounded to two bf16 planes
         std::vector<double> xc(size_t(n) * K), z(size_t(n) * N, 0.0), p2(size_t(K) * N);
@@ -543,7 +543,7 @@ bool op_power_pass_means(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
     double ssq = 0;
     for (int64_t i = 0; i < n; ++i)
         for (int64_t f = 0; f < K; ++f) { const double v = centred(X, dt, i * ldx + f, muT, f); sums[f] += v; ssq += v * v; }
-    if (!op_power_pass(d, dt, X, n, K, ldx, muT, P, N, ldp, nullptr, 0, Y, ldy, false)) return false;
+    if (!op_power_pass(d, dt, X, n, K, ldx, muT, P, N, ldp, nullptr, 0, Y, ldy, /*steering=*/true)) return false;   // (as on the device)
     std::vector<double> t(N, 0.0);
     double q = 0;
     for (int64_t f = 0; f < K; ++f) {

@@ -2257,6 +2257,12 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
 // X image of 64 KB instead of 96 -- which leaves room for the partial z of BOTH 16-row halves (80 KB), so a stage has TWO barriers
 // instead of four: product 1 of both halves, park, barrier, add + publish z, barrier, product 2.
 #define POW3_LANE(ln) int ln = threadIdx.x & 63; asm volatile("" : "+v"(ln))
+#ifndef PETAL_POW3F_ZPF
+#define PETAL_POW3F_ZPF 0
+#endif
+#ifndef PETAL_POW3F_DEPHASE
+#define PETAL_POW3F_DEPHASE 0
+#endif
 __device__ __forceinline__ void split2(const f32x8 x, bf16x8& h, bf16x8& m) {
     u32x4 hh, mm;
 #pragma unroll
@@ -2269,9 +2275,13 @@ __device__ __forceinline__ void split2(const f32x8 x, bf16x8& h, bf16x8& m) {
     h = __builtin_bit_cast(bf16x8, hh);
     m = __builtin_bit_cast(bf16x8, mm);
 }
-template <int NT, bool CENTER>
+// MEANS: as k_pow3's (the first pass of a fit about a provisional centre: the last column of z set to one gathers the column sums, the
+// splits accumulate sum (x - mu0)^2 -- from the values BEFORE their rounding; the sums themselves are those of the 16-bit values, off the
+// exact ones by 2^-17 sigma / sqrt(n) per column: 1e-8 sigma at the 200000 rows the fold starts from).
+template <int NT, bool CENTER, bool MEANS = false>
 __global__ __launch_bounds__(512) void k_pow3f(const float* __restrict__ X, int64_t n, int64_t ldx, const float* __restrict__ mu,
-                                               const bf16x8* __restrict__ Ppk3, int NTtot, float* __restrict__ part, int64_t nstages) {
+                                               const bf16x8* __restrict__ Ppk3, int NTtot, float* __restrict__ part, int64_t nstages,
+                                               double* __restrict__ ssq_part) {
     constexpr int WV = 8, K = 512, XIMG = 2 * 32 * 128;          // bytes of one wave's two-plane image
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_pow3[];
     unsigned char* const sX = sm_pow3;                                           // [WV][2][32][128 B]
@@ -2346,7 +2356,8 @@ __global__ __launch_bounds__(512) void k_pow3f(const float* __restrict__ X, int6
         for (int w = 1; w < WV; ++w) zs += sZp[((h * WV + w) * NT + wave) * 64 + ln];
         return zs;
     };
-    auto split_park = [&](int c) {
+    float ssq = 0.f;
+    auto split_park = [&](int c, int64_t sidx) {
         POW3_LANE(ln);
         const int li = ln & 15, lq = ln >> 4;
 #pragma unroll
@@ -2356,6 +2367,12 @@ __global__ __launch_bounds__(512) void k_pow3f(const float* __restrict__ X, int6
                 const float* mp = sMu + 64 * wave + 32 * c + 8 * lq;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(mp), hi = *reinterpret_cast<const f32x4*>(mp + 4);
                 x -= f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            if (MEANS) {   // sum (x - mu0)^2 over the valid rows (rows beyond n are clamped loads of the last row)
+                float q2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q2 = fmaf(x[e], x[e], q2);
+                ssq += sidx * 32 + 16 * t + li < n ? q2 : 0.f;
             }
             bf16x8 xh, xm;
             split2(x, xh, xm);
@@ -2367,8 +2384,8 @@ __global__ __launch_bounds__(512) void k_pow3f(const float* __restrict__ X, int6
     };
     __syncthreads();   // mu
     if (s0 < s1) {
-        split_park(0);
-        split_park(1);
+        split_park(0, s0);
+        split_park(1, s0);
         if (s0 + 1 < s1) load_x(s0 + 1);
     }
     for (int64_t s = s0; s < s1; ++s) {
@@ -2399,6 +2416,13 @@ __global__ __launch_bounds__(512) void k_pow3f(const float* __restrict__ X, int6
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z8[4 + r] = rb + 16 + r < n ? zhi[r] : 0.f;
             }
+            if (MEANS && wave == NT - 1 && (ln & 15) == 15) {   // the all-ones column: Y'[:, 16 NT - 1] = Xc0^T 1
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z8[r] = rb + r < n ? 1.f : 0.f;
+                    z8[4 + r] = rb + 16 + r < n ? 1.f : 0.f;
+                }
+            }
             bf16x8 zh, zm;
             split2(z8, zh, zm);
             sZB[(wave * 2 + 0) * 64 + ln] = zh;
@@ -2409,10 +2433,20 @@ __global__ __launch_bounds__(512) void k_pow3f(const float* __restrict__ X, int6
             POW3_LANE(ln);
             const int trq = (ln >> 2) & 3, trp = ln & 3, lq = ln >> 4;
             auto mfma_pair = [&](const bf16x8(&ax)[2][2], int mp) {
+#if PETAL_POW3F_ZPF
+                bf16x8 zc[2];
+                zc[0] = sZB[(0 * 2 + 0) * 64 + ln]; zc[1] = sZB[(0 * 2 + 1) * 64 + ln];
+#endif
 #pragma unroll
                 for (int u = 0; u < NT; ++u) {
                     __builtin_amdgcn_sched_barrier(0);
+#if PETAL_POW3F_ZPF
+                    const bf16x8 zh = zc[0], zm = zc[1];
+                    if (u + 1 < NT) { zc[0] = sZB[((u + 1) * 2 + 0) * 64 + ln]; zc[1] = sZB[((u + 1) * 2 + 1) * 64 + ln]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#else
                     const bf16x8 zh = sZB[(u * 2 + 0) * 64 + ln], zm = sZB[(u * 2 + 1) * 64 + ln];
+#endif
 #pragma unroll
                     for (int mm = 0; mm < 2; ++mm) {
                         f32x4 c4 = acc2[2 * mp + mm][u];
@@ -2434,14 +2468,32 @@ __global__ __launch_bounds__(512) void k_pow3f(const float* __restrict__ X, int6
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) ax[mm][pl] = lds_tr2(a0 + pl * 4096, a0 + pl * 4096 + 2048);
                 }
-                if (s + 1 < s1) {                // this half of the image has been read for the last time: the next stage's pieces
+                // this half of the image has been read for the last time: the next stage's pieces go there -- in front of the pair's MFMAs
+                // in one wave of a SIMD, behind them in the other (DEPHASE)
+#if PETAL_POW3F_DEPHASE
+                const bool split_first = wave < 4;
+#else
+                const bool split_first = true;
+#endif
+                if (split_first && s + 1 < s1) {
                     __builtin_amdgcn_sched_barrier(0);
-                    split_park(mp);
+                    split_park(mp, s + 1);
                 }
                 mfma_pair(ax, mp);
+                if (!split_first && s + 1 < s1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    split_park(mp, s + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         if (s + 2 < s1) load_x(s + 2);
+    }
+    if (MEANS) {         // one partial of sum (x - mu0)^2 per wave, lanes added in a fixed order
+        float v = ssq;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) ssq_part[(int64_t)blockIdx.x * WV + wave] = (double)v;
     }
     // this workgroup's slab: D[row = 4 q + r][col = i] of tile (m, u) is Y'[64 wave + 16 m + 4 q + r][16 u + i]
     {
@@ -7803,19 +7855,20 @@ bool op_power_pass_applies(Dev* d, int dt, const void* X, int64_t n, int64_t K, 
 static void launch_pow3(Dev* d, const float* X, int64_t n, int64_t ldx, const float* mu, const bf16x8* Ppk3, int64_t N, float* Z, int64_t ldz,
                         double* Y, int64_t ldy, double** ssq_parts_out = nullptr, int* nparts_out = nullptr, bool steering = false) {
     const bool ssq_out = ssq_parts_out != nullptr;
-    static const bool no_fast = getenv("PETAL_NO_POW3_FAST") != nullptr;
-    if (steering && !no_fast && !Z && !ssq_out) {
+    const bool no_fast = getenv("PETAL_NO_POW3_FAST") != nullptr;   // (read per launch: the tests compare the two forms in one process)
+    if (steering && !no_fast && !Z) {
         const int NT = (int)(N / 16);
         const int64_t nstages = cdiv(n, 32);
         const int grid = (int)std::min<int64_t>(num_cus(d), nstages);
         float* part = (float*)dev_alloc(d, sizeof(float) * (size_t)grid * 512 * N);
+        double* ssq_part = ssq_out ? (double*)dev_alloc(d, sizeof(double) * (size_t)grid * 8) : nullptr;
         const size_t lds = (size_t)8 * 8192 + (size_t)2 * 8 * NT * 1024 + (size_t)NT * 2048 + 2048;
-#define POW3F_GO(NTv, CE)                                                                                                          \
+#define POW3F_GO(NTv, CE, ME)                                                                                                      \
     do {                                                                                                                           \
-        set_max_lds(d, reinterpret_cast<const void*>(k_pow3f<NTv, CE>));                                                           \
-        hipLaunchKernelGGL((k_pow3f<NTv, CE>), dim3(grid), dim3(512), lds, d->stream, X, n, ldx, mu, Ppk3, NT, part, nstages);      \
+        set_max_lds(d, reinterpret_cast<const void*>(k_pow3f<NTv, CE, ME>));                                                       \
+        hipLaunchKernelGGL((k_pow3f<NTv, CE, ME>), dim3(grid), dim3(512), lds, d->stream, X, n, ldx, mu, Ppk3, NT, part, nstages, ssq_part); \
     } while (0)
-#define POW3F_NT(NTv) do { if (mu) POW3F_GO(NTv, true); else POW3F_GO(NTv, false); } while (0)
+#define POW3F_NT(NTv) do { if (ssq_out) POW3F_GO(NTv, true, true); else if (mu) POW3F_GO(NTv, true, false); else POW3F_GO(NTv, false, false); } while (0)
         {
             TagScope ts(d);
             switch (NT) {
@@ -7833,6 +7886,7 @@ static void launch_pow3(Dev* d, const float* X, int64_t n, int64_t ldx, const fl
         hipLaunchKernelGGL(k_sum_parts4, dim3(cdiv(512 * N, 128)), dim3(256), 0, d->stream, part, (int64_t)grid, (int64_t)512 * N, Y, N, ldy);
         launch_check();
         dev_free(d, part);
+        if (ssq_parts_out) { *ssq_parts_out = ssq_part; *nparts_out = grid * 8; }   // (the caller's next kernel adds them; it frees the block)
         return;
     }
     const int NT = (int)(N / 16);
@@ -7938,7 +7992,7 @@ bool op_power_pass_means(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
     launch_check();
     double* parts = nullptr;
     int nparts = 0;
-    launch_pow3(d, (const float*)X, n, ldx, (const float*)muT, Ppk3, N, nullptr, 0, Y, ldy, &parts, &nparts);
+    launch_pow3(d, (const float*)X, n, ldx, (const float*)muT, Ppk3, N, nullptr, 0, Y, ldy, &parts, &nparts, /*steering=*/true);
     dev_free(d, Ppk3);
     (void)ssq_scratch;
     const int c1 = (int)(N - 1);

@@ -444,6 +444,32 @@ def ica_split_gram_case(ctx, n, d, nc):
     assert np.abs(1.0 - c[np.arange(nc), perm]).max() <= 5e-3
 
 
+def steering_pass_case(ctx, monkeypatch, n, d, k, n_iter, spectrum="planted", seed=91, tol=1e-5):
+    """The intermediate power iterations on 16-bit operands (k_pow3f: Xc, z and the iterate on two bf16 planes each; the last pass of the
+    fit keeps its exact products): parity with the oracle as for the five / six-piece passes, the same fit under PETAL_NO_POW3_FAST
+    within the same bar, and different bits -- the steering kernel did run."""
+    x = po.synth_pca(n, d, k, seed=seed, dtype=np.float32) if spectrum == "planted" else slow_decay_matrix(n, d, spectrum, seed)
+    om = np.random.default_rng(seed + 1000).standard_normal((d, k + 10)).astype(np.float32)
+    o = po.RandomizedPcaOracle(k, n_iter=n_iter)
+    o._inner_fit(x.astype(np.float64), omega=om.astype(np.float64))
+    res = []
+    for fast in (True, False):
+        if fast:
+            monkeypatch.delenv("PETAL_NO_POW3_FAST", raising=False)
+        else:
+            monkeypatch.setenv("PETAL_NO_POW3_FAST", "1")
+        m = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter).fit(x, omega=om)
+        c = m.components().astype(np.float64)
+        rel = rowwise_rel(c, o.components)
+        assert rel.max() <= tol, (fast, rel.max())
+        assert np.abs(m.singular_values() / o.singular - 1).max() <= tol
+        res.append((c, ctx.stats()["rpca_redo"]))
+    monkeypatch.delenv("PETAL_NO_POW3_FAST", raising=False)
+    if res[0][1] == 0 and res[1][1] == 0:
+        assert not np.array_equal(res[0][0], res[1][0]), "the steering passes left no trace: k_pow3f did not run"
+    return res[0][1]
+
+
 def ica_means_fold_case(ctx, n, d, nc, offset=40.0):
     """FastICA on data far off centre (|mean| = `offset` standard deviations): the single-rank fp32 fit gathers the column means inside
     the split-product Gram pass about a provisional centre (a row sample's means) and moves to the true centre afterwards.  The

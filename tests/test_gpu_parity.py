@@ -251,6 +251,19 @@ def test_fastica_whitening_from_the_split_product_covariance():
         c.close()
 
 
+def test_steering_passes_on_sixteen_bit_operands(monkeypatch):
+    """(split-product mode) RandomizedPca on the fused pass: every power iteration but the last runs k_pow3f"""
+    import petal_decomposition_amd as petal
+    c = petal.Context(0)
+    try:
+        assert pc.steering_pass_case(c, monkeypatch, 20000, 512, 64, 5) == 0
+        assert pc.steering_pass_case(c, monkeypatch, 33333, 500, 24, 3, seed=92) == 0
+        assert pc.steering_pass_case(c, monkeypatch, 8192, 512, 64, 7, seed=93) == 0
+        pc.steering_pass_case(c, monkeypatch, 20000, 512, 64, 5, spectrum="geo97", seed=94)   # (a redo is allowed here: the verdict's call)
+    finally:
+        c.close()
+
+
 def test_fastica_means_gathered_in_the_gram_pass():
     """(split-product modes only) single-rank fp32 FastICA: no means pass of its own -- the column sums come out of the Gram kernel's
     diagonal tiles about a provisional centre (k_gram5 SUMS, k_gram5_centre), on data 40 sigma off centre; shapes with one and with

@@ -76,6 +76,15 @@ def test_fastica_whitening_from_the_split_product_covariance(ctx):
         ctx.set_gemm_mode("fp32")
 
 
+def test_steering_passes_on_sixteen_bit_operands(ctx, monkeypatch):
+    """the host sequencing of the steering passes (algo.cpp marks every fused pass but the last one) on the simulation's rounding"""
+    ctx.set_gemm_mode("bf16x3")
+    try:
+        assert pc.steering_pass_case(ctx, monkeypatch, 1500, 64, 6, 5, seed=95, tol=2e-5) == 0
+    finally:
+        ctx.set_gemm_mode("fp32")
+
+
 def test_fastica_means_gathered_in_the_gram_pass(ctx, monkeypatch):
     """the host logic of the folded means (algo.cpp: fastica_fit) on the simulation's restatement of the device arithmetic, and the
     separate means pass under PETAL_NO_MEANS_FOLD: same sources"""

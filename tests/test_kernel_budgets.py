@@ -27,6 +27,8 @@ BUDGETS = [
     # stage's X loads -- vmcnt retires in order -- which cost the first build 7300 cycles in a 1300-cycle phase)
     (r"k_pow3<5, (true|false), (true|false), (true|false)>$", 256, 0, "fused power-iteration pass, l = 74 (configs[1], the north-star point)"),
     (r"k_pow3<", 256, 0, "every fused-pass instantiation: no scratch"),
+    (r"k_pow3f<5, (true|false), (true|false)>$", 256, 0, "steering fused pass (four piece products, two barriers per stage), l = 74"),
+    (r"k_pow3f<", 256, 0, "every steering-pass instantiation: no scratch"),
     (r"k_ica3<2>$", 128, 0, "FastICA step, 32 components: 4 waves/SIMD"),
     (r"k_ica3<4>$", 256, 0, "FastICA step, 64 components"),
     (r"k_ica3p<2>$", 128, 0, "FastICA step on pre-split planes, 32 components: 4 waves/SIMD"),
