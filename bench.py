@@ -312,7 +312,8 @@ def main():
         # more often, not which is slower.  The dominant kernel is the kind a fit spends most of its time in: the fused pass where
         # it runs -- n_iter + 1 launches per fit, K1 / K2 then do not run in the loop at all -- else the longer of K1 / K2)
         steer = steering_passes(n, d, l, n_iter, args.gemm, redo, world)
-        kinds = kind_table(n, d, l, args.gemm, two_plane=(redo == 0 and n_iter > 0), k3_pieces_avg=k3_pieces(n_iter, steer))
+        kinds = kind_table(n, d, l, args.gemm, two_plane=(redo == 0 and n_iter > 0), k3_pieces_avg=k3_pieces(n_iter, steer), n_iter=n_iter,
+                           steer12=steering_k12(l, n_iter, args.gemm, redo))
         dom = "K3 (Y' = Xc^T.(Xc.P), fused)" if per["K3 (Y' = Xc^T.(Xc.P), fused)"] > 0 else max(per, key=per.get)
         roofline = roofline_entry(dom, per, kinds, args.gemm, args.pmc_traffic, n, d, l)
         out = {
@@ -498,11 +499,23 @@ def k3_pieces(n_iter, steering):
     return (4.0 * steering + 5.5 * (n_iter + 1 - steering)) / (n_iter + 1)
 
 
-def kind_table(n, d, l, mode, two_plane, k3_pieces_avg=5.5):
-    """algorithmic work of ONE launch of each kernel kind: (flops, bytes, bf16 piece products per fp32 product)"""
+def steering_k12(l, n_iter, mode, redo=0):
+    """Do the K1 / K2 launches of a fit's loop run as STEERING products (four piece products: Xc, Z and P on two bf16 planes each)?  The
+    forms for more than 80 columns do, in every iteration but the last K1 and the final K2 (whose results the fit's outputs are made of)."""
+    return mode == "bf16x3" and l > 80 and n_iter >= 3 and redo == 0 and not os.environ.get("PETAL_NO_POW3_FAST")
+
+
+def kind_table(n, d, l, mode, two_plane, k3_pieces_avg=5.5, n_iter=0, steer12=False):
+    """algorithmic work of ONE launch of each kernel kind: (flops, bytes, bf16 piece products per fp32 product -- averaged over the
+    fit's launches of the kind where steering launches issue four and the last one five or six)"""
     gemm = (2.0 * n * d * l, 4.0 * (n * d + n * l + d * l))
-    return {"K1 (Z = Xc.P)": gemm + (5.0 if two_plane and mode == "bf16x3" else 6.0,),
-            "K2 (Y = Xc^T.Z)": gemm + (6.0,),
+    k1 = 5.0 if two_plane and mode == "bf16x3" else 6.0
+    k2 = 6.0
+    if steer12:
+        k1 = (4.0 * n_iter + k1) / (n_iter + 1)
+        k2 = (4.0 * n_iter + k2) / (n_iter + 1)
+    return {"K1 (Z = Xc.P)": gemm + (k1,),
+            "K2 (Y = Xc^T.Z)": gemm + (k2,),
             # both products of a power iteration in ONE pass: X is read once, Z is neither written nor read
             "K3 (Y' = Xc^T.(Xc.P), fused)": (4.0 * n * d * l, 4.0 * (n * d + 2 * d * l), k3_pieces_avg)}
 

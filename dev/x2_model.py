@@ -48,9 +48,22 @@ def fit(x, om, k, n_iter, mode):
     return vt[:k], s[:k]
 
 rng = np.random.default_rng(0)
-for (n, d, k, n_iter, kind) in ((20000, 512, 64, 5, "planted"), (20000, 512, 64, 3, "planted"), (20000, 512, 64, 5, "geo97"), (20000, 512, 64, 5, "rsqrt"),
-                                (100000, 512, 64, 5, "planted")):
-    x = po.synth_pca(n, d, k, seed=7, dtype=np.float32) if kind == "planted" else pc.slow_decay_matrix(n, d, kind, 7)
+def make(n, d, k, kind):
+    if kind == "planted": return po.synth_pca(n, d, k, seed=7, dtype=np.float32)
+    if kind in ("geo97", "rsqrt"): return pc.slow_decay_matrix(n, d, kind, 7)
+    r = np.random.default_rng(7)
+    m = min(n, d)
+    if kind.startswith("geo"):
+        sv = float(kind[3:]) ** np.arange(m)
+    else:   # "noiseX": k planted values 1 .. 0.1 on a flat floor X
+        fl = float(kind[5:])
+        sv = np.concatenate([np.linspace(1.0, 0.1, k), np.full(m - k, fl * 0.1)])
+    u, _ = np.linalg.qr(r.standard_normal((n, m)))
+    v, _ = np.linalg.qr(r.standard_normal((d, m)))
+    return ((u * (sv * 30.0)) @ v.T + r.standard_normal(d)).astype(np.float32)
+cases = [(20000, 512, 64, 5, kd) for kd in (sys.argv[1:] or ["planted", "geo97", "rsqrt"])]
+for (n, d, k, n_iter, kind) in cases:
+    x = make(n, d, k, kind)
     om = rng.standard_normal((d, k + 10)).astype(np.float32).astype(np.float64)
     o = po.RandomizedPcaOracle(k, n_iter=n_iter)
     o._inner_fit(x.astype(np.float64), omega=om)

@@ -109,7 +109,8 @@ static double two_plane(double v) {
     return double(h) + double(m);
 }
 void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P0,
-                int64_t N, int64_t ldp0, const void* bias, void* Z, int64_t ldz, double* sumsq, int p_planes) {
+                int64_t N, int64_t ldp0, const void* bias, void* Z, int64_t ldz, double* sumsq, int p_planes, bool steering) {
+    const bool x2 = steering && p_planes == 2 && dt == F32 && d->gemm_mode == 0 && !sumsq && N > 80 && std::getenv("PETAL_NO_POW3_FAST") == nullptr;
     // (split-product mode, fp32 data: a caller that accepts a two-plane P gets one, as on the device)
     std::vector<double> p2;
     const double* P = P0;
@@ -124,6 +125,7 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
     double ss = 0;
     for (int64_t i = 0; i < n; ++i) {
         for (int64_t k = 0; k < K; ++k) { row[k] = centred(X, dt, i * ldx + k, mu, k); ss += row[k] * row[k]; }
+        if (x2) for (int64_t k = 0; k < K; ++k) row[k] = two_plane(double(float(row[k])));   // (the device's steering pass: Xc on two planes)
         std::fill(acc.begin(), acc.end(), 0.0);
         for (int64_t k = 0; k < K; ++k) {
             const double a = row[k];
@@ -135,14 +137,19 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
     }
     if (sumsq) *sumsq += ss;
 }
-void op_gemm_atb(Dev*, int dt, const void* A, int64_t lda, int64_t M, const void* muA, const void* B, int64_t ldb,
-                 int64_t N, const void* muB, int64_t n, double* C, int64_t ldc, bool) {
+void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const void* muA, const void* B, int64_t ldb,
+                 int64_t N, const void* muB, int64_t n, double* C, int64_t ldc, bool precise, bool steering) {
+    const bool p4 = steering && !precise && dt == F32 && d->gemm_mode == 0 && N > 80 && std::getenv("PETAL_NO_POW3_FAST") == nullptr;
     for (int64_t m = 0; m < M; ++m)
         for (int64_t j = 0; j < N; ++j) C[m * ldc + j] = 0;
     std::vector<double> a(M), b(N);
     for (int64_t i = 0; i < n; ++i) {
         for (int64_t m = 0; m < M; ++m) a[m] = centred(A, dt, i * lda + m, muA, m);
         for (int64_t j = 0; j < N; ++j) b[j] = centred(B, dt, i * ldb + j, muB, j);
+        if (p4) {   // (the device's steering pass: both operands on two planes)
+            for (int64_t m = 0; m < M; ++m) a[m] = two_plane(double(float(a[m])));
+            for (int64_t j = 0; j < N; ++j) b[j] = two_plane(double(float(b[j])));
+        }
         for (int64_t m = 0; m < M; ++m) {
             if (a[m] == 0.0) continue;
             double* c = C + m * ldc;
@@ -480,13 +487,13 @@ void op_gemm_xp_prod_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K,
 }
 void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                   int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
-                  double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes) {
+                  double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes, bool steering) {
     op_chol_inv(d, G, L, ldg, T, ldt, rel_tol, ndead, M);
     if (dt == F32 && d->gemm_mode == 0 && p_planes == 2) {   // the two-plane iterate: P_out itself is rounded, every later use sees it
         op_dgemm(d, false, false, K, M, M, 1.0, A, lda, T, ldt, 0.0, P_out, ldpo);
         for (int64_t k = 0; k < K; ++k)
             for (int64_t j = 0; j < M; ++j) P_out[k * ldpo + j] = two_plane(P_out[k * ldpo + j]);
-        op_gemm_xp(d, dt, X, n, K, ldx, mu, P_out, M, ldpo, nullptr, Z, ldz, nullptr);
+        op_gemm_xp(d, dt, X, n, K, ldx, mu, P_out, M, ldpo, nullptr, Z, ldz, nullptr, 2, steering);
         return;
     }
     op_gemm_xp_prod(d, dt, X, n, K, ldx, mu, A, M, lda, T, M, ldt, P_out, ldpo, Z, ldz);

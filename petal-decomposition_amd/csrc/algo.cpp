@@ -634,6 +634,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // The FUSED power-iteration pass Y' = Xc^T (Xc P) (one pass over X where K1 + K2 make two; it needs P on two planes, so it
     // belongs to the optimistic run): every product pair of the loop below, the last one also storing Z.
     const bool use_pow = planes == 2 && op_power_pass_applies(c.dev, dt, X.p, n, dp, X.ld, muT.p, LP);
+    // STEERING products: every product of the optimistic run whose result only feeds the next re-basing may round its
+    // large operands to two bf16 planes like the iterate (the fused passes do; K1 / K2 in their forms for more than 80 columns do)
+    const bool steer = planes == 2 && dt == F32 && n_iter >= 3;
     bool have_yp = false;   // Yp already holds Xc^T Z for the current basis
     if (!means_done) {      // (fold_means: the first run of the pipeline)
         if (use_pow) {
@@ -656,7 +659,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     dev_set_tag(c.dev, TAG_XP);
     // (with power iterations behind it the sketch matrix may be ANY matrix: the optimistic run lets the kernel round Omega to two
     // bf16 planes -- five piece products; n_iter = 0 and the robust redo keep Omega as given)
-    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv_from_sq ? nullptr : tvp, planes);
+    op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv_from_sq ? nullptr : tvp, planes, steer);
     dev_set_tag(c.dev, TAG_NONE);
 
     // A SHORT iteration (n_iter 1 - 2) on fp32 data re-bases the sketch Z = Xc Omega on the tall side first, as the crate does
@@ -679,7 +682,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     for (int64_t it = 0; it < n_iter; ++it) {  // pca.rs:708-715
         if (!have_yp) {
             dev_set_tag(c.dev, TAG_ATB);
-            op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, it == 0 ? Zfirst : Z.p, LP, LP, nullptr, n, Yp, LP);  // Yp = Xc^T Z (pca.rs:711)
+            op_gemm_atb(c.dev, dt, X.p, X.ld, dp, muT.p, it == 0 ? Zfirst : Z.p, LP, LP, nullptr, n, Yp, LP, false, steer);  // Yp = Xc^T Z (pca.rs:711)
             dev_set_tag(c.dev, TAG_NONE);
             allreduce_f64(c, Yp, dp * LP, PETAL_SUM);
         }
@@ -704,7 +707,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
             }
             if (!have_yp) {
             dev_set_tag(c.dev, TAG_XP);   // (only the product kernel itself is bracketed)
-            op_rebase_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, G, L, LP, 1e-15, ndead, Yp, LP, LP, T.f64(), LP, Y.f64(), LP, Z.p, LP, planes);  // pca.rs:714
+            op_rebase_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, G, L, LP, 1e-15, ndead, Yp, LP, LP, T.f64(), LP, Y.f64(), LP, Z.p, LP, planes,
+                         steer && it + 1 < n_iter);  // pca.rs:714 (the last iteration's Z is the iterate the results are made of: exact)
             dev_set_tag(c.dev, TAG_NONE);
             }
         } else {
@@ -788,7 +792,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // (the two-plane verdict, from the spectrum just found)
     if (!robust && !exact && two_plane_applies)
         op_tail_verdict(c.dev, lam, L, std::max<int64_t>(k, 1), (tv_from_sq && !tv_direct) ? mu64 : nullptr, dp, d, ri.n_total,
-                        tv_direct ? mu64 + dp : tvp, use_pow ? 4e-6 * 1.7320508 : 4e-6, p2_thr, ndead);   // (steering passes round P, Xc and z: three sources)
+                        tv_direct ? mu64 + dp : tvp, (use_pow || steer) ? 4e-6 * 1.2 : 4e-6, p2_thr, ndead);   // (steering passes round Xc and z too: where the estimate
+                        // matters -- slowly decaying spectra -- that adds at most 16 % to what P's rounding costs: dev/x2_model.py)
     // rows of V^T: v_j = B^T u_j / sigma_j, sigma_j = sqrt(lam_j) (the host takes the same square roots of lam)
     op_components_out(c.dev, dt, Bt.f64(), LP, Uh.f64(), LP, lam, dt == F32 ? 1e-7 : 1e-12, d, L, k, comp_dev);
 

@@ -1144,6 +1144,19 @@ __device__ __forceinline__ void split3(const f32x8 x, bf16x8& h, bf16x8& m, bf16
     m = __builtin_bit_cast(bf16x8, mm);
     l = __builtin_bit_cast(bf16x8, ll);
 }
+// the two leading pieces only (16 significant bits): the operands of the STEERING passes (k_pow3f, k_xp3<.., X2>, k_atb3<.., P4>)
+__device__ __forceinline__ void split2(const f32x8 x, bf16x8& h, bf16x8& m) {
+    u32x4 hh, mm;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float r0 = x[2 * e], r1 = x[2 * e + 1];
+        hh[e] = cvt_pk_bf16(r0, r1);
+        sub_pk_bf16(r0, r1, hh[e]);
+        mm[e] = cvt_pk_bf16(r0, r1);
+    }
+    h = __builtin_bit_cast(bf16x8, hh);
+    m = __builtin_bit_cast(bf16x8, mm);
+}
 // Ppk3[((c NTtot + nt) 3 + plane) 64 + lane][e] = plane of (float)P[32 c + 8 (lane >> 4) + e][16 nt + (lane & 15)]
 __global__ __launch_bounds__(256) void k_pack_p3(const double* __restrict__ P, int64_t K, int64_t N, int64_t ldp,
                                                  bf16x8* __restrict__ out, int NTtot, int64_t total) {
@@ -1171,7 +1184,8 @@ __global__ __launch_bounds__(256) void k_pack_p3(const double* __restrict__ P, i
 // NPL = planes of P that take part: 3, or 2 when the caller DEFINED P as the sum of its two leading bf16 pieces (the re-based
 // iterate of the power iteration, k_trsm_pack<NB, true>): the product x_h p_l has nothing to multiply then -- five piece products
 // instead of six, and a third less of P to stage through LDS.
-template <int RT, int NT, int DEPTH, bool CENTER, int WVK = 4, int OCC = PETAL_XP3_OCC, int NPL = 3>  // WVK = waves (row tiles of 16 RT rows) per workgroup
+// X2 (needs NPL = 2; a STEERING pass, see k_pow3f): X too is rounded to its two leading pieces -- four piece products per tile.
+template <int RT, int NT, int DEPTH, bool CENTER, int WVK = 4, int OCC = PETAL_XP3_OCC, int NPL = 3, bool X2 = false>  // WVK = waves (row tiles of 16 RT rows) per workgroup
 __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__ X, int64_t n, int K, int64_t ldx,
                                                             const float* __restrict__ mu, const bf16x8* __restrict__ Ppk3,
                                                             int NTtot, int nt0, int N, const float* __restrict__ bias,
@@ -1264,7 +1278,8 @@ __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
                     if (CENTER) a[s][t] -= m;
-                    split3(a[s][t], ah[t], am[t], al[t]);
+                    if (X2) { split2(a[s][t], ah[t], am[t]); al[t] = am[t]; }
+                    else split3(a[s][t], ah[t], am[t], al[t]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1291,7 +1306,7 @@ __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__
                     f32x4 c4 = acc[t][u];
                     if (NPL == 3) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[t], c4, 0, 0, 0);   // smallest terms first
                     c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[t], c4, 0, 0, 0);
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[t], c4, 0, 0, 0);
+                    if (!X2) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[t], c4, 0, 0, 0);
                     c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[t], c4, 0, 0, 0);
                     c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[t], c4, 0, 0, 0);
                     c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[t], c4, 0, 0, 0);
@@ -1708,7 +1723,8 @@ __global__ __launch_bounds__(256, 2) void k_atb_mfma(const float* __restrict__ A
 // 32-row stage of B, which is read from memory and converted ONCE per workgroup: with 4-wave workgroups a 512-column A
 // makes two workgroups per row chunk read and convert the same stage (K2's PMC traffic was 1.16-1.23x algorithmic, most
 // of it this); 8-wave workgroups cover 512 columns with one.
-template <int NT, bool CA, int WV, int MT = 4>  // MT = column tiles of A per wave (4: 64 columns, 16-B loads; 2: 32 columns, 8-B loads)
+// P4 (a STEERING pass, see k_pow3f): A and B are both rounded to their two leading pieces -- four piece products per tile instead of six.
+template <int NT, bool CA, int WV, int MT = 4, bool P4 = false>  // MT = column tiles of A per wave (4: 64 columns, 16-B loads; 2: 32 columns, 8-B loads)
 __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ muA,
                                                      const float* __restrict__ B, int64_t ldb, int N, int n0col, int64_t n,
                                                      int64_t chunk, float* __restrict__ part, int Npart, int n_tail) {
@@ -1765,10 +1781,10 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
     auto stage_z1 = [&](int buf, f32x8 zr, int u, bool on) {
         if (!on) zr = f32x8{0, 0, 0, 0, 0, 0, 0, 0};  // columns beyond N contribute zeros
         bf16x8 h, m, l;
-        split3(zr, h, m, l);
+        if (P4) split2(zr, h, m); else split3(zr, h, m, l);
         sB[buf][(u * 3 + 0) * 64 + lane] = h;
         sB[buf][(u * 3 + 1) * 64 + lane] = m;
-        sB[buf][(u * 3 + 2) * 64 + lane] = l;
+        if (!P4) sB[buf][(u * 3 + 2) * 64 + lane] = l;
     };
     auto split_a = [&](fvecm(&av)[8], bf16x8(&ah)[MT], bf16x8(&am)[MT], bf16x8(&al)[MT]) {
         if (CA) {  // centred in place (a centred COPY would keep 32 more registers alive across the four splits)
@@ -1778,23 +1794,24 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const f32x8 x = f32x8{av[0][t], av[1][t], av[2][t], av[3][t], av[4][t], av[5][t], av[6][t], av[7][t]};
-            split3(x, ah[t], am[t], al[t]);
+            if (P4) { split2(x, ah[t], am[t]); al[t] = am[t]; }
+            else split3(x, ah[t], am[t], al[t]);
         }
     };
     auto mfma_stage = [&](int buf, int lane, const bf16x8(&ah)[MT], const bf16x8(&am)[MT], const bf16x8(&al)[MT]) {
         // B fragments one tile ahead of the MFMAs that use them (pinned: hoisting all 15 reads costs 48 more registers)
-        bf16x8 bh = sB[buf][0 * 64 + lane], bm = sB[buf][1 * 64 + lane], bl = sB[buf][2 * 64 + lane];
+        bf16x8 bh = sB[buf][0 * 64 + lane], bm = sB[buf][1 * 64 + lane], bl = P4 ? bm : sB[buf][2 * 64 + lane];
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             bf16x8 nh = bh, nm = bm, nl = bl;
-            if (u + 1 < NT) { nh = sB[buf][(u * 3 + 3) * 64 + lane]; nm = sB[buf][(u * 3 + 4) * 64 + lane]; nl = sB[buf][(u * 3 + 5) * 64 + lane]; }
+            if (u + 1 < NT) { nh = sB[buf][(u * 3 + 3) * 64 + lane]; nm = sB[buf][(u * 3 + 4) * 64 + lane]; nl = P4 ? nm : sB[buf][(u * 3 + 5) * 64 + lane]; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 f32x4 c4 = acc[t][u];
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bh, c4, 0, 0, 0);   // smallest terms first
+                if (!P4) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bh, c4, 0, 0, 0);   // smallest terms first
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bm, c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bl, c4, 0, 0, 0);
+                if (!P4) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bl, c4, 0, 0, 0);
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bh, c4, 0, 0, 0);
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bm, c4, 0, 0, 0);
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bh, c4, 0, 0, 0);
@@ -1859,10 +1876,10 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
 #pragma unroll
             for (int e = 0; e < 8; ++e) zr[e] = (8 * q2 + e < tail && zcol < N) ? zp[(int64_t)(8 * q2 + e) * ldb + min(zcol, N - 1)] : 0.f;
             bf16x8 h, m, l;
-            split3(zr, h, m, l);
+            if (P4) split2(zr, h, m); else split3(zr, h, m, l);
             sB[buf][(u * 3 + 0) * 64 + lane2] = h;
             sB[buf][(u * 3 + 1) * 64 + lane2] = m;
-            sB[buf][(u * 3 + 2) * 64 + lane2] = l;
+            if (!P4) sB[buf][(u * 3 + 2) * 64 + lane2] = l;
         };
         if (wave2 < NT) tail_z(wave2);
         if (Z2 && WV + wave2 < NT) tail_z(WV + wave2);
@@ -2263,18 +2280,6 @@ __global__ __launch_bounds__(512) void k_pow3(const float* __restrict__ X, int64
 #ifndef PETAL_POW3F_DEPHASE
 #define PETAL_POW3F_DEPHASE 0
 #endif
-__device__ __forceinline__ void split2(const f32x8 x, bf16x8& h, bf16x8& m) {
-    u32x4 hh, mm;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float r0 = x[2 * e], r1 = x[2 * e + 1];
-        hh[e] = cvt_pk_bf16(r0, r1);
-        sub_pk_bf16(r0, r1, hh[e]);
-        mm[e] = cvt_pk_bf16(r0, r1);
-    }
-    h = __builtin_bit_cast(bf16x8, hh);
-    m = __builtin_bit_cast(bf16x8, mm);
-}
 // MEANS: as k_pow3's (the first pass of a fit about a provisional centre: the last column of z set to one gathers the column sums, the
 // splits accumulate sum (x - mu0)^2 -- from the values BEFORE their rounding; the sums themselves are those of the 16-bit values, off the
 // exact ones by 2^-17 sigma / sqrt(n) per column: 1e-8 sigma at the 200000 rows the fold starts from).
@@ -6260,10 +6265,10 @@ struct AbsmaxReq { int64_t cols, row_offset; double *absmax, *idx, *sign; };
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
                          int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am = nullptr,
-                         bool p2_hint = false);
+                         bool p2_hint = false, bool steering = false);
 void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
-                int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, int p_planes) {
-    gemm_xp_impl(d, dt, X, n, K, ldx, mu, P, N, ldp, bias, Z, ldz, sumsq, nullptr, 0, 0, nullptr, 0, false, nullptr, p_planes == 2);
+                int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, int p_planes, bool steering) {
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, P, N, ldp, bias, Z, ldz, sumsq, nullptr, 0, 0, nullptr, 0, false, nullptr, p_planes == 2, steering);
 }
 void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* A, int64_t M,
                      int64_t lda, const double* T, int64_t N, int64_t ldt, double* P_out, int64_t ldpo, void* Z, int64_t ldz) {
@@ -6316,7 +6321,7 @@ void op_gemm_xp_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K, int6
 }
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
-                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am, bool p2_hint) {
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am, bool p2_hint, bool steering) {
     if (n == 0 || N == 0) return;
     const bool mfma = dt == F32 && K % 16 == 0 && K > 0 && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
                       K < (1 << 24) && N < (1 << 24) && N % 16 == 0 && ldz % 4 == 0 && aligned16(Z) && (!bias || aligned16(bias));
@@ -6391,6 +6396,7 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         static const bool no_p2 = getenv("PETAL_NO_P2") != nullptr;
         static const bool no_p2_it = no_p2 || getenv("PETAL_NO_P2_ITERATE") != nullptr, no_p2_om = no_p2 || getenv("PETAL_NO_P2_OMEGA") != nullptr;
         const bool p2 = p2_hint && ((prod_A && prod_rt && !no_p2_it) || (!prod_A && !no_p2_om)) && !am;
+        const bool x2 = p2 && steering && getenv("PETAL_NO_POW3_FAST") == nullptr;   // (a steering pass: X on two planes too; the wide form only)
         if (prod_A) {
             // P = prod_A . P: the fp64 GEMM kernel writes the product (prod_out) AND its operand planes from its epilogue
             if (prod_rt)   // P is R in RT form: blocked triangular solve instead of the product with the explicit inverse
@@ -6437,7 +6443,14 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
                 if (muf) hipLaunchKernelGGL((k_xp3<2, NTv, DPv, true, 8, PETAL_XP3_OCC, NPLv>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
                 else hipLaunchKernelGGL((k_xp3<2, NTv, DPv, false, 8, PETAL_XP3_OCC, NPLv>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
             } while (0)
-#define XP3_LAUNCH8(NTv) do { if (p2) XP3_LAUNCH8P(NTv, 2); else XP3_LAUNCH8P(NTv, 3); } while (0)
+#define XP3_LAUNCH8X(NTv)                                                                                                                 \
+            do {                                                                                                                            \
+                const int blocksw = cdiv(n, 256);                                                                                           \
+                if (lds > 64 * 1024) set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp3<2, NTv, DPv, true, 8, PETAL_XP3_OCC, 2, true>) : reinterpret_cast<const void*>(k_xp3<2, NTv, DPv, false, 8, PETAL_XP3_OCC, 2, true>)); \
+                if (muf) hipLaunchKernelGGL((k_xp3<2, NTv, DPv, true, 8, PETAL_XP3_OCC, 2, true>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
+                else hipLaunchKernelGGL((k_xp3<2, NTv, DPv, false, 8, PETAL_XP3_OCC, 2, true>), dim3(blocksw), dim3(512), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
+            } while (0)
+#define XP3_LAUNCH8(NTv) do { if (p2 && x2) XP3_LAUNCH8X(NTv); else if (p2) XP3_LAUNCH8P(NTv, 2); else XP3_LAUNCH8P(NTv, 3); } while (0)
             if (w >= 6) {   // eight 32-row waves per workgroup: the P chunk is staged once per 256 rows, as in the 64-row form
                 switch (w) {
                     case 9: XP3_LAUNCH8(9); break;
@@ -6603,8 +6616,9 @@ static void launch_atb(Dev* d, const float* A, int64_t lda, int M, const float* 
 }
 
 void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const void* muA, const void* B, int64_t ldb, int64_t N,
-                 const void* muB, int64_t n, double* C, int64_t ldc, bool precise) {
+                 const void* muB, int64_t n, double* C, int64_t ldc, bool precise, bool steering) {
     if (M == 0 || N == 0) return;
+    const bool p4 = steering && !precise && getenv("PETAL_NO_POW3_FAST") == nullptr;   // (a steering pass: both operands on two planes; the wide form only)
     if (n == 0) { HIP_CHECK(hipMemset2DAsync(C, ldc * sizeof(double), 0, N * sizeof(double), M, d->stream)); return; }
     const bool mfma = !precise && dt == F32 && M % 16 == 0 && N % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B) &&
                       (!muA || aligned16(muA)) && (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
@@ -6764,7 +6778,9 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
             const dim3 grid(8 * cdiv(M, 256), (unsigned)cdiv(nsplit, 8)), block(512);   // 8 waves x 32 columns per workgroup
 #define ATB3W_LAUNCH(NTv)                                                                                                             \
             do {                                                                                                                      \
-                if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, 8, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
+                if (p4 && ma) hipLaunchKernelGGL((k_atb3<NTv, true, 8, 2, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
+                else if (p4) hipLaunchKernelGGL((k_atb3<NTv, false, 8, 2, true>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
+                else if (ma) hipLaunchKernelGGL((k_atb3<NTv, true, 8, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
                 else hipLaunchKernelGGL((k_atb3<NTv, false, 8, 2>), grid, block, 0, d->stream, Af, lda, (int)M, ma, Bf, ldb, (int)N, 16 * nt0, n_main, chunk, part, (int)N, (int)n_tail); \
             } while (0)
             switch (w) {
@@ -7253,7 +7269,7 @@ static void chol_inv_blocked(Dev* d, const double* G, int64_t L, int64_t ldg, do
 // while it packs the operand planes of the product that follows.
 void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                   int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
-                  double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes) {
+                  double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes, bool steering) {
     static const bool no_rt = getenv("PETAL_NO_TRSM") != nullptr;
     const bool fused = dt == F32 && gemm_split_product(d) && n >= 64 && K % 16 == 0 && K > 0 && M % 16 == 0 && ldx % 4 == 0 &&
                        aligned16(X) && (!mu || aligned16(mu)) && ldz % 4 == 0 && aligned16(Z) && K < (1 << 24) && M < (1 << 24);
@@ -7266,7 +7282,7 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
     hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead,
                        (int)M, (const double*)nullptr, 1, (int)L);
     launch_check();
-    gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, M, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, true, nullptr, p_planes == 2);
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, M, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, true, nullptr, p_planes == 2, steering);
 }
 
 // ---- split-product Gram matrix C = (X - mu)^T (X - mu) for FastICA's whitening (round 5) --------------------------------------

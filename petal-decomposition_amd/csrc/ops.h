@@ -86,7 +86,10 @@ void op_colmean(Dev*, int dtype, const void* X, int64_t n, int64_t d, int64_t ld
 // serves) -- the split-product kernel then forms five piece products instead of six; other paths ignore it.
 void op_gemm_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
                 const double* P, int64_t N, int64_t ldp, const void* bias,
-                void* Z, int64_t ldz, double* sumsq, int p_planes = 3);
+                void* Z, int64_t ldz, double* sumsq, int p_planes = 3, bool steering = false);
+// steering (op_gemm_xp, op_rebase_xp with p_planes = 2; op_gemm_atb): the product only STEERS a power iteration -- the split-product
+// kernels may round the LARGE operands (Xc; Xc and Z) to two bf16 planes as well: four piece products per tile (the forms for more than
+// 80 columns; see op_power_pass).
 // op_gemm_xp with P = A . T formed on the fly (A: K x M, lda; T: M x N, ldt; both fp64 small matrices): the re-basing
 // product Y = Yp T of the power iteration goes straight into the GEMM kernel's operand planes instead of through a GEMM
 // launch of its own.  P_out (nullable, K x N fp64, ldpo) also receives the product.
@@ -111,7 +114,7 @@ void op_gemm_xp_absmax(Dev*, int dtype, const void* X, int64_t n, int64_t K, int
 // that saves a piece product; 3: P_out is the re-based iterate to fp64 / fp32 accuracy.
 void op_rebase_xp(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                   int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
-                  double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes = 2);
+                  double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes = 2, bool steering = false);
 // One FUSED power-iteration pass, the two products of pca.rs:711 + 714 in ONE pass over X:
 //     Y (K x N fp64, ldy) = (X - mu)^T ((X - mu) P),     Z (nullable, n x N, ldz) = (X - mu) P
 // with P rounded to the sum of its two leading bf16 pieces (a caller that needs P to fp32 accuracy uses op_gemm_xp + op_gemm_atb).
@@ -147,7 +150,7 @@ void op_tail_verdict(Dev*, const double* lam, int64_t L, int64_t k, const double
 // matter: exact Pca, FastICA whitening); otherwise fp32 MFMA chunks combined in fp64.
 void op_gemm_atb(Dev*, int dtype, const void* A, int64_t lda, int64_t M, const void* muA,
                  const void* B, int64_t ldb, int64_t N, const void* muB, int64_t n,
-                 double* C, int64_t ldc, bool precise = false);
+                 double* C, int64_t ldc, bool precise = false, bool steering = false);
 // C (dp x dp fp64, ldc; only the leading d x d block is non-zero) = (X - mu)^T (X - mu) for fp32 X by EXACT bf16-piece products with
 // fp32 accumulation over row chunks (fp64 across them): good to ~1e-6 of C's largest entries -- enough for a whitening whose wanted
 // eigenvalues lie within two decades (the caller checks), not for an exact Pca.  False, nothing done: shape / mode not covered.

@@ -16,12 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel (regex on the demangled name) -> (max VGPRs (unified: VGPR + AGPR), max scratch bytes, who uses it)
 BUDGETS = [
-    (r"k_atb3<5, (true|false), 8, 2>$", 128, 0, "K2 split-product, configs[1] (l = 74): 4 waves/SIMD"),
-    (r"k_atb3<5, (true|false), 8, 4>$", 208, 0, "K2 split-product, long-row form (1e6 x 512)"),
-    (r"k_atb3<9, (true|false), 8, 2>$", 170, 0, "K2 split-product, l = 138 (configs[3])"),
+    (r"k_atb3<5, (true|false), 8, 2, (true|false)>$", 128, 0, "K2 split-product, configs[1] (l = 74): 4 waves/SIMD"),
+    (r"k_atb3<5, (true|false), 8, 4, false>$", 208, 0, "K2 split-product, long-row form (1e6 x 512)"),
+    (r"k_atb3<9, (true|false), 8, 2, (true|false)>$", 170, 0, "K2 split-product, l = 138 (configs[3])"),
     (r"k_atb3<", 256, 0, "every K2 split-product instantiation: no scratch"),
-    (r"k_xp3<4, 5, 1, (true|false), 4, 2, [23]>$", 232, 0, "K1 split-product, l = 74"),
-    (r"k_xp3<2, 9, 1, (true|false), 8, 2, [23]>$", 180, 0, "K1 split-product, l = 138"),
+    (r"k_xp3<4, 5, 1, (true|false), 4, 2, [23], false>$", 232, 0, "K1 split-product, l = 74"),
+    (r"k_xp3<2, 9, 1, (true|false), 8, 2, [23], (true|false)>$", 180, 0, "K1 split-product, l = 138"),
     (r"k_xp3<", 256, 0, "every K1 split-product instantiation: no scratch"),
     # (one 8-wave workgroup per CU, two waves per SIMD: 256 is the whole budget, and a spilled P fragment is reloaded BEHIND the
     # stage's X loads -- vmcnt retires in order -- which cost the first build 7300 cycles in a 1300-cycle phase)
@@ -53,7 +53,7 @@ def resources():
 
 def test_notes_are_readable(resources):
     assert len(resources) > 100
-    assert any("k_atb3<5, true, 8, 2>" in k for k in resources)
+    assert any("k_atb3<5, true, 8, 2, false>" in k for k in resources)
 
 
 @pytest.mark.parametrize("pattern,max_vgpr,max_scratch,who", BUDGETS, ids=[b[0] for b in BUDGETS])
