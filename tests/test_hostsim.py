@@ -81,6 +81,7 @@ def test_steering_passes_on_sixteen_bit_operands(ctx, monkeypatch):
     ctx.set_gemm_mode("bf16x3")
     try:
         assert pc.steering_pass_case(ctx, monkeypatch, 1500, 64, 6, 5, seed=95, tol=2e-5) == 0
+        assert pc.steering_pass_case(ctx, monkeypatch, 1200, 128, 90, 4, seed=98, tol=5e-5) == 0   # (l = 100: the K1 / K2 steering products)
     finally:
         ctx.set_gemm_mode("fp32")
 
