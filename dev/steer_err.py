@@ -7,7 +7,8 @@ import petal_decomposition_amd as petal
 from oracle import petal_oracle as po
 import parity_cases as pc
 ctx = petal.Context(0)
-for (n, d, k, it, seed) in ((20000, 1024, 128, 4, 96), (9000, 400, 100, 7, 97), (20000, 1024, 128, 7, 99), (40000, 1024, 64, 5, 100), (9000, 400, 40, 5, 101)):
+SHAPES = ((20000, 512, 64, 5, 91), (33333, 500, 24, 3, 92), (8192, 512, 64, 7, 93), (100000, 512, 64, 5, 7), (20000, 512, 64, 3, 5)) if len(sys.argv) > 1 else ((20000, 1024, 128, 4, 96), (9000, 400, 100, 7, 97), (20000, 1024, 128, 7, 99), (40000, 1024, 64, 5, 100), (9000, 400, 40, 5, 101))
+for (n, d, k, it, seed) in SHAPES:
     x = po.synth_pca(n, d, k, seed=seed, dtype=np.float32)
     om = np.random.default_rng(seed + 1000).standard_normal((d, k + 10)).astype(np.float32)
     o = po.RandomizedPcaOracle(k, n_iter=it)

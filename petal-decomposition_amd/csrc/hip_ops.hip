@@ -1112,6 +1112,13 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // one v_cv
 }
 // written pair-wise so hipcc emits packed converts (12), shifts / masks (16) and packed subtracts (8) per 8 elements;
 // the generic vector conversion costs one convert per ELEMENT
+#ifndef PETAL_STEER_PIECES
+#define PETAL_STEER_PIECES 4   // piece products of a STEERING product (both operands on two planes): 4, or 3 = without x_m p_m.  That term is 2^-18 of
+                               // x_h p_h, the size of what the pass has dropped already -- but not below it: with three pieces configs[1] runs 0.96-0.98 ms
+                               // for 0.99-1.02 and the converged fits keep their errors (2.8e-6 / 2.9e-6 / 3.0e-6 with three / four pieces / exact passes at
+                               // 100000 x 512), while the LAST component of a fit that has not converged loses a factor two to three (20000 x 512, n_iter 3:
+                               // 3.4e-5 / 1.1e-5 / 1.5e-5; 20000 x 1024, k = 128, n_iter 7: 1.04e-5 / 7.4e-6 / 7.2e-6).  Measured, not taken.
+#endif
 #ifndef PETAL_SPLIT_DOT2
 #define PETAL_SPLIT_DOT2 1
 #endif
@@ -1307,7 +1314,7 @@ __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__
                 for (int t = 0; t < RT; ++t) {  // P fragment as the A operand: the accumulator tile is Z^T (16-B stores below)
                     f32x4 c4 = acc[t][u];
                     if (NPL == 3) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[t], c4, 0, 0, 0);   // smallest terms first
-                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[t], c4, 0, 0, 0);
+                    if (!X2 || PETAL_STEER_PIECES >= 4) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[t], c4, 0, 0, 0);
                     if (!X2) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[t], c4, 0, 0, 0);
                     c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[t], c4, 0, 0, 0);
                     c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[t], c4, 0, 0, 0);
@@ -1812,7 +1819,7 @@ __global__ __launch_bounds__(64 * WV, 2) void k_atb3(const float* __restrict__ A
             for (int t = 0; t < MT; ++t) {
                 f32x4 c4 = acc[t][u];
                 if (!P4) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bh, c4, 0, 0, 0);   // smallest terms first
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bm, c4, 0, 0, 0);
+                if (!P4 || PETAL_STEER_PIECES >= 4) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bm, c4, 0, 0, 0);
                 if (!P4) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bl, c4, 0, 0, 0);
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bh, c4, 0, 0, 0);
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bm, c4, 0, 0, 0);
@@ -2343,7 +2350,9 @@ __global__ __launch_bounds__(512) void k_pow3f(const float* __restrict__ X, int6
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 f32x4 c4 = acc1[u];
+#if PETAL_STEER_PIECES >= 4
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, pm[c][u], c4, 0, 0, 0);   // smallest terms first
+#endif
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, ph[c][u], c4, 0, 0, 0);
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, pm[c][u], c4, 0, 0, 0);
                 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, ph[c][u], c4, 0, 0, 0);
@@ -2457,7 +2466,9 @@ __global__ __launch_bounds__(512) void k_pow3f(const float* __restrict__ X, int6
 #pragma unroll
                     for (int mm = 0; mm < 2; ++mm) {
                         f32x4 c4 = acc2[2 * mp + mm][u];
+#if PETAL_STEER_PIECES >= 4
                         c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][1], zm, c4, 0, 0, 0);   // smallest terms first
+#endif
                         c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][1], zh, c4, 0, 0, 0);
                         c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][0], zm, c4, 0, 0, 0);
                         c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mm][0], zh, c4, 0, 0, 0);
