@@ -353,6 +353,8 @@ def main():
                                          "nor read (the last pass of a fit also stores Z)"}
         if not strong or world == 1:
             out["serial_chain"] = serial_chain(ctx, model, x, omega, elapsed / args.steps * 1e3)
+            if cfg["model"] == "rpca" and world == 1:
+                out["predicted_scaling"] = predicted_scaling(out["ms_per_step"], out["serial_chain"], n_iter, d, l, strong)
         if world == 1 and x_host is not None:
             # host-ndarray-in rate (H2D over PCIe included) -- informational, never `value`
             model.fit(x_host, omega=omega)
@@ -371,6 +373,10 @@ def main():
 
         if world == 1 and args.gemm == "bf16x3" and not args.no_northstar:
             out["fp32_mfma_mode"] = fp32_mode_extra(petal, ctx, model, x, omega)
+            # the two figures that price the optimism of `value`: the same fit with three-plane operands in every pass
+            # (no steering passes, no verdict), and a fit whose spectrum the verdict refuses -- the caller then pays for two runs
+            out["exact_mode"] = exact_mode_extra(petal, ctx, model, x, omega)
+            out["redo_case"] = redo_case_extra(petal, ctx, torch, dev, n, d, k, n_iter)
 
         if world == 1 and not args.no_northstar and not strong:
             del x
@@ -394,8 +400,14 @@ def main():
             try:
                 out["one_gpu_same_matrix"] = strong_baseline(petal, torch, dev, cfg, n_total, d, k, n_iter, omega, args.gemm,
                                                              out["ms_per_step"])
+                # top level: value(N) / value(1) across bench lines compares DIFFERENT workloads (--gpus 1 is configs[1]); this is the
+                # ratio a scaling table wants -- the same matrix, the same job, one GPU against N
+                out["speedup_vs_one_gpu_same_matrix"] = out["one_gpu_same_matrix"].get("speedup_of_the_sharded_run")
             except Exception as e:  # informational: never loses the line
                 out["one_gpu_same_matrix"] = {"error": repr(e)}
+                out["speedup_vs_one_gpu_same_matrix"] = None
+    if rank == 0 and out is not None and world > 1 and "speedup_vs_one_gpu_same_matrix" not in out:
+        out["speedup_vs_one_gpu_same_matrix"] = None   # (weak-scaling configs / --no-strong-baseline: no same-matrix one-GPU fit in this job)
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
@@ -618,6 +630,28 @@ def serial_chain(ctx, model, x, omega, ms_per_step, reps=8):
                     "all-reduces: Cholesky / triangular solve / Gram / eigen-solve / slab combines / launch gaps -- replicated on every rank"}
 
 
+def predicted_scaling(ms_per_step, chain, n_iter, d, l, strong, allreduce_us=(20.0, 50.0)):
+    """What a 2 / 4 / 8-GPU run of THIS workload is expected to give, from figures measured on one GPU: the row-streaming kernels shrink
+    with the rank count, the replicated small-matrix chain does not, and a fit adds n_iter + 3 all-reduces (prologue, n_iter + 1 products
+    of d x l fp64, the svd_flip key).  Two all-reduce latencies bracket what a <= 1.2 MB RCCL all-reduce over xGMI costs; the first
+    measured SCALE line can be read against this.  Strong scaling: one matrix split N ways; weak: N copies of the per-GPU workload."""
+    serial = chain["serial_chain_ms"]
+    streaming = max(ms_per_step - serial, 0.0)
+    calls = n_iter + 3
+    res = {"model": "t(N) = streaming_ms / N + serial_chain_ms + (n_iter + 3) x allreduce latency (strong) ; "
+                    "t(N) = ms_per_step + (n_iter + 3) x allreduce latency (weak)",
+           "streaming_ms": round(streaming, 4), "serial_chain_ms": round(serial, 4), "allreduce_calls_per_fit": calls,
+           "allreduce_payload_bytes": 8 * d * l, "assumed_allreduce_us": list(allreduce_us)}
+    for N in (2, 4, 8):
+        lo_hi = []
+        for us in allreduce_us:
+            t_strong = streaming / N + serial + calls * us * 1e-3
+            t_weak = ms_per_step + calls * us * 1e-3
+            lo_hi.append(round(ms_per_step / t_strong, 2) if strong else round(N * ms_per_step / t_weak, 2))
+        res[f"speedup_at_{N}_gpus"] = {"best": max(lo_hi), "worst": min(lo_hi)}
+    return res
+
+
 def padded_pitch_extra(petal, ctx, torch, model, x, omega, steps=20, pad_elems=32):
     """The same fit with X held by the CALLER with a padded row pitch (a strided device view, streamed in place): informational.
     A row pitch that is a multiple of 1 KiB puts column chunk c of every row on the same few memory channels; 128 B of padding per
@@ -659,6 +693,55 @@ def fp32_mode_extra(petal, ctx, model, x, omega, steps=10):
     return {"ms_per_step": round(ms, 4), "samples_per_s": round(x.shape[0] / (ms * 1e-3), 1),
             "K1": {"avg_launch_ms": round(k1, 5), "TFLOP/s": round(fl / (k1 * 1e-3) / 1e12, 2), "frac_of_fp32_mfma_peak": round(fl / (k1 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)},
             "K2": {"avg_launch_ms": round(k2, 5), "TFLOP/s": round(fl / (k2 * 1e-3) / 1e12, 2), "frac_of_fp32_mfma_peak": round(fl / (k2 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}}
+
+
+def exact_mode_extra(petal, ctx, model, x, omega, steps=20):
+    """The same fit with PETAL_GEMM_SPLIT_BF16X3_EXACT: three bf16 planes of every operand in every pass (five / six piece products,
+    no 16-bit steering passes, no spectrum verdict) -- the split-product arithmetic that is fp32-equivalent throughout."""
+    ctx.set_gemm_mode("bf16x3-exact")
+    try:
+        ramp(lambda: model.fit(x, omega=omega), 0.05)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.fit(x, omega=omega)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        st = ctx.stats()
+    finally:
+        ctx.set_gemm_mode("bf16x3")
+    return {"ms_per_step": round(ms, 4), "samples_per_s": round(x.shape[0] / (ms * 1e-3), 1), "rpca_redo": int(st["rpca_redo"]),
+            "note": "petal_ctx_set_gemm_mode(PETAL_GEMM_SPLIT_BF16X3_EXACT): every pass on three-plane operands; `value` above is the "
+                    "default mode, whose passes before the last run on 16-bit operands behind a spectrum verdict"}
+
+
+def heavy_tail_matrix(torch, dev, n, d, rho=0.97, seed=11):
+    """n x d fp32 with singular values 100 sqrt(n) rho^i over ALL d directions (no planted gap, no noise floor below): the
+    slowly decaying spectrum on which the two-plane verdict refuses the optimistic run"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    q, _ = torch.linalg.qr(torch.randn((d, d), generator=g, device=dev, dtype=torch.float32))
+    s = 100.0 * float(np.sqrt(n)) * torch.pow(torch.tensor(rho, device=dev, dtype=torch.float32), torch.arange(d, device=dev, dtype=torch.float32))
+    x = torch.randn((n, d), generator=g, device=dev, dtype=torch.float32) / float(np.sqrt(n))
+    return (x * s) @ q.T
+
+
+def redo_case_extra(petal, ctx, torch, dev, n, d, k, n_iter, steps=20):
+    """A fit that the verdict REDOES: the same shape, singular values 0.97^i (heavy tail).  The optimistic run is thrown away and the
+    fit repeated on three-plane operands (petal_stats.rpca_redo = 1): what a user with such data pays in the default mode."""
+    x = heavy_tail_matrix(torch, dev, n, d)
+    omega = np.random.default_rng(3).standard_normal((d, k + 10)).astype(np.float32)
+    m = petal.RandomizedPca(k, ctx=ctx, n_iter=n_iter)
+    ramp(lambda: m.fit(x, omega=omega), 0.05)
+    redo = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.fit(x, omega=omega)
+        redo = max(redo, int(ctx.stats()["rpca_redo"]))
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    del x
+    return {"ms_per_step": round(ms, 4), "samples_per_s": round(n / (ms * 1e-3), 1), "rpca_redo": redo,
+            "spectrum": "sigma_i = 100 sqrt(n) 0.97^i over all 512 directions",
+            "note": "rpca_redo = 1: the spectrum verdict refused the optimistic (16-bit operand) run and the fit was repeated with three "
+                    "planes everywhere; PETAL_GEMM_SPLIT_BF16X3_EXACT avoids the first run for callers who know their spectra"}
 
 
 def northstar(petal, ctx, torch, dev, n=1_000_000, d=512, l=74, reps=5):
@@ -764,19 +847,24 @@ def bench_fastica(args, cfg, petal, ctx, torch, dist, dev, rank, world, collecti
                     "traffic": None, "kernel": "K7 fused FastICA step (fp32 MFMA)", "avg_launch_ms": round(avg, 5),
                     "flops_per_launch": st["ica_step_flops"], "bytes_per_launch": st["ica_step_bytes"]}
     else:
-        # split-product step on pre-split planes (k_ica3p): both products form six bf16 piece products per fp32 product, and X1 is read
-        # as three bf16 planes (6 B per value where the fp32 data had 4): priced like K1 - K3, against whichever roof gives the larger floor
+        # split-product step on pre-split planes (k_ica3p).  Algorithmic work per iteration (SURVEY.md 8 d): 4 nc^2 n flop and 4 nc n
+        # bytes -- the fp32 whitened data read once.  Both products form six bf16 piece products per fp32 product, so the candidate
+        # floors are 4 nc n / 8 TB/s and 6 x flops / 2.5 PFLOP/s; the kernel's own layout (three bf16 planes of the padded data, 6 B per
+        # value) is what it MOVES -- reported as `traffic` (layout bytes, not a PMC reading), never as the floor.
         ncp = -(-nc // 16) * 16
+        alg_bytes = 4.0 * nc * n
         plane_bytes = 6.0 * ncp * n
-        floors = {"hbm": plane_bytes / (HBM_PEAK_GBS * 1e9), "mfma-bf16": 6.0 * st["ica_step_flops"] / (BF16_MFMA_PEAK_TF * 1e12)}
+        floors = {"hbm": alg_bytes / (HBM_PEAK_GBS * 1e9), "mfma-bf16": 6.0 * st["ica_step_flops"] / (BF16_MFMA_PEAK_TF * 1e12)}
         pipe = max(floors, key=floors.get)
-        common = {"pipe": pipe, "candidate_floors_us": {k: round(v * 1e6, 2) for k, v in floors.items()}, "traffic": None,
+        common = {"pipe": pipe, "candidate_floors_us": {k: round(v * 1e6, 2) for k, v in floors.items()},
+                  "traffic": plane_bytes, "traffic_note": "bytes of the three-plane layout the step kernel streams (6 B per padded value, "
+                                                          "1.5 x the algorithmic 4 B): layout arithmetic, not a PMC measurement",
                   "kernel": "K7 fused FastICA step on pre-split planes, k_ica3p (bf16x3 split-product, fp32 accumulate)", "piece_products": 6,
-                  "avg_launch_ms": round(avg, 5), "flops_per_launch": st["ica_step_flops"], "bytes_per_launch": plane_bytes,
+                  "avg_launch_ms": round(avg, 5), "flops_per_launch": st["ica_step_flops"], "bytes_per_launch": alg_bytes,
                   "fp32_equivalent_TFLOP/s": round(tf, 3),
                   "note": "the step kernel is 10 launches of a fit whose largest single launch is the split-product Gram kernel k_gram5 (timelines in profiles/)"}
         if pipe == "hbm":
-            gbs = plane_bytes / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+            gbs = alg_bytes / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **common}
         else:
             btf = 6.0 * tf

@@ -3963,6 +3963,147 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
     chol2_body(sm_chol, L, T, ldt, rel_tol, ndead_out, Lz, rt_form, ncount);
 }
 
+// ---- k_chol_rt<NB>: the re-basing Cholesky of the power iterations in the registers of ONE wave (round 6) ------------------------
+// G = R^T R for an order L <= 16 NB, "RT form" output (diagonal 16 x 16 blocks: T_JJ = R_JJ^-1, blocks above them: R, zeros below:
+// what k_trsm_pack reads).  k_chol_inv2 spends a third of its 28 us at l = 74 in barriers and LDS round trips between its phases;
+// here block (I, J), I <= J, of the working matrix sits in the accumulator layout of v_mfma_f64_16x16x4_f64 -- register m of lane
+// (g, c) = (lane >> 4, lane & 15) is element (g + 4 m, c) of the block -- which is at once
+//   * the layout the 16 x 16 diagonal factorisation wants: four rows of a column per lane; the multiplier of row k, S[k][i], sits in
+//     column i of the symmetric block, i.e. in lane i of the 16-lane row that holds row k -- a DPP row broadcast (row_newbcast, the
+//     one DPP control 64-bit operands have), where k_chol_inv2 sends five values per pivot through the LDS crossbar;
+//   * the B operand of an MFMA for the block itself and the A operand for its TRANSPOSE, k-slots declared as k' = (l >> 4) + 4 r,
+// so the panel R_JK = T_JJ^T S_JK and the trailing update S_KM -= R_JK^T R_JM take the registers as they are: no barrier, no LDS
+// image of the matrix, one 2-KB LDS transpose per block row (T_JJ^T, which the elimination of [S_JJ | I] leaves, -> T_JJ).
+// Blocks not yet factored are kept NEGATED (N = -S): the trailing update is a plain accumulation N_KM += R_JK^T R_JM.  One Newton
+// step on v_rsq_f64 (1.5 ulp): the factor only has to keep the re-based iterate well conditioned (backward error 6e-16 either way,
+// dev/chol1w.hip).  Measured there, over an empty kernel: 12.3 us at l = 74 (k_chol_inv2: 25), 43 us at l = 138 (72).  What is left
+// is the pivot chain (280 cycles x l: readlane -> rsq -> Newton -> scale -> update, issue-bound at ~35 instructions) and the MFMAs,
+// which a wave cannot overlap with its own VALU work (EXPERIMENTS.md round 6: interleaving them between the pivots gains nothing).
+__device__ __forceinline__ constexpr int chol_rt_idx(int NB, int I, int J) { return I * NB - (I * (I - 1)) / 2 + (J - I); }
+// compile-time loops: every block index is a constant expression, so the blocks are registers (a #pragma unroll the optimizer gives
+// up on turns the whole array into scratch memory)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void chol_static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        chol_static_for<I0 + 1, I1>(f);
+    }
+}
+#define CHOL_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+template <int NB>
+__global__ __launch_bounds__(64) void k_chol_rt(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T, int64_t ldt,
+                                                double rel_tol, int* __restrict__ ndead_out, int ncount) {
+    __shared__ double sm[16 * 17];
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    cf64x4 S[NB * (NB + 1) / 2];
+    double gd[NB];
+    // (clamped addresses and a select instead of predicated loads: no exec-mask branches in the load phase; the upper triangle only)
+    chol_static_for<0, NB>([&](auto Ic) {
+        constexpr int I = decltype(Ic)::value;
+        gd[I] = G[(int64_t)min(16 * I + c, L - 1) * (ldg + 1)];
+        gd[I] = (16 * I + c < L) ? gd[I] : 0.0;
+        chol_static_for<I, NB>([&](auto Jc) {
+            constexpr int J = decltype(Jc)::value;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int row = 16 * I + g + 4 * m, col = 16 * J + c;
+                const int rr = (I == J && row > col) ? col : row, cc = (I == J && row > col) ? row : col;
+                const double v = G[(int64_t)min(rr, L - 1) * ldg + min(cc, L - 1)];
+                S[chol_rt_idx(NB, I, J)][m] = (row < L && col < L) ? -v : 0.0;
+            }
+        });
+    });
+    chol_static_for<1, NB>([&](auto Ic) {
+        constexpr int I = decltype(Ic)::value;
+        chol_static_for<0, I>([&](auto Jc) {
+            constexpr int J = decltype(Jc)::value;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) T[(int64_t)(16 * I + g + 4 * m) * ldt + 16 * J + c] = 0.0;
+        });
+    });
+    int cdead = 0;
+    const int nlim = min(L, ncount);
+    chol_static_for<0, NB>([&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        const int jb = 16 * J;
+        cf64x4 D = -S[chol_rt_idx(NB, J, J)], Id;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) Id[m] = (g + 4 * m == c) ? 1.0 : 0.0;
+        // pivot i is accepted when it exceeds rel_tol x the original diagonal entry (which must be positive): a threshold per column
+        const double thr = (gd[J] > 0.0) ? rel_tol * gd[J] : __builtin_inf();
+        chol_static_for<0, 16>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, mi = i >> 2, gi = i & 3, src = 16 * gi;
+            const double dii = readlane_d(D[mi], src + i);
+            const double thi = readlane_d(thr, i);
+            const bool ok = dii > thi;
+            // the UNSCALED pivot row travels while the reciprocal square root is formed
+            const double su_c = bperm_d(D[mi], src + c), su_ci = bperm_d(Id[mi], src + c);
+            double y = __builtin_amdgcn_rsq(dii);
+            const double en = fma(-dii * y, y, 1.0);
+            y = fma(0.5 * y, en, y);
+            const double inv = ok ? y : 0.0;     // a dependent column is dropped: zero row of R, zero row and column of T_JJ
+            const double ninv2 = -(inv * inv);
+            // w = -S[i][c] / d_i: the update of row k is S[k][c] += S[k][i] w, S[k][i] by row broadcast from lane i
+            const double w = su_c * ninv2, wi = su_ci * ninv2;
+            {   // the register that holds row i: lanes g == gi scale it, g > gi update, g < gi are finished
+                double bk = __builtin_amdgcn_update_dpp(0.0, D[mi], 0x150 + i, 0xf, 0xf, false);
+                bk = (g > gi) ? bk : 0.0;
+                const double v = (g == gi) ? inv : 1.0;
+                Id[mi] = fma(bk, wi, Id[mi] * v);
+                D[mi] = fma(bk, w, D[mi] * v);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m <= mi) continue;
+                const double bk = __builtin_amdgcn_update_dpp(0.0, D[m], 0x150 + i, 0xf, 0xf, false);
+                Id[m] = fma(bk, wi, Id[m]);
+                D[m] = fma(bk, w, D[m]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (one pivot at a time: interleaving two only lengthens live ranges, the chain is serial)
+        });
+        // T_JJ^T (lower triangular, in Id) -> T_JJ through LDS
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sm[(g + 4 * m) * 17 + c] = Id[m];
+        cf64x4 A;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[r] = sm[c * 17 + g + 4 * r];
+        {
+            bool dead = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dead = dead || (g + 4 * r == c && jb + c < nlim && !(A[r] > 0.0));
+            cdead += __builtin_popcountll(__ballot(dead));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(int64_t)(jb + g + 4 * r) * ldt + jb + c] = A[r];
+        const cf64x4 negA = -A;
+        // the next diagonal block's inputs first: R_J,J+1 = (-T_JJ)^T N_J,J+1 and N_J+1,J+1 += R_J,J+1^T R_J,J+1
+        chol_static_for<J + 1, NB>([&](auto Kc) {
+            constexpr int K = decltype(Kc)::value;
+            cf64x4 acc = cf64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = CHOL_MFMA(negA[r], S[chol_rt_idx(NB, J, K)][r], acc);
+            S[chol_rt_idx(NB, J, K)] = acc;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) T[(int64_t)(jb + g + 4 * m) * ldt + 16 * K + c] = acc[m];
+            if constexpr (K == J + 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[chol_rt_idx(NB, K, K)] = CHOL_MFMA(acc[r], acc[r], S[chol_rt_idx(NB, K, K)]);
+            }
+        });
+        chol_static_for<J + 1, NB>([&](auto Kc) {
+            constexpr int K = decltype(Kc)::value;
+            chol_static_for<(K == J + 1 ? K + 1 : K), NB>([&](auto Mc) {
+                constexpr int Mb = decltype(Mc)::value;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    S[chol_rt_idx(NB, K, Mb)] = CHOL_MFMA(S[chol_rt_idx(NB, J, K)][r], S[chol_rt_idx(NB, J, Mb)][r], S[chol_rt_idx(NB, K, Mb)]);
+            });
+        });
+    });
+    if (lane == 0 && ndead_out && cdead > *ndead_out) *ndead_out = cdead;
+}
+#undef CHOL_MFMA
+
 // ---- convergence of a Jacobi sweep, graded matrices included ------------------------------------------------------------
 // Every matrix these solvers see is a Gram matrix (PSD, often with eigenvalues spread over many decades: B B^T of the
 // randomized SVD, the covariance of exact Pca / FastICA whitening).  A stopping rule on ||off||_F / ||diag||_F, the
@@ -7277,6 +7418,21 @@ static void chol_inv_blocked(Dev* d, const double* G, int64_t L, int64_t ldg, do
     dev_free(d, tmp); dev_free(d, gd); dev_free(d, R); dev_free(d, W);
 }
 
+// the re-basing factorisation in RT form (what k_trsm_pack reads): k_chol_rt on one wave for M = 16 NB <= 144
+static void launch_chol_rt(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t M) {
+    switch ((int)(M / 16)) {
+#define PETAL_CHOL_RT_CASE(NB)                                                                                                      \
+    case NB:                                                                                                                        \
+        hipLaunchKernelGGL((k_chol_rt<NB>), dim3(1), dim3(64), 0, d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead, (int)L);        \
+        break
+        PETAL_CHOL_RT_CASE(1); PETAL_CHOL_RT_CASE(2); PETAL_CHOL_RT_CASE(3); PETAL_CHOL_RT_CASE(4); PETAL_CHOL_RT_CASE(5);
+        PETAL_CHOL_RT_CASE(6); PETAL_CHOL_RT_CASE(7); PETAL_CHOL_RT_CASE(8); PETAL_CHOL_RT_CASE(9);
+#undef PETAL_CHOL_RT_CASE
+        default: throw std::logic_error("launch_chol_rt: order out of range");
+    }
+    launch_check();
+}
+
 // One re-basing step of the power iteration (see ops.h).  With the split-product kernels and L <= 140 the inverse of R is never
 // formed: k_chol_inv2 stops after the diagonal-block inverses ("RT form") and k_trsm_pack applies R^-1 by blocked substitution
 // while it packs the operand planes of the product that follows.
@@ -7291,10 +7447,7 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
         op_gemm_xp_prod(d, dt, X, n, K, ldx, mu, A, M, lda, T, M, ldt, P_out, ldpo, Z, ldz);
         return;
     }
-    set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
-    hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead,
-                       (int)M, (const double*)nullptr, 1, (int)L);
-    launch_check();
+    launch_chol_rt(d, G, L, ldg, T, ldt, rel_tol, ndead, M);
     gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, M, ldt, nullptr, Z, ldz, nullptr, A, M, lda, P_out, ldpo, true, nullptr, p_planes == 2, steering);
 }
 
@@ -8050,10 +8203,7 @@ bool op_rebase_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, i
                           double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering) {
     static const bool no_rt = getenv("PETAL_NO_TRSM") != nullptr || pow3_knob_off("PETAL_NO_P2_ITERATE");
     if (!pow3_ok(d, dt, X, n, K, ldx, mu, M, Z, ldz) || no_rt || L == 0 || L > CHOL2_MAXL || M > TRSM_MAXM || M < L || P_out == nullptr) return false;
-    set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
-    hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead,
-                       (int)M, (const double*)nullptr, 1, (int)L);
-    launch_check();
+    launch_chol_rt(d, G, L, ldg, T, ldt, rel_tol, ndead, M);
     const int NTtot = (int)(M / 16);
     const int64_t total = (K / 32) * (int64_t)NTtot * 64;
     bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
