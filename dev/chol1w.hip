@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 #include <type_traits>
+#include <cstdint>
 typedef double cf64x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double readlane_d(double x, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
@@ -23,6 +24,7 @@ __device__ __forceinline__ double rsqrt_pos(double d) {
     return y;
 }
 #include "chol1w_kernel.h"
+#include "chol4w_kernel.h"
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 static double urand(unsigned long long& s) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; return ((s >> 11) + 0.5) / 9007199254740992.0; }
@@ -30,7 +32,7 @@ static double nrand(unsigned long long& s) { const double u = urand(s), v = uran
 __global__ void k_empty(int* p) { if (p && threadIdx.x == 9999) *p = 1; }
 __global__ void k_copy(const double* a, double* b, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) b[i] = a[i]; }
 
-template <int NB, int NEWTON, bool IL = true>
+template <int NB, int NEWTON, bool IL = true, int KIND = 0>
 static void run(int L, double decay, int dead_col) {
     constexpr int M = 16 * NB;
     const int rows = 512;
@@ -57,8 +59,9 @@ static void run(int L, double decay, int dead_col) {
     hipMemcpy(dG, G.data(), sizeof(double) * M * M, hipMemcpyHostToDevice);
     hipMemcpy(dG0, G.data(), sizeof(double) * M * M, hipMemcpyHostToDevice);
     hipMemset(dT, 0xff, sizeof(double) * M * M); hipMemset(dnd, 0, 4);
-    hipLaunchKernelGGL((k_chol_rt<NB, NEWTON, IL>), dim3(1), dim3(64), 0, 0, dG, L, (long)M, dT, (long)M, 1e-14, dnd, L, dcyc);
-    hipDeviceSynchronize();
+    if (KIND == 0) hipLaunchKernelGGL((k_chol_rt<NB, NEWTON, IL>), dim3(1), dim3(64), 0, 0, dG, L, (long)M, dT, (long)M, 1e-14, dnd, L, dcyc);
+    else hipLaunchKernelGGL((k_chol_rt4<NB>), dim3(1), dim3(256), 0, 0, dG, L, (int64_t)M, dT, (int64_t)M, 1e-14, dnd, L);
+    if (hipDeviceSynchronize() != hipSuccess) printf("KERNEL FAILED\n");
     std::vector<double> T((size_t)M * M); int nd = -1; long long cyc[64];
     hipMemcpy(T.data(), dT, sizeof(double) * M * M, hipMemcpyDeviceToHost);
     hipMemcpy(&nd, dnd, 4, hipMemcpyDeviceToHost); hipMemcpy(cyc, dcyc, 8 * 64, hipMemcpyDeviceToHost);
@@ -105,7 +108,8 @@ static void run(int L, double decay, int dead_col) {
         hipEventRecord(e0);
         for (int i = 0; i < reps; ++i) {
             hipLaunchKernelGGL(k_copy, dim3((M * M + 255) / 256), dim3(256), 0, 0, dG0, dG, M * M);
-            hipLaunchKernelGGL((k_chol_rt<NB, NEWTON, IL>), dim3(1), dim3(64), 0, 0, dG, L, (long)M, dT, (long)M, 1e-14, dnd, L, (long long*)nullptr);
+            if (KIND == 0) hipLaunchKernelGGL((k_chol_rt<NB, NEWTON, IL>), dim3(1), dim3(64), 0, 0, dG, L, (long)M, dT, (long)M, 1e-14, dnd, L, (long long*)nullptr);
+            else hipLaunchKernelGGL((k_chol_rt4<NB>), dim3(1), dim3(256), 0, 0, dG, L, (int64_t)M, dT, (int64_t)M, 1e-14, dnd, L);
         }
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms_pair, e0, e1);
         hipEventRecord(e0);
@@ -118,26 +122,30 @@ static void run(int L, double decay, int dead_col) {
         for (int i = 0; i < 2 * reps; ++i) hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, 0, (int*)nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms_empty, e0, e1);
     }
-    printf("NB=%d il=%d L=%d newton=%d decay=%.3f dead=%d: backward err %.2e, junk outside the factor %.1e, ndead %d | in-kernel %lld cycles "
-           "(load %lld, rows:", NB, (int)IL, L, NEWTON, decay, dead_col, berr, worst_low, nd, cyc[63], cyc[0]);
+    printf("kind=%d NB=%d il=%d L=%d newton=%d decay=%.3f dead=%d: backward err %.2e, junk outside the factor %.1e, ndead %d | in-kernel %lld cycles "
+           "(load %lld, rows:", KIND, NB, (int)IL, L, NEWTON, decay, dead_col, berr, worst_low, nd, cyc[63], cyc[0]);
     for (int J = 0; J < NB; ++J) printf(" %lld+%lld", cyc[1 + 2 * J], cyc[2 + 2 * J]);
     printf(") | copy+chol %.2f us, copy+empty %.2f us, empty %.2f us -> chol over an empty kernel %.2f us\n", ms_pair * 1e3 / reps,
            ms_copy * 1e3 / reps, ms_empty * 1e3 / (2 * reps), (ms_pair - ms_copy) * 1e3 / reps);
     hipFree(dG); hipFree(dG0); hipFree(dT); hipFree(dnd); hipFree(dcyc);
 }
 int main() {
-    run<5, 2>(74, 0.85, -1);
-    run<5, 2, false>(74, 0.85, -1);
-    run<5, 1>(74, 0.85, -1);
-    run<5, 2>(74, 0.70, -1);
-    run<5, 2>(74, 0.85, 20);
-    run<5, 2>(80, 0.85, -1);
-    run<5, 2>(65, 0.85, -1);
-    run<3, 2>(48, 0.85, -1);
-    run<1, 2>(10, 0.85, -1);
-    run<9, 2>(138, 0.92, -1);
-    run<9, 2, false>(138, 0.92, -1);
-    run<9, 1>(138, 0.92, -1);
-    run<9, 2>(144, 0.92, 77);
+    run<5, 1, false>(74, 0.85, -1);
+    run<5, 1, false, 1>(74, 0.85, -1);
+    run<5, 1, false, 1>(74, 0.70, -1);
+    run<5, 1, false, 1>(74, 0.85, 20);
+    run<5, 1, false, 1>(80, 0.85, 79);
+    run<5, 1, false, 1>(65, 0.85, 0);
+    run<3, 1, false, 1>(48, 0.85, -1);
+    run<2, 1, false, 1>(20, 0.85, -1);
+    run<1, 1, false, 1>(10, 0.85, -1);
+    run<4, 1, false, 1>(64, 0.85, 33);
+    run<6, 1, false, 1>(90, 0.9, -1);
+    run<7, 1, false, 1>(100, 0.9, -1);
+    run<8, 1, false, 1>(128, 0.9, 5);
+    run<9, 1, false>(138, 0.92, -1);
+    run<9, 1, false, 1>(138, 0.92, -1);
+    run<9, 1, false, 1>(144, 0.92, 77);
+    run<9, 1, false, 1>(129, 0.95, 128);
     return 0;
 }

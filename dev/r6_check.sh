@@ -10,3 +10,7 @@ bash dev/tl.sh r6_${tag}_rp2 dev/rpca_one.py > /dev/null 2>&1
 bash dev/tl.sh r6_${tag}_rp4 dev/rpca_one.py cfg4 > /dev/null 2>&1
 grep -E "^#   " gpurun_out/tl_r6_${tag}_rp2.txt | head -12
 grep -E "^#   " gpurun_out/tl_r6_${tag}_rp4.txt | head -12
+if [ "$2" = "dbg" ]; then
+  bash dev/build_dbg.sh > /dev/null 2>&1
+  python dev/dbg_phases.py > gpurun_out/r6_${tag}_dbg_phases.txt 2>&1; tail -3 gpurun_out/r6_${tag}_dbg_phases.txt
+fi

@@ -87,10 +87,12 @@ typedef struct petal_stats {
                                   level 2, fit time - (xp + atb + pow + stream + allreduce) is the replicated small-matrix chain   */
     int64_t stream_launches;
     /* FastIca: how the last fit ran */
-    int64_t ica_redo;          /* 0: the optimistic run stood (two-product subspace iteration; for fp32 data of >= 384 features the
-                                  covariance from the split-product Gram kernels); 1: redone with the residual-controlled iteration
-                                  on the fp64-MFMA covariance (failed residual verdict, or kept eigenvalues spread over > 2 decades) */
+    int64_t ica_redo;          /* 0: the optimistic run stood (two-product subspace iteration; for fp32 data of >= 256 padded features the
+                                  covariance from the split-product Gram kernel); 1: redone with the residual-controlled iteration
+                                  on the fp64-MFMA covariance (failed residual verdict, or kept eigenvalues spread over > 1 decade)  */
     int64_t ica_gram_split;    /* 1: the covariance that reached the result came from the split-product Gram kernels              */
+    int64_t means_folded;      /* 1: the column means of the last fit were gathered INSIDE its first pass over X (RandomizedPca: the
+                                  first fused power-iteration pass; FastIca: the split-product Gram pass), 0: a means pass of its own */
 } petal_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -133,6 +135,33 @@ int         petal_ctx_set_profiling(petal_ctx* ctx, int profiling);
 #define PETAL_GEMM_FP32_MFMA 1
 #define PETAL_GEMM_SPLIT_BF16X3_EXACT 2
 int         petal_ctx_set_gemm_mode(petal_ctx* ctx, int mode);
+/* Options of a ctx.  Every switch that selects WHICH arithmetic or kernel form a fit runs is an option of the ctx: its default comes
+ * from the environment variable named with it, read ONCE at petal_ctx_create; afterwards only petal_ctx_set_option changes it (no
+ * library call reads the environment).  Options 0 - 8 change numerics within the documented parity bar; 9 - 13 are test / tooling aids.
+ * Unknown option: PETAL_INVALID_INPUT. */
+#define PETAL_OPT_TWO_PLANE_OPERANDS 0   /* (1) optimistic first run of an fp32 RandomizedPca fit: sketch matrix and re-based iterates on two bf16
+                                            planes behind the spectrum verdict; 0 = three planes throughout            PETAL_NO_P2=1 -> 0 */
+#define PETAL_OPT_TWO_PLANE_OMEGA 1      /* (1) ... the sketch matrix alone                                             PETAL_NO_P2_OMEGA=1 -> 0 */
+#define PETAL_OPT_TWO_PLANE_ITERATE 2    /* (1) ... the re-based iterates alone                                         PETAL_NO_P2_ITERATE=1 -> 0 */
+#define PETAL_OPT_STEERING_PASSES 3      /* (1) every pass before the last one rounds Xc and z to 16 bits as well        PETAL_NO_POW3_FAST=1 -> 0 */
+#define PETAL_OPT_FUSED_PASS 4           /* (1) Y' = Xc^T (Xc P) in one pass over X where the kernel exists              PETAL_NO_POW3=1 -> 0 */
+#define PETAL_OPT_FUSED_PASS_MIN_ROWS 5  /* (8192) fewer rows: the two GEMM kernels                                      PETAL_POW3_MIN_ROWS */
+#define PETAL_OPT_VERDICT_THRESHOLD 6    /* (4e-6) the verdict redoes a fit whose estimated component error exceeds it   PETAL_P2_VERDICT_THR */
+#define PETAL_OPT_MEANS_FOLD_ROWS 7      /* (200000) single-rank fp32 fits gather the column means inside their first pass from this many
+                                            rows on; negative: never                         PETAL_MEANS_FOLD_ROWS, PETAL_NO_MEANS_FOLD=1 -> -1 */
+#define PETAL_OPT_GRAM_SPLIT 8           /* (1) FastICA whitening of fp32 data: optimistic split-product covariance; 0 = fp64 products
+                                                                                                                         PETAL_NO_GRAM3=1 -> 0 */
+#define PETAL_OPT_GRAM_SPLIT_HOOK 9      /* (0) test hook: petal_gemm_atb sends Gram products to the split-product Gram kernel  PETAL_GRAM_SPLIT=1 */
+#define PETAL_OPT_D2H_KERNEL 10          /* (1) small results leave through a copy kernel into the pinned ring; 0 = hipMemcpyAsync
+                                                                                                                         PETAL_D2H_MEMCPY=1 -> 0 */
+#define PETAL_OPT_ROW_PAD 11             /* (1) copied inputs get 128 B of row padding when the natural pitch is a multiple of 1 KiB
+                                                                                                                         PETAL_NO_ROW_PAD=1 -> 0 */
+#define PETAL_OPT_EIGH_JACOBI 12         /* (0) symmetric eigenproblems go straight to the Jacobi solvers                 PETAL_EIGH_JACOBI=1 */
+#define PETAL_OPT_POISON 13              /* (0) every workspace block is filled with NaN patterns when handed out          PETAL_POISON=1 */
+#define PETAL_OPT_FORCE_COLLECTIVE 14    /* (0) a one-rank ctx with a collective installed still takes the sharded code path
+                                                                                                                         PETAL_FORCE_COLLECTIVE=1 */
+int         petal_ctx_set_option(petal_ctx* ctx, int option, double value);
+int         petal_ctx_get_option(const petal_ctx* ctx, int option, double* value);
 int         petal_get_stats(const petal_ctx* ctx, petal_stats* out);
 
 /* ---- Pca<A>::fit / fit_transform  (src/pca.rs:116-122, 153-167, 195-231) ---------------------- */

@@ -18,9 +18,37 @@
 
 namespace petal {
 
-struct Dev { int tag = 0; int gemm_mode = 1; };
+struct Dev { int tag = 0; int gemm_mode = 1; double opt[OPT_COUNT] = {}; };
 
-Dev* dev_create(int, void*, char*, size_t) { return new Dev(); }
+// the same option table as the device library (ops.h PetalOpt), defaults from the same environment variables, read once per ctx
+Dev* dev_create(int, void*, char*, size_t) {
+    Dev* d = new Dev();
+    auto on = [](const char* name) { return std::getenv(name) != nullptr; };
+    auto num = [](const char* name, double dflt) { const char* e = std::getenv(name); return e ? std::atof(e) : dflt; };
+    d->opt[OPT_TWO_PLANE] = on("PETAL_NO_P2") ? 0 : 1;
+    d->opt[OPT_TWO_PLANE_OMEGA] = on("PETAL_NO_P2_OMEGA") ? 0 : 1;
+    d->opt[OPT_TWO_PLANE_ITERATE] = on("PETAL_NO_P2_ITERATE") ? 0 : 1;
+    d->opt[OPT_STEERING] = on("PETAL_NO_POW3_FAST") ? 0 : 1;
+    d->opt[OPT_FUSED_PASS] = on("PETAL_NO_POW3") ? 0 : 1;
+    d->opt[OPT_FUSED_PASS_MIN_ROWS] = num("PETAL_POW3_MIN_ROWS", 8192);
+    d->opt[OPT_VERDICT_THRESHOLD] = num("PETAL_P2_VERDICT_THR", 4e-6);
+    d->opt[OPT_MEANS_FOLD_ROWS] = on("PETAL_NO_MEANS_FOLD") ? -1 : num("PETAL_MEANS_FOLD_ROWS", 200000);
+    d->opt[OPT_GRAM_SPLIT] = on("PETAL_NO_GRAM3") ? 0 : 1;
+    d->opt[OPT_GRAM_SPLIT_HOOK] = on("PETAL_GRAM_SPLIT") ? 1 : 0;
+    d->opt[OPT_D2H_KERNEL] = 1;
+    d->opt[OPT_ROW_PAD] = on("PETAL_NO_ROW_PAD") ? 0 : 1;
+    d->opt[OPT_EIGH_JACOBI] = on("PETAL_EIGH_JACOBI") ? 1 : 0;
+    d->opt[OPT_POISON] = 0;
+    return d;
+}
+void dev_set_option(Dev* d, int opt, double value) {
+    if (opt < 0 || opt >= OPT_COUNT) throw std::invalid_argument("unknown ctx option");
+    d->opt[opt] = value;
+}
+double dev_option(const Dev* d, int opt) {
+    if (opt < 0 || opt >= OPT_COUNT) throw std::invalid_argument("unknown ctx option");
+    return d->opt[opt];
+}
 void dev_destroy(Dev* d) { delete d; }
 void* dev_stream(Dev*) { return nullptr; }
 void* dev_alloc(Dev*, size_t bytes) {
@@ -110,7 +138,7 @@ static double two_plane(double v) {
 }
 void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P0,
                 int64_t N, int64_t ldp0, const void* bias, void* Z, int64_t ldz, double* sumsq, int p_planes, bool steering) {
-    const bool x2 = steering && p_planes == 2 && dt == F32 && d->gemm_mode == 0 && !sumsq && N > 80 && std::getenv("PETAL_NO_POW3_FAST") == nullptr;
+    const bool x2 = steering && p_planes == 2 && dt == F32 && d->gemm_mode == 0 && !sumsq && N > 80 && d->opt[OPT_STEERING] != 0;
     // (split-product mode, fp32 data: a caller that accepts a two-plane P gets one, as on the device)
     std::vector<double> p2;
     const double* P = P0;
@@ -139,7 +167,7 @@ void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx
 }
 void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const void* muA, const void* B, int64_t ldb,
                  int64_t N, const void* muB, int64_t n, double* C, int64_t ldc, bool precise, bool steering) {
-    const bool p4 = steering && !precise && dt == F32 && d->gemm_mode == 0 && N > 80 && std::getenv("PETAL_NO_POW3_FAST") == nullptr;
+    const bool p4 = steering && !precise && dt == F32 && d->gemm_mode == 0 && N > 80 && d->opt[OPT_STEERING] != 0;
     for (int64_t m = 0; m < M; ++m)
         for (int64_t j = 0; j < N; ++j) C[m * ldc + j] = 0;
     std::vector<double> a(M), b(N);
@@ -159,12 +187,12 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
 }
 bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc,
                    double* mu64_fold, double n_total) {
-    static const bool off = std::getenv("PETAL_NO_GRAM3") != nullptr;
+    const bool off = d->opt[OPT_GRAM_SPLIT] == 0;
     if (off || d->gemm_mode == 1 || n < 64 || dd < 4) return false;   // (the simulation takes every shape the split-product modes would)
     if (mu64_fold) {
         // the device path's arithmetic (hip_ops.hip, k_gram5 SUMS): a provisional centre from a strided row sample, the Gram matrix and
         // the column sums about it, then the move to the true centre
-        static const bool no_fold = std::getenv("PETAL_NO_MEANS_FOLD") != nullptr;
+        const bool no_fold = d->opt[OPT_MEANS_FOLD_ROWS] < 0;
         if (no_fold || !mu) return false;
         float* muT = static_cast<float*>(const_cast<void*>(mu));
         const float* x = static_cast<const float*>(X);
@@ -502,13 +530,13 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
 // the fused power-iteration pass: simulated for fp32 data in the split-product mode at ANY width (the device kernel exists for
 // K = 512, N <= 80), so that the host sequencing of the fused pipeline is covered by the CPU suite
 bool op_power_pass_applies(Dev* d, int dt, const void*, int64_t n, int64_t K, int64_t, const void*, int64_t N) {
-    static const bool off = std::getenv("PETAL_NO_POW3") != nullptr;
+    const bool off = d->opt[OPT_FUSED_PASS] == 0;
     return !off && dt == F32 && d->gemm_mode == 0 && n >= 64 && K % 16 == 0 && N % 16 == 0 && N <= 80;
 }
 bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
                    void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering) {
     if (!op_power_pass_applies(d, dt, X, n, K, ldx, mu, N)) return false;
-    const bool no_fast = std::getenv("PETAL_NO_POW3_FAST") != nullptr;
+    const bool no_fast = d->opt[OPT_STEERING] == 0;
     if (steering && !Z && !no_fast) {
         // the device's steering pass (k_pow3f): the centred X, the iterate and z each rounded to two bf16 planes
         std::vector<double> xc(size_t(n) * K), z(size_t(n) * N, 0.0), p2(size_t(K) * N);
@@ -541,7 +569,7 @@ bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t 
 }
 bool op_power_pass_means(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t dcols, int64_t ldx, double n_total, const double* P,
                          int64_t N, int64_t ldp, int64_t L, double* Y, int64_t ldy, double* mu64, void* muT, double* ssq_scratch, double* tv) {
-    static const bool off = std::getenv("PETAL_NO_MEANS_FOLD") != nullptr;
+    const bool off = d->opt[OPT_MEANS_FOLD_ROWS] < 0;
     if (off || L >= N || !op_power_pass_applies(d, dt, X, n, K, ldx, muT, N)) return false;
     // as on the device: a provisional centre from a strided row sample, the exact sums about it from the pass, then the move
     const int64_t ns = std::min<int64_t>(n, 4096), stride = n / ns;

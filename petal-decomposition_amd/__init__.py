@@ -26,6 +26,10 @@ PETAL_F32, PETAL_F64 = 0, 1
 PETAL_HOST, PETAL_DEVICE = 0, 1
 PETAL_SUM, PETAL_MAX, PETAL_MIN = 0, 1, 2
 GEMM_SPLIT_BF16X3, GEMM_FP32_MFMA, GEMM_SPLIT_BF16X3_EXACT = 0, 1, 2
+# petal_ctx_set_option (petal_hip.h PETAL_OPT_*): name -> option number
+OPTIONS = {"two_plane_operands": 0, "two_plane_omega": 1, "two_plane_iterate": 2, "steering_passes": 3, "fused_pass": 4,
+           "fused_pass_min_rows": 5, "verdict_threshold": 6, "means_fold_rows": 7, "gram_split": 8, "gram_split_hook": 9,
+           "d2h_kernel": 10, "row_pad": 11, "eigh_jacobi": 12, "poison": 13, "force_collective": 14}
 ICA_TEXTBOOK, ICA_REFERENCE_LITERAL = 0, 1
 
 
@@ -68,7 +72,8 @@ class petal_stats(C.Structure):
                 ("allreduce_ms", C.c_double), ("allreduce_timed", C.c_int64),
                 ("x_row_pitch_bytes", C.c_int64), ("x_zero_copy", C.c_int64),
                 ("rpca_redo", C.c_int64), ("pow_ms", C.c_double), ("pow_launches", C.c_int64),
-                ("stream_ms", C.c_double), ("stream_launches", C.c_int64), ("ica_redo", C.c_int64), ("ica_gram_split", C.c_int64)]
+                ("stream_ms", C.c_double), ("stream_launches", C.c_int64), ("ica_redo", C.c_int64), ("ica_gram_split", C.c_int64),
+                ("means_folded", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -87,6 +92,8 @@ ABI = [
     ("petal_ctx_set_collective", C.c_int, [_P, ALLREDUCE_FN, _P, C.c_int, C.c_int]),
     ("petal_ctx_set_profiling", C.c_int, [_P, C.c_int]),
     ("petal_ctx_set_gemm_mode", C.c_int, [_P, C.c_int]),
+    ("petal_ctx_set_option", C.c_int, [_P, C.c_int, C.c_double]),
+    ("petal_ctx_get_option", C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     ("petal_rccl_unique_id", C.c_int, [_P]),
     ("petal_ctx_init_rccl", C.c_int, [_P, _P, C.c_int, C.c_int]),
     ("petal_get_stats", C.c_int, [_P, C.POINTER(petal_stats)]),
@@ -253,6 +260,18 @@ class Context:
         if isinstance(mode, str):
             mode = {"bf16x3": GEMM_SPLIT_BF16X3, "fp32": GEMM_FP32_MFMA, "bf16x3-exact": GEMM_SPLIT_BF16X3_EXACT}[mode]
         self.check(self.lib.petal_ctx_set_gemm_mode(self._h, int(mode)))
+
+    def set_option(self, option, value) -> None:
+        """petal_ctx_set_option: `option` a PETAL_OPT_* number or its name in OPTIONS ("steering_passes", "means_fold_rows", ...).
+        The defaults were read from the environment once, when the ctx was created; nothing in the library reads it afterwards."""
+        opt = OPTIONS[option] if isinstance(option, str) else int(option)
+        self.check(self.lib.petal_ctx_set_option(self._h, opt, float(value)))
+
+    def get_option(self, option) -> float:
+        opt = OPTIONS[option] if isinstance(option, str) else int(option)
+        v = C.c_double(0.0)
+        self.check(self.lib.petal_ctx_get_option(self._h, opt, C.byref(v)))
+        return v.value
 
     def collective_info(self) -> dict:
         """kind ("none" / "hook" / "rccl"), rank / world_size as the ctx was told them, and -- for the built-in communicator -- what

@@ -432,7 +432,7 @@ DevMat ingest(petal_ctx& c, const petal_matrix& x) {
     // same few memory channels; the matrix is being copied anyway, so the copy lands with 128 more bytes per row (measured with
     // dev/pitch_probe.py, EXPERIMENTS.md round 3: K1 -5 %, K2 -7 % at 100000 x 512).  The padding is never read.
     m.ld = m.dp;
-    if (m.n >= 4096 && (size_t(m.dp) * esz) % 1024 == 0 && getenv("PETAL_NO_ROW_PAD") == nullptr) m.ld = m.dp + int64_t(128 / esz);
+    if (m.n >= 4096 && (size_t(m.dp) * esz) % 1024 == 0 && dev_option(c.dev, OPT_ROW_PAD) != 0) m.ld = m.dp + int64_t(128 / esz);
     m.owned = DBuf(c.dev, esz * size_t(m.n) * m.ld);
     m.p = m.owned.p;
     c.stats.x_row_pitch_bytes = int64_t(size_t(m.ld) * esz);
@@ -571,10 +571,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // (From 200000 rows on: at configs[1]'s 100000 x 512 the matrix sits in the Infinity Cache, the means pass costs 37 us and what
     // replaces it -- the sample's means, the all-ones column and the squares in the first pass, the move to the true centre -- costs
     // the same; at 1e6 rows the pass is 0.33 ms of HBM time and the fold takes 5 % off the fit.)
-    const char* fold_env = getenv("PETAL_MEANS_FOLD_ROWS");   // (read per fit: the tests lower it)
-    const int64_t fold_rows = fold_env ? (int64_t)atoll(fold_env) : (int64_t)200000;
-    const bool fold_means = !sharded(c) && tv_from_sq && dev_gemm_mode(c.dev) == 0 && n_iter >= 3 && L < LP && n >= fold_rows &&
-                            op_power_pass_applies(c.dev, dt, X.p, n, dp, X.ld, X.p, LP) && getenv("PETAL_NO_P2") == nullptr;
+    const double fold_rows = dev_option(c.dev, OPT_MEANS_FOLD_ROWS);   // (PETAL_OPT_MEANS_FOLD_ROWS; negative: never)
+    const bool fold_means = !sharded(c) && tv_from_sq && dev_gemm_mode(c.dev) == 0 && n_iter >= 3 && L < LP && fold_rows >= 0 && double(n) >= fold_rows &&
+                            op_power_pass_applies(c.dev, dt, X.p, n, dp, X.ld, X.p, LP) && dev_option(c.dev, OPT_TWO_PLANE) != 0;
     bool means_done = false, tv_direct = false;
     auto means_pass = [&] {
         if (!tv_from_sq) dev_memset(c.dev, mu64 + dp, 0, sizeof(double) * dp);
@@ -627,7 +626,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // pipeline with three planes everywhere (exact = true).  Nothing is remembered from fit to fit: the same input gives the same
     // bits whatever the ctx ran before (a caller who knows the data selects PETAL_GEMM_SPLIT_BF16X3_EXACT and skips the first run).
     const bool two_plane_applies = dt == F32 && dev_gemm_mode(c.dev) == 0 && n_iter > 0;
-    static const double p2_thr = [] { const char* e = getenv("PETAL_P2_VERDICT_THR"); return e ? atof(e) : 4e-6; }();
+    const double p2_thr = dev_option(c.dev, OPT_VERDICT_THRESHOLD);
     auto pipeline = [&](bool robust, bool exact) {
     const int planes = (n_iter > 0 && !robust && !exact) ? 2 : 3;
     if (robust || exact) dev_memset(c.dev, tvp, 0, sizeof(double) * (2 + LP));  // tv, ndead, lam (only lam[0 .. L) is written below); the first run's were cleared with Omega
@@ -701,7 +700,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
                 const bool last = it + 1 == n_iter;
                 dev_set_tag(c.dev, TAG_POW);
                 have_yp = op_rebase_power_pass(c.dev, dt, X.p, n, dp, X.ld, muT.p, G, L, LP, 1e-15, ndead, Yp, LP, LP, T.f64(), LP, Y.f64(), LP,
-                                               last ? Z.p : nullptr, LP, Yp, LP, /*steering=*/!last);   // pca.rs:714 + 711
+                                               last ? Z.p : nullptr, LP, Yp, LP, /*steering=*/steer && !last);   // pca.rs:714 + 711
+                // (steer: n_iter >= 3 -- the short iterations keep every pass at five / six piece products: ADVICE round 5)
                 dev_set_tag(c.dev, TAG_NONE);
                 if (have_yp) allreduce_f64(c, Yp, dp * LP + (last ? 1 : 0), PETAL_SUM);   // (the last one: [ Xc^T Z | sum Xc^2 ])
             }
@@ -817,9 +817,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     const void* hcomp = nullptr;
     std::vector<double> sg, keep;
     std::vector<char> comp_keep;
-    static const bool host_tl = getenv("PETAL_HOST_TIMELINE") != nullptr;
     double t_q = 0, t_s = 0;
-    static const bool never_p2 = getenv("PETAL_NO_P2") != nullptr;
+    const bool never_p2 = dev_option(c.dev, OPT_TWO_PLANE) == 0;
     bool robust = false, exact = !two_plane_applies || never_p2;
     for (int attempt = 0; attempt < 3; ++attempt) {
         pipeline(robust, exact);
@@ -895,7 +894,8 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         dev_h2d(c.dev, dsc.p, sc.data(), dsc.bytes);
         emit(c, dt, Uout, n, k, LP, *y_out, dsc.f64());
     }
-    if (host_tl) std::fprintf(stderr, "rpca_fit host: queued %.1f us, synced %.1f us, done %.1f us\n", t_q * 1e3, t_s * 1e3, timer.ms() * 1e3);
+    (void)t_q; (void)t_s;
+    c.stats.means_folded = tv_direct ? 1 : 0;
     finish_stats(c, timer);
 }
 
@@ -1348,7 +1348,10 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
         }
         dev_sync(c.dev);
         // (the split-product covariance stands only where its ~2e-6 lam_1 is small beside the smallest kept eigenvalue)
-        const bool spectrum_ok = !gram_fast || (hl2[0] > 0 && hl2[1] >= 1e-2 * hl2[0]);
+        // (within ONE decade: at the edge the covariance's error is 2e-5 of the smallest kept eigenvalue, which the whitening divides
+        // by -- the level of the crate's own f32 SVD whitening, ica.rs:189-208; the round-5 bound of two decades left 2e-4 there,
+        // ADVICE round 5)
+        const bool spectrum_ok = !gram_fast || (hl2[0] > 0 && hl2[1] >= 1e-1 * hl2[0]);
         return !agree_any(c, ((topk && optimistic) && !topk_verdict_ok(h3, vtol)) || !spectrum_ok);   // every rank redoes, or none
     };
     bool redone = false;
@@ -1369,6 +1372,7 @@ void fastica_fit(petal_ctx& c, const petal_matrix& x, int64_t n_components, doub
     }
     c.stats.ica_redo = redone ? 1 : 0;
     c.stats.ica_gram_split = gram_fast ? 1 : 0;
+    c.stats.means_folded = (fold_means && gram_fast) ? 1 : 0;
     finish_stats(c, timer);
 }
 
@@ -1581,7 +1585,7 @@ void gemm_atb(petal_ctx& c, const petal_matrix& a, const void* mu_a, const petal
     dev_set_tag(c.dev, TAG_ATB);
     // (test hook: PETAL_GRAM_SPLIT=1 sends a Gram matrix -- b == NULL, both sides centred alike -- to the split-product Gram kernels of
     // the FastICA whitening, so that the parity tests reach them on exact-integer data)
-    const bool gram_hook = !b && dt == F32 && ((mu_a == nullptr) == (mu_b == nullptr)) && getenv("PETAL_GRAM_SPLIT") != nullptr &&
+    const bool gram_hook = !b && dt == F32 && ((mu_a == nullptr) == (mu_b == nullptr)) && dev_option(c.dev, OPT_GRAM_SPLIT_HOOK) != 0 &&
                            (!mu_a || std::memcmp(ha.data(), hb.data(), ha.size()) == 0);
     if (!(gram_hook && op_gram_split(c.dev, A.p, A.n, M, A.dp, A.ld, mu_a ? muA.p : nullptr, C.f64(), A.dp)))
         op_gemm_atb(c.dev, dt, A.p, A.ld, A.dp, mu_a ? muA.p : nullptr, Bm.p, Bm.ld, Bm.dp, mu_b ? muB.p : nullptr, A.n, C.f64(), Bm.dp);

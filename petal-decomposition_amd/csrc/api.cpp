@@ -69,6 +69,7 @@ int petal_ctx_create(int device, void* stream, petal_ctx** out) {
         delete c;
         return PETAL_DEVICE_ERROR;
     }
+    c->force_collective = std::getenv("PETAL_FORCE_COLLECTIVE") != nullptr;   // (the default of PETAL_OPT_FORCE_COLLECTIVE)
     *out = c;
     return PETAL_OK;
 }
@@ -129,6 +130,22 @@ int petal_ctx_set_gemm_mode(petal_ctx* ctx, int mode) {
         if (mode != PETAL_GEMM_SPLIT_BF16X3 && mode != PETAL_GEMM_FP32_MFMA && mode != PETAL_GEMM_SPLIT_BF16X3_EXACT) invalid_input("unknown GEMM mode");
         dev_set_gemm_mode(ctx->dev, mode);
     });
+}
+
+int petal_ctx_set_option(petal_ctx* ctx, int option, double value) {
+    return guarded(ctx, [&] {
+        if (option == PETAL_OPT_FORCE_COLLECTIVE) { ctx->force_collective = value != 0; return; }
+        if (option < 0 || option >= OPT_COUNT || !(value == value)) invalid_input("unknown ctx option or NaN value");
+        dev_set_option(ctx->dev, option, value);
+    });
+}
+
+int petal_ctx_get_option(const petal_ctx* ctx, int option, double* value) {
+    if (!ctx || !value) return PETAL_INVALID_INPUT;
+    if (option == PETAL_OPT_FORCE_COLLECTIVE) { *value = ctx->force_collective ? 1.0 : 0.0; return PETAL_OK; }
+    if (option < 0 || option >= OPT_COUNT) return PETAL_INVALID_INPUT;
+    *value = dev_option(ctx->dev, option);
+    return PETAL_OK;
 }
 
 int petal_get_stats(const petal_ctx* ctx, petal_stats* out) {

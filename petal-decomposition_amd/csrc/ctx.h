@@ -18,6 +18,7 @@ struct petal_ctx {
     void* allreduce_user = nullptr;
     int rank = 0, world = 1;
     int profiling = 0;
+    bool force_collective = false;   // PETAL_OPT_FORCE_COLLECTIVE (default: env PETAL_FORCE_COLLECTIVE at petal_ctx_create)
     petal_stats stats{};
     void* rccl = nullptr;  // the built-in RCCL communicator (rccl.cpp), when petal_ctx_init_rccl installed it
     // the fixed pseudo-random start block of the subspace iteration (topk_eigh), kept on the device per shape: generating it on the
@@ -38,10 +39,10 @@ struct Error : std::runtime_error {
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-// true when the fit must take the sharded code path: several ranks, or PETAL_FORCE_COLLECTIVE=1 with a collective
+// true when the fit must take the sharded code path: several ranks, or PETAL_OPT_FORCE_COLLECTIVE with a collective
 // installed (runs the complete multi-rank path -- packing kernels, all-reduces -- on a one-rank group: test / timing aid)
 inline bool sharded(const petal_ctx& c) {
-    return c.world > 1 || (c.allreduce != nullptr && std::getenv("PETAL_FORCE_COLLECTIVE") != nullptr);
+    return c.world > 1 || (c.allreduce != nullptr && c.force_collective);
 }
 
 // rccl.cpp: the built-in collective

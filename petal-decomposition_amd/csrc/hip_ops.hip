@@ -8,12 +8,13 @@
 //     k_pow3       K3  Y' = Xc^T (Xc P)        the FUSED power iteration: one pass over X, P and Y' in registers, X planes through a
 //                                              swizzled LDS image read back transposed (ds_read_b64_tr_b16); 512 features, l <= 80
 //     k_gram5          C = Xc^T Xc (+ means)   256 x 256 tiles over row chunks, panels fetched in fragment order and split under the
-//                                              MFMAs, upper sub-tiles only (k_gram4 / k_gram3 + k_presplit_t: earlier forms, selectable)
+//                                              MFMAs, upper sub-tiles only
 //     k_ica3p      K7  fused FastICA step      on planes of X1 made once per loop (k_ica_planes); k_ica3: splits X1 every iteration
 //   fp32 MFMA kernels (GEMM mode "fp32": v_mfma_f32_16x16x4_f32): k_xp_mfma / k_xp_pers (K1), k_atb_mfma (K2), k_ica_mfma (K7)
 //   fp64 MFMA kernels (v_mfma_f64_16x16x4_f64): k_xp_f64, k_atb_f64 (K1 / K2 for fp64 data; the precise Gram matrix), k_syrk_f64,
 //     k_trsm_pack, k_dgemm / k_gemm_nn_f64
-//   one-workgroup fp64 small-matrix kernels: k_chol_inv2 (blocked Cholesky + inverse / RT form), k_tridiag_r / k_tridiag_w +
+//   one-workgroup fp64 small-matrix kernels: k_chol_rt4 (re-basing Cholesky, RT form, register-resident on four waves), k_chol_inv2 (blocked
+//     Cholesky + explicit inverse), k_tridiag_r / k_tridiag_w +
 //     k_trieig_r (symmetric eigenproblem up to order 138), k_jacobi_* (fallbacks and one-sided SVD), k_symdecorr / k_ica_tail
 //     (symmetric decorrelation: scaled Newton-Schulz polar factor in LDS)
 //   *_simple     generic (any shape, f32 / f64, fp64 accumulate) kernels for small / unaligned / f64 inputs
@@ -111,7 +112,8 @@ struct Dev {
     // caller's (pageable) buffers at the next dev_sync, instead of one blocking staged copy each
     char* pin = nullptr;
     char* pin_dev = nullptr;         // the ring's address as the device sees it
-    bool d2h_kernel = getenv("PETAL_D2H_MEMCPY") == nullptr;   // small results leave through a copy kernel (default) or hipMemcpyAsync
+    bool d2h_kernel = true;          // small results leave through a copy kernel (default) or hipMemcpyAsync: OPT_D2H_KERNEL
+    double opt[OPT_COUNT] = {};      // dev_option / dev_set_option (defaults: dev_defaults_from_env, once, at dev_create)
     size_t pin_cap = 0, pin_used = 0;
     struct Pend { void* dst; size_t off, bytes; };
     std::vector<Pend> pend;
@@ -131,6 +133,38 @@ struct Dev {
     int* progress = nullptr;  // pinned, device-writable: FastICA's tail kernel reports {converged at, iterations done} here
 };
 
+// The ONLY place the product reads its environment knobs (besides PETAL_GEMM / PETAL_FORCE_COLLECTIVE / PETAL_DEBUG at ctx creation):
+// defaults of the ctx options.  Everything after this goes through dev_option.
+static void dev_defaults_from_env(Dev* d) {
+    auto on = [](const char* name) { return getenv(name) != nullptr; };
+    auto num = [](const char* name, double dflt) { const char* e = getenv(name); return e ? atof(e) : dflt; };
+    d->opt[OPT_TWO_PLANE] = on("PETAL_NO_P2") ? 0 : 1;
+    d->opt[OPT_TWO_PLANE_OMEGA] = on("PETAL_NO_P2_OMEGA") ? 0 : 1;
+    d->opt[OPT_TWO_PLANE_ITERATE] = on("PETAL_NO_P2_ITERATE") ? 0 : 1;
+    d->opt[OPT_STEERING] = on("PETAL_NO_POW3_FAST") ? 0 : 1;
+    d->opt[OPT_FUSED_PASS] = on("PETAL_NO_POW3") ? 0 : 1;
+    d->opt[OPT_FUSED_PASS_MIN_ROWS] = num("PETAL_POW3_MIN_ROWS", 8192);
+    d->opt[OPT_VERDICT_THRESHOLD] = num("PETAL_P2_VERDICT_THR", 4e-6);
+    d->opt[OPT_MEANS_FOLD_ROWS] = on("PETAL_NO_MEANS_FOLD") ? -1 : num("PETAL_MEANS_FOLD_ROWS", 200000);
+    d->opt[OPT_GRAM_SPLIT] = on("PETAL_NO_GRAM3") ? 0 : 1;
+    d->opt[OPT_GRAM_SPLIT_HOOK] = on("PETAL_GRAM_SPLIT") ? 1 : 0;
+    d->opt[OPT_D2H_KERNEL] = on("PETAL_D2H_MEMCPY") ? 0 : 1;
+    d->opt[OPT_ROW_PAD] = on("PETAL_NO_ROW_PAD") ? 0 : 1;
+    d->opt[OPT_EIGH_JACOBI] = on("PETAL_EIGH_JACOBI") ? 1 : 0;
+    d->opt[OPT_POISON] = on("PETAL_POISON") ? 1 : 0;
+    d->d2h_kernel = d->opt[OPT_D2H_KERNEL] != 0;
+}
+void dev_set_option(Dev* d, int opt, double value) {
+    if (opt < 0 || opt >= OPT_COUNT) throw std::invalid_argument("unknown ctx option");
+    d->opt[opt] = value;
+    if (opt == OPT_D2H_KERNEL) d->d2h_kernel = value != 0;
+}
+double dev_option(const Dev* d, int opt) {
+    if (opt < 0 || opt >= OPT_COUNT) throw std::invalid_argument("unknown ctx option");
+    return d->opt[opt];
+}
+static inline bool opt_on(const Dev* d, int opt) { return d->opt[opt] != 0; }
+
 Dev* dev_create(int device, void* stream, char* err, size_t errlen) {
     auto fail = [&](const std::string& m) -> Dev* {
         if (err && errlen) std::snprintf(err, errlen, "%s", m.c_str());
@@ -148,6 +182,7 @@ Dev* dev_create(int device, void* stream, char* err, size_t errlen) {
         return fail(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
     Dev* d = new Dev();
     d->device = device;
+    dev_defaults_from_env(d);
     if (stream) {
         d->stream = static_cast<hipStream_t>(stream);
     } else {
@@ -224,8 +259,7 @@ void* dev_alloc(Dev* d, size_t bytes) {
     d->live[p] = sz;
     // PETAL_POISON=1 (test aid): every block handed out is filled with 0xFF bytes (NaN as fp32 / fp64), so a kernel that
     // reads memory it never wrote produces a visible NaN instead of depending on what the block held before
-    static const bool poison = getenv("PETAL_POISON") != nullptr;
-    if (poison) HIP_CHECK(hipMemsetAsync(p, 0xFF, sz, d->stream));
+    if (opt_on(d, OPT_POISON)) HIP_CHECK(hipMemsetAsync(p, 0xFF, sz, d->stream));
     return p;
 }
 
@@ -1409,158 +1443,6 @@ __global__ __launch_bounds__(64 * WVK, OCC) void k_xp3(const float* __restrict__
                 amax[plane + o] = any ? (double)((int64_t)blockIdx.x * (WVK * 16 * RT) + lrow) : (double)INFINITY;
                 amax[2 * plane + o] = (any && (key & 1)) ? -1.0 : 1.0;
             }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1, split-product form with the X stream on LDS-DMA ("k_xp4").  Same arithmetic, same MFMA order and therefore the same
-// bits as k_xp3; what changes is how the operands reach the wave.  k_xp3 prefetches ONE 32-column chunk of X per wave into
-// registers: in-kernel stamps (dev/xp3_phases.py) show the MFMA phase of a chunk at 2050 of ~4800 cycles and the rest of the
-// chunk waiting -- for loads that could only be issued one chunk ahead, and at the workgroup barrier for whichever of the four
-// waves waited longest.  Here every wave keeps a TWO-deep ring of its own 8-KB X chunks in LDS, filled by
-// global_load_lds_dwordx4 (no register destination, so the prefetch distance costs LDS, not VGPRs): chunk c + 2 is requested
-// as soon as chunk c has been read out of its slot and is needed two chunk-times later.  The P chunk (shared by the eight
-// waves of the one workgroup a CU holds: 2 x 64 KB of X rings + 2 x 15 KB of P + mu = the whole 160 KB) arrives the same way,
-// one chunk ahead.  Counted waits only: the wave's DMAs retire in order, so `s_waitcnt vmcnt(8)` -- the eight pieces of X
-// chunk c + 1 may stay in flight -- covers X chunk c and this wave's share of P chunk c; a raw s_barrier then publishes P
-// (no vmcnt(0) anywhere in the loop, which is what __syncthreads() would emit).
-// LDS images are lane-linear (a DMA piece = 64 lanes x 16 B = 1 KB, lane l at +16 l).
-typedef __attribute__((address_space(1))) const void* glds_src_t;
-typedef __attribute__((address_space(3))) void* glds_dst_t;
-template <int NT, bool CENTER>
-__global__ __launch_bounds__(512) void k_xp4(const float* __restrict__ X, int64_t n, int K, int64_t ldx, const float* __restrict__ mu,
-                                             const bf16x8* __restrict__ Ppk3, int NTtot, int nt0, int N,
-                                             const float* __restrict__ bias, float* __restrict__ Z, int64_t ldz) {
-    constexpr int RT = 4, WV = 8;
-    constexpr int PPIECES = NT * 3, PBYTES = PPIECES * 1024;       // P chunk: NT tiles x 3 planes, 1 KB each
-    constexpr int XSLOT = RT * 2 * 1024;                            // one X chunk of one wave
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm_xp4[];
-    unsigned char* const sXr = sm_xp4;                              // [WV][2][XSLOT]
-    unsigned char* const sPr = sm_xp4 + WV * 2 * XSLOT;             // [2][PBYTES]
-    float* const sMu = reinterpret_cast<float*>(sPr + 2 * PBYTES);  // [K]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 15, q = lane >> 4;
-    const int64_t row0 = ((int64_t)blockIdx.x * WV + wave) * (16 * RT);
-    const int nchunk = K >> 5;                                      // (the host sends K % 32 != 0 to k_xp3)
-    if (CENTER) {
-        for (int k = tid; k < K; k += 64 * WV) sMu[k] = mu[k];
-        __syncthreads();                                            // (before the first DMA: a plain barrier, nothing in flight)
-    }
-    f32x4 acc[RT][NT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int u = 0; u < NT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // DMA pieces are WHOLE cache lines: piece p = rows 8 p .. 8 p + 7 of the wave's 64, the 128 bytes of chunk c of each (lane l:
-    // row 8 p + (l >> 3), bytes 16 (l & 7) ..), so every line is requested by exactly one instruction.  (Fragment-shaped pieces
-    // -- 16 rows x 64 B, each line touched by two instructions -- issued at 300-500 cycles per instruction under load.)
-    // The ring slot is then the plain row-major image [64 rows][128 B] of the chunk.
-    const float* xrow[2 * RT];
-#pragma unroll
-    for (int p8 = 0; p8 < 2 * RT; ++p8) {
-        const int64_t r = row0 + 8 * p8 + (lane >> 3);
-        xrow[p8] = X + (r < n ? r : (n - 1)) * ldx + 4 * (lane & 7);
-    }
-    unsigned char* const myX = sXr + wave * 2 * XSLOT;
-    auto dma_x = [&](int c) {                                       // 8 pieces: chunk c of this wave's rows -> ring slot c & 1
-        unsigned char* dst = myX + (c & 1) * XSLOT;
-#pragma unroll
-        for (int p8 = 0; p8 < 2 * RT; ++p8)
-            __builtin_amdgcn_global_load_lds((glds_src_t)(xrow[p8] + 32 * c), (glds_dst_t)(dst + p8 * 1024), 16, 0, 0);
-    };
-    const bf16x8* const psrc = Ppk3 + (int64_t)nt0 * 192 + lane;
-    auto dma_p = [&](int c) {                                       // this wave's share of P chunk c (pieces wave, wave + 8)
-        unsigned char* dst = sPr + (c & 1) * PBYTES;
-        const bf16x8* src = psrc + (int64_t)c * NTtot * 192;
-#pragma unroll
-        for (int j = 0; j < (PPIECES + WV - 1) / WV; ++j) {
-            const int piece = wave + WV * j;
-            if (piece < PPIECES) __builtin_amdgcn_global_load_lds((glds_src_t)(src + piece * 64), (glds_dst_t)(dst + piece * 1024), 16, 0, 0);
-        }
-    };
-    dma_p(0);
-    dma_x(0);
-    if (nchunk > 1) dma_x(1);
-#ifdef PETAL_DEBUG_COUNTERS
-    long long ph[6] = {0, 0, 0, 0, 0, 0};
-    long long tq = __builtin_amdgcn_s_memtime();
-#define XP4_STAMP(i) do { const long long _t = __builtin_amdgcn_s_memtime(); ph[i] += _t - tq; tq = _t; } while (0)
-#else
-#define XP4_STAMP(i) do {} while (0)
-#endif
-    for (int c = 0; c < nchunk; ++c) {
-        // in flight, oldest first: [X(c)] P(c) [X(c + 1)] -- everything but the eight pieces of X(c + 1) must have landed
-        if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        XP4_STAMP(0);
-        __builtin_amdgcn_s_barrier();                               // every wave's share of P(c) is in; nobody reads P(c - 1) any more
-        asm volatile("" ::: "memory");
-        XP4_STAMP(1);
-        if (c + 1 < nchunk) dma_p(c + 1);                           // into the slot P(c - 1) just left
-        // X(c): out of the ring, centred, split
-        bf16x8 ah[RT], am[RT], al[RT];
-        {
-            const unsigned char* xs = myX + (c & 1) * XSLOT + i * 128 + q * 32;   // row 16 t + i, columns 8 q .. 8 q + 7
-            f32x8 m = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (CENTER) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(sMu + 32 * c + 8 * q), hi = *reinterpret_cast<const f32x4*>(sMu + 32 * c + 8 * q + 4);
-                m = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(xs + t * 2048), hi = *reinterpret_cast<const f32x4*>(xs + t * 2048 + 16);
-                f32x8 a = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                if (CENTER) a -= m;
-                split3(a, ah[t], am[t], al[t]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        XP4_STAMP(2);
-        if (c + 2 < nchunk) dma_x(c + 2);                           // the slot X(c) has just been read out of
-        __builtin_amdgcn_sched_barrier(0);
-        XP4_STAMP(3);
-        const bf16x8* sPb = reinterpret_cast<const bf16x8*>(sPr + (c & 1) * PBYTES) + lane;
-        bf16x8 bh = sPb[0], bm = sPb[64], bl = sPb[128];
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            bf16x8 nh = bh, nm = bm, nl = bl;
-            if (u + 1 < NT) { nh = sPb[(u * 3 + 3) * 64]; nm = sPb[(u * 3 + 4) * 64]; nl = sPb[(u * 3 + 5) * 64]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {  // (operand roles and order of the six piece products as in k_xp3: identical results)
-                f32x4 c4 = acc[t][u];
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[t], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[t], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[t], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[t], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[t], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[t], c4, 0, 0, 0);
-                acc[t][u] = c4;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            bh = nh; bm = nm; bl = nl;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        XP4_STAMP(4);
-    }
-#ifdef PETAL_DEBUG_COUNTERS
-    if (lane == 0) {
-        for (int e = 0; e < 6; ++e) atomicAdd((unsigned long long*)&g_cyc[20 + e], (unsigned long long)ph[e]);
-        atomicAdd((unsigned long long*)&g_cyc[26], 1ull);
-    }
-#endif
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        const int col = 16 * (nt0 + u) + 4 * q;
-        if (col >= N) continue;
-        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const int64_t row = row0 + 16 * t + i;
-            if (row < n) *reinterpret_cast<f32x4*>(Z + row * ldz + col) = acc[t][u] + bv;
         }
     }
 }
@@ -3489,185 +3371,7 @@ __global__ __launch_bounds__(64) void k_trsm_pack(const double* __restrict__ A, 
     }
 }
 
-// One workgroup.  The working copy of G lives in LDS as a packed upper triangle (L (L+1) / 2 doubles, 83.5 KB at
-// L = 144); T = R^-1 is built in LDS too when it fits, else directly in global memory.
-//   factorisation: right-looking, ONE barrier per column: rows are left unscaled (U[j][c], d_j = U[j][j]) and the
-//                  trailing update uses U[j][r] U[j][c] / d_j; R = diag(d)^-1/2 U is formed in one pass afterwards.
-//                  A pivot d_j <= rel_tol * G_jj (or G_jj <= 0) marks column j as dependent: row/column j := 0.
-//   inverse:       blocked (16 x 16): diagonal blocks by substitution, then block super-diagonals
-//                  T_IJ = -T_II (sum_K R_IK T_KJ): 1 + 3 (L/16 - 1) barriers.
 constexpr int CHOL_THREADS = 512;
-constexpr int CHOL_MAXL = 200;
-__device__ __forceinline__ int pk(int r, int c, int L) { return r * L - (r * (r - 1)) / 2 + (c - r); }
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T,
-                                                           int64_t ldt, double rel_tol, int t_mode, int* __restrict__ ndead_out, int Lz) {
-    extern __shared__ __attribute__((aligned(16))) double sm_chol[];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int np = L * (L + 1) / 2;
-    double* Rw = sm_chol;
-    double* gd = Rw + np;
-    int* dead = reinterpret_cast<int*>(gd + L);
-    // T storage: 0 = the global output itself, 1 = full square in LDS, 2 = packed upper triangle in LDS (only entries
-    // on or above the diagonal are ever touched below)
-    double* Tl = t_mode ? (gd + L + (L + 1) / 2) : T;
-    const int64_t tl = t_mode ? L : ldt;
-#define TI(r, c) (t_mode == 2 ? (int64_t)pk((r), (c), L) : (int64_t)(r) * tl + (c))
-    for (int e = tid; e < L * L; e += nt) {
-        const int r = e / L, c = e % L;
-        if (c >= r) Rw[pk(r, c, L)] = G[(int64_t)r * ldg + c];
-        if (c == r) gd[r] = G[(int64_t)r * ldg + c];
-        if (c >= r || t_mode != 2) Tl[TI(r, c)] = 0.0;
-    }
-    for (int e = tid; e < Lz * Lz; e += nt) {  // zero padding of the output beyond the factored block
-        const int r = e / Lz, c = e % Lz;
-        if (r >= L || c >= L) T[(int64_t)r * ldt + c] = 0.0;
-    }
-    __syncthreads();
-#ifdef PETAL_DEBUG_COUNTERS
-    long long _t0 = clock64();
-#endif
-    // ---- blocked (16) left-looking factorisation: 3 barriers per block row instead of one per column ----
-    {
-        const int nbk = (L + 15) / 16;
-        for (int J = 0; J < nbk; ++J) {
-            const int jb = 16 * J;
-            // (1) block row J -= (finished rows above)^T (finished rows above): threads = 16 rows x 32 column lanes
-            if (jb > 0) {
-                const int r = jb + (tid >> 5);
-                if (r < L) {
-                    for (int c = r + (tid & 31); c < L; c += 32) {
-                        double acc = 0;
-                        for (int k = 0; k < jb; ++k) acc += Rw[pk(k, r, L)] * Rw[pk(k, c, L)];
-                        Rw[pk(r, c, L)] -= acc;
-                    }
-                }
-            }
-            __syncthreads();
-            DBG_T(8);
-            // (2) diagonal block: one wave, column c of the block in the registers of lane c, pivots broadcast by readlane
-            if (tid < 64) {
-                const int c = jb + tid;
-                double a[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) a[i] = (tid < 16 && i <= tid && c < L) ? Rw[pk(jb + i, c, L)] : 0.0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    double sres = a[i];
-#pragma unroll
-                    for (int k = 0; k < i; ++k) sres -= __shfl(a[k], i, 64) * a[k];
-                    const double dii = __shfl(sres, i, 64);
-                    const double gi = (jb + i < L) ? gd[jb + i] : 0.0;
-                    const bool ok = (gi > 0.0) && (dii > rel_tol * gi);
-                    const double rii = ok ? sqrt(dii) : 0.0;
-                    a[i] = (!ok || tid < i) ? 0.0 : (tid == i ? rii : sres / rii);
-                    if (tid == 0 && jb + i < L) dead[jb + i] = ok ? 0 : 1;
-                }
-                if (tid < 16 && c < L) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (i <= tid) Rw[pk(jb + i, c, L)] = a[i];
-                }
-            }
-            __syncthreads();
-            DBG_T(9);
-            // (3) panel: R[jb.., c] = R_JJ^-T A[jb.., c] for every column right of the block (one thread per column)
-            {
-                const int c = jb + 16 + tid;
-                if (c < L) {
-                    double v[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = Rw[pk(jb + i, c, L)];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        double sres = v[i];
-#pragma unroll
-                        for (int k = 0; k < i; ++k) sres -= Rw[pk(jb + k, jb + i, L)] * v[k];
-                        const double rii = Rw[pk(jb + i, jb + i, L)];
-                        v[i] = rii > 0.0 ? sres / rii : 0.0;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) Rw[pk(jb + i, c, L)] = v[i];
-                }
-            }
-            __syncthreads();
-            DBG_T(10);
-        }
-        if (tid == 0 && ndead_out) { int cdead = 0; for (int j = 0; j < L; ++j) cdead += dead[j]; if (cdead > *ndead_out) *ndead_out = cdead; }
-        // dependent columns: zero the column above the (already zero) diagonal
-        for (int e = tid; e < L * L; e += nt) {
-            const int r = e / L, c = e % L;
-            if (c > r && dead[c]) Rw[pk(r, c, L)] = 0.0;
-        }
-        __syncthreads();
-    }
-    DBG_T(6);
-    // ---- blocked inverse ----
-    const int nb = (L + 15) / 16;
-    for (int t = tid; t < nb * 16; t += nt) {  // diagonal blocks: one thread per column, substitution inside the block
-        const int bI = t / 16, j = t;
-        if (j < L && !dead[j]) {
-            Tl[TI(j, j)] = 1.0 / Rw[pk(j, j, L)];
-            for (int r = j - 1; r >= 16 * bI; --r) {
-                if (dead[r]) continue;
-                double sacc = 0;
-                for (int k = r + 1; k <= j; ++k) sacc += Rw[pk(r, k, L)] * Tl[TI(k, j)];
-                Tl[TI(r, j)] = -sacc / Rw[pk(r, r, L)];
-            }
-        }
-    }
-    __syncthreads();
-    DBG_T(11);
-    for (int dl = 1; dl < nb; ++dl) {
-        const int nblk = nb - dl, nel = nblk * 256;
-        // (a) W_IJ = sum_{K = I+1 .. J} R_IK T_KJ, parked in T_IJ's (still zero) slot
-        for (int e = tid; e < nel; e += nt) {
-            const int bI = e / 256, r = 16 * bI + (e % 256) / 16, c = 16 * (bI + dl) + (e % 16);
-            if (r < L && c < L) {
-                double w = 0;
-                const int k1 = min(c + 1, 16 * (bI + dl + 1));  // T is upper triangular: T[k][c] = 0 for k > c
-                for (int k = 16 * (bI + 1); k < k1; ++k) w += Rw[pk(r, k, L)] * Tl[TI(k, c)];
-                Tl[TI(r, c)] = w;
-            }
-        }
-        __syncthreads();
-        DBG_T(12);
-        // (b) T_IJ = -T_II W_IJ (results held in registers across the barrier: W is overwritten in place)
-        double res[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int e = tid + it * nt;
-            res[it] = 0;
-            if (e < nel) {
-                const int bI = e / 256, r = 16 * bI + (e % 256) / 16, c = 16 * (bI + dl) + (e % 16);
-                if (r < L && c < L) {
-                    double t2 = 0;
-                    const int m1 = min(L, 16 * (bI + 1));
-                    for (int m = r; m < m1; ++m) t2 += Tl[TI(r, m)] * Tl[TI(m, c)];
-                    res[it] = -t2;
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int e = tid + it * nt;
-            if (e < nel) {
-                const int bI = e / 256, r = 16 * bI + (e % 256) / 16, c = 16 * (bI + dl) + (e % 16);
-                if (r < L && c < L) Tl[TI(r, c)] = res[it];
-            }
-        }
-        __syncthreads();
-        DBG_T(13);
-    }
-    DBG_T(7);
-    if (t_mode)
-        for (int e = tid; e < L * L; e += nt) {
-            const int r = e / L, c = e % L;
-            T[(int64_t)r * ldt + c] = (t_mode == 2) ? (c >= r ? Tl[pk(r, c, L)] : 0.0) : Tl[e];
-        }
-#undef TI
-}
-
 // ---- fast Cholesky-inverse for L <= 140: R and T both packed COLUMN-major in LDS (cp(k, c) = c (c + 1) / 2 + k, k <= c),
 // so every inner product below walks contiguous words with incremental addresses (no index arithmetic in the loops);
 // the 16 x 16 diagonal block is factored AND inverted in the registers of one wave (column c in lane c, pivots and
@@ -3963,23 +3667,30 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_inv2(const double* __rest
     chol2_body(sm_chol, L, T, ldt, rel_tol, ndead_out, Lz, rt_form, ncount);
 }
 
-// ---- k_chol_rt<NB>: the re-basing Cholesky of the power iterations in the registers of ONE wave (round 6) ------------------------
+// ---- k_chol_rt4<NB>: the re-basing Cholesky of the power iterations, register-resident on four waves (round 6) ----------------
 // G = R^T R for an order L <= 16 NB, "RT form" output (diagonal 16 x 16 blocks: T_JJ = R_JJ^-1, blocks above them: R, zeros below:
-// what k_trsm_pack reads).  k_chol_inv2 spends a third of its 28 us at l = 74 in barriers and LDS round trips between its phases;
-// here block (I, J), I <= J, of the working matrix sits in the accumulator layout of v_mfma_f64_16x16x4_f64 -- register m of lane
-// (g, c) = (lane >> 4, lane & 15) is element (g + 4 m, c) of the block -- which is at once
+// what k_trsm_pack reads).  k_chol_inv2 keeps the matrix in LDS and spends a third of its 28 us at l = 74 in barriers and LDS round
+// trips between its phases.  Here block (I, J), I <= J, of the working matrix lives in REGISTERS in the accumulator layout of
+// v_mfma_f64_16x16x4_f64 -- register m of lane (g, c) = (lane >> 4, lane & 15) is element (g + 4 m, c) of the block -- which is at once
 //   * the layout the 16 x 16 diagonal factorisation wants: four rows of a column per lane; the multiplier of row k, S[k][i], sits in
 //     column i of the symmetric block, i.e. in lane i of the 16-lane row that holds row k -- a DPP row broadcast (row_newbcast, the
 //     one DPP control 64-bit operands have), where k_chol_inv2 sends five values per pivot through the LDS crossbar;
 //   * the B operand of an MFMA for the block itself and the A operand for its TRANSPOSE, k-slots declared as k' = (l >> 4) + 4 r,
-// so the panel R_JK = T_JJ^T S_JK and the trailing update S_KM -= R_JK^T R_JM take the registers as they are: no barrier, no LDS
-// image of the matrix, one 2-KB LDS transpose per block row (T_JJ^T, which the elimination of [S_JJ | I] leaves, -> T_JJ).
-// Blocks not yet factored are kept NEGATED (N = -S): the trailing update is a plain accumulation N_KM += R_JK^T R_JM.  One Newton
-// step on v_rsq_f64 (1.5 ulp): the factor only has to keep the re-based iterate well conditioned (backward error 6e-16 either way,
-// dev/chol1w.hip).  Measured there, over an empty kernel: 12.3 us at l = 74 (k_chol_inv2: 25), 43 us at l = 138 (72).  What is left
-// is the pivot chain (280 cycles x l: readlane -> rsq -> Newton -> scale -> update, issue-bound at ~35 instructions) and the MFMAs,
-// which a wave cannot overlap with its own VALU work (EXPERIMENTS.md round 6: interleaving them between the pivots gains nothing).
-__device__ __forceinline__ constexpr int chol_rt_idx(int NB, int I, int J) { return I * NB - (I * (I - 1)) / 2 + (J - I); }
+// so the panel R_JK = T_JJ^T S_JK and the trailing update S_KM -= R_JK^T R_JM take the registers as they are; T_JJ^T is what the
+// elimination of [S_JJ | I] leaves, one 2-KB LDS transpose turns it into T_JJ.  Blocks not yet factored are kept NEGATED (N = -S):
+// the trailing update is a plain accumulation.  One Newton step on v_rsq_f64 (1.5 ulp): the factor only has to keep the re-based
+// iterate well conditioned (backward error 6e-16 either way, dev/chol1w.hip).
+// A wave cannot overlap its own MFMAs with its own VALU work (a ONE-wave form of this kernel, dev/chol1w_kernel.h: 12.0 us over an
+// empty kernel at l = 74, 41.7 at l = 138, and 78 in the fit, where its 75 KB of straight-line code arrive cold; interleaving the
+// MFMAs between the pivots gains nothing), so the three other matrix pipes of the CU take the panel and the trailing update while
+// wave 0 runs nothing but the pivot chain (280 cycles a pivot: readlane -> rsq -> Newton -> scale -> update, ~35 instructions):
+//   wave 0   factors the diagonal block D_J, publishes -T_JJ, forms R_J,J+1 and N_J+1,J+1 += R_J,J+1^T R_J,J+1 from the two blocks
+//            the owner of column J + 1 handed over, goes on;
+//   wave h   (1..3) owns whole block COLUMNS M >= 2: after -T_JJ is out it forms its panel blocks R_JM, publishes them, and after every
+//            panel is out updates its blocks N_KM += R_JK^T R_JM.
+// Two workgroup barriers per block row; what crosses them goes through LDS in register order (lane-contiguous 8-byte words: no bank
+// conflicts, no layout change).  Measured (dev/chol1w.hip, over an empty kernel): 9.5 us at l = 74 (k_chol_inv2: 25), 21.4 us at
+// l = 138 (72).
 // compile-time loops: every block index is a constant expression, so the blocks are registers (a #pragma unroll the optimizer gives
 // up on turns the whole array into scratch memory)
 template <int I0, int I1, class F>
@@ -3989,63 +3700,145 @@ __device__ __forceinline__ void chol_static_for(F&& f) {
         chol_static_for<I0 + 1, I1>(f);
     }
 }
-#define CHOL_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 template <int NB>
-__global__ __launch_bounds__(64) void k_chol_rt(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T, int64_t ldt,
-                                                double rel_tol, int* __restrict__ ndead_out, int ncount) {
-    __shared__ double sm[16 * 17];
-    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-    cf64x4 S[NB * (NB + 1) / 2];
-    double gd[NB];
-    // (clamped addresses and a select instead of predicated loads: no exec-mask branches in the load phase; the upper triangle only)
-    chol_static_for<0, NB>([&](auto Ic) {
-        constexpr int I = decltype(Ic)::value;
-        gd[I] = G[(int64_t)min(16 * I + c, L - 1) * (ldg + 1)];
-        gd[I] = (16 * I + c < L) ? gd[I] : 0.0;
-        chol_static_for<I, NB>([&](auto Jc) {
-            constexpr int J = decltype(Jc)::value;
+__device__ __forceinline__ constexpr int chol4_owner(int M) {   // columns dealt out from the last (longest) one, boustrophedon over the 3 helpers
+    const int idx = NB - 1 - M, round = idx / 3, pos = idx % 3;
+    return (round & 1) ? 3 - pos : 1 + pos;
+}
+// (not __syncthreads(): that also waits for the global stores of the factor -- vmcnt -- a microsecond per barrier; only LDS crosses here)
+__device__ __forceinline__ void chol4_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void chol4_put(double* slot, const cf64x4& v, int lane) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int row = 16 * I + g + 4 * m, col = 16 * J + c;
-                const int rr = (I == J && row > col) ? col : row, cc = (I == J && row > col) ? row : col;
-                const double v = G[(int64_t)min(rr, L - 1) * ldg + min(cc, L - 1)];
-                S[chol_rt_idx(NB, I, J)][m] = (row < L && col < L) ? -v : 0.0;
-            }
-        });
+    for (int r = 0; r < 4; ++r) slot[r * 64 + lane] = v[r];
+}
+__device__ __forceinline__ cf64x4 chol4_get(const double* slot, int lane) {
+    cf64x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = slot[r * 64 + lane];
+    return v;
+}
+// block (I, J) of G, negated, upper triangle only, zero beyond L (clamped addresses + select: no exec-mask branches)
+__device__ __forceinline__ cf64x4 chol4_load(const double* __restrict__ G, int L, int64_t ldg, int I, int J, int g, int c) {
+    cf64x4 v;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int row = 16 * I + g + 4 * m, col = 16 * J + c;
+        const int rr = (I == J && row > col) ? col : row, cc = (I == J && row > col) ? row : col;
+        const double x = G[(int64_t)min(rr, L - 1) * ldg + min(cc, L - 1)];
+        v[m] = (row < L && col < L) ? -x : 0.0;
+    }
+    return v;
+}
+__device__ __forceinline__ void chol4_store(double* __restrict__ T, int64_t ldt, int I, int J, int g, int c, const cf64x4& v) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) T[(int64_t)(16 * I + g + 4 * m) * ldt + 16 * J + c] = v[m];
+}
+#define CHOL4_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// helper wave H: all of its work, unrolled over the block rows (its blocks are registers)
+template <int NB, int H>
+__device__ __forceinline__ void chol4_helper(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T, int64_t ldt,
+                                             double* s_tjj, double* s_hand, double* s_panel, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    // S[M][K]: block (K, M) of an owned column M (K <= M); columns that are not mine stay unused (and cost nothing)
+    cf64x4 S[NB][NB];
+    chol_static_for<2, NB>([&](auto Mc) {
+        constexpr int M = decltype(Mc)::value;
+        if constexpr (chol4_owner<NB>(M) == H)
+            chol_static_for<0, M + 1>([&](auto Kc) { constexpr int K = decltype(Kc)::value; S[M][K] = chol4_load(G, L, ldg, K, M, g, c); });
     });
+    // zeros below the block diagonal of the output: rows I = H, H + 3, ...
     chol_static_for<1, NB>([&](auto Ic) {
         constexpr int I = decltype(Ic)::value;
-        chol_static_for<0, I>([&](auto Jc) {
-            constexpr int J = decltype(Jc)::value;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) T[(int64_t)(16 * I + g + 4 * m) * ldt + 16 * J + c] = 0.0;
-        });
+        if constexpr (I % 3 == H % 3)
+            chol_static_for<0, I>([&](auto Jc) { chol4_store(T, ldt, I, decltype(Jc)::value, g, c, cf64x4{0.0, 0.0, 0.0, 0.0}); });
     });
-    int cdead = 0;
-    const int nlim = min(L, ncount);
     chol_static_for<0, NB>([&](auto Jc) {
         constexpr int J = decltype(Jc)::value;
+        // hand column J + 1's two leading blocks to wave 0 (complete through block row J - 1; column 1 is wave 0's own)
+        if constexpr (J >= 1 && J + 1 < NB) {
+            if constexpr (chol4_owner<NB>(J + 1) == H) {
+                chol4_put(s_hand, S[J + 1][J], lane);
+                chol4_put(s_hand + 256, S[J + 1][J + 1], lane);
+            }
+        }
+        chol4_sync();   // barrier 1: -T_JJ is out
+        if constexpr (J + 2 < NB) {
+            const cf64x4 negA = chol4_get(s_tjj, lane);
+            chol_static_for<J + 2, NB>([&](auto Mc) {
+                constexpr int M = decltype(Mc)::value;
+                if constexpr (chol4_owner<NB>(M) == H) {
+                    cf64x4 acc = cf64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = CHOL4_MFMA(negA[r], S[M][J][r], acc);
+                    S[M][J] = acc;   // R_JM
+                    chol4_put(s_panel + ((J & 1) * NB + M) * 256, acc, lane);
+                    chol4_store(T, ldt, J, M, g, c, acc);
+                }
+            });
+        }
+        chol4_sync();   // barrier 2: every panel block of row J is out
+        if constexpr (J + 2 < NB) {
+            // N_KM += R_JK^T R_JM for my columns M >= J + 2, K = J + 1 .. M; R_JK read once per K
+            chol_static_for<J + 1, NB>([&](auto Kc) {
+                constexpr int K = decltype(Kc)::value;
+                constexpr bool any = [] { for (int M = (K > J + 2 ? K : J + 2); M < NB; ++M) if (chol4_owner<NB>(M) == H) return true; return false; }();
+                if constexpr (any) {
+                    const cf64x4 rk = chol4_get(s_panel + ((J & 1) * NB + K) * 256, lane);
+                    chol_static_for<(K > J + 2 ? K : J + 2), NB>([&](auto Mc) {
+                        constexpr int M = decltype(Mc)::value;
+                        if constexpr (chol4_owner<NB>(M) == H) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) S[M][K] = CHOL4_MFMA(rk[r], S[M][J][r], S[M][K]);
+                        }
+                    });
+                }
+            });
+        }
+    });
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_chol_rt4(const double* __restrict__ G, int L, int64_t ldg, double* __restrict__ T, int64_t ldt,
+                                                  double rel_tol, int* __restrict__ ndead_out, int ncount) {
+    __shared__ double s_tr[16 * 17];            // wave 0's transpose scratch
+    __shared__ double s_tjj[256];               // -T_JJ in register order
+    __shared__ double s_hand[512];              // the two blocks handed to wave 0
+    __shared__ double s_panel[2 * NB * 256];    // R_JM of block row J, double buffered
+    __shared__ double s_thr[16 * NB];           // the acceptance threshold of every pivot: rel_tol x the original diagonal
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave == 1) { chol4_helper<NB, 1>(G, L, ldg, T, ldt, s_tjj, s_hand, s_panel, lane); return; }
+    if (wave == 2) { chol4_helper<NB, 2>(G, L, ldg, T, ldt, s_tjj, s_hand, s_panel, lane); return; }
+    if (wave == 3) { chol4_helper<NB, 3>(G, L, ldg, T, ldt, s_tjj, s_hand, s_panel, lane); return; }
+    const int c = lane & 15, g = lane >> 4;
+    cf64x4 D = -chol4_load(G, L, ldg, 0, 0, g, c);
+    cf64x4 Off = cf64x4{0.0, 0.0, 0.0, 0.0}, Next = cf64x4{0.0, 0.0, 0.0, 0.0};
+    if (NB > 1) { Off = chol4_load(G, L, ldg, 0, 1, g, c); Next = chol4_load(G, L, ldg, 1, 1, g, c); }
+    int cdead = 0;
+    const int nlim = min(L, ncount);
+    for (int e = lane; e < 16 * NB; e += 64) {
+        const double gdj = G[(int64_t)min(e, L - 1) * (ldg + 1)];
+        s_thr[e] = (e < L && gdj > 0.0) ? rel_tol * gdj : __builtin_inf();
+    }
+    for (int J = 0; J < NB; ++J) {
         const int jb = 16 * J;
-        cf64x4 D = -S[chol_rt_idx(NB, J, J)], Id;
+        const double thr = s_thr[jb + c];       // (wave 0's own writes: LDS operations of a wave stay in order)
+        cf64x4 Id;
 #pragma unroll
         for (int m = 0; m < 4; ++m) Id[m] = (g + 4 * m == c) ? 1.0 : 0.0;
-        // pivot i is accepted when it exceeds rel_tol x the original diagonal entry (which must be positive): a threshold per column
-        const double thr = (gd[J] > 0.0) ? rel_tol * gd[J] : __builtin_inf();
         chol_static_for<0, 16>([&](auto ic) {
             constexpr int i = decltype(ic)::value, mi = i >> 2, gi = i & 3, src = 16 * gi;
             const double dii = readlane_d(D[mi], src + i);
             const double thi = readlane_d(thr, i);
             const bool ok = dii > thi;
-            // the UNSCALED pivot row travels while the reciprocal square root is formed
             const double su_c = bperm_d(D[mi], src + c), su_ci = bperm_d(Id[mi], src + c);
             double y = __builtin_amdgcn_rsq(dii);
             const double en = fma(-dii * y, y, 1.0);
             y = fma(0.5 * y, en, y);
-            const double inv = ok ? y : 0.0;     // a dependent column is dropped: zero row of R, zero row and column of T_JJ
+            const double inv = ok ? y : 0.0;
             const double ninv2 = -(inv * inv);
-            // w = -S[i][c] / d_i: the update of row k is S[k][c] += S[k][i] w, S[k][i] by row broadcast from lane i
             const double w = su_c * ninv2, wi = su_ci * ninv2;
-            {   // the register that holds row i: lanes g == gi scale it, g > gi update, g < gi are finished
+            {
                 double bk = __builtin_amdgcn_update_dpp(0.0, D[mi], 0x150 + i, 0xf, 0xf, false);
                 bk = (g > gi) ? bk : 0.0;
                 const double v = (g == gi) ? inv : 1.0;
@@ -4059,14 +3852,15 @@ __global__ __launch_bounds__(64) void k_chol_rt(const double* __restrict__ G, in
                 Id[m] = fma(bk, wi, Id[m]);
                 D[m] = fma(bk, w, D[m]);
             }
-            __builtin_amdgcn_sched_barrier(0);   // (one pivot at a time: interleaving two only lengthens live ranges, the chain is serial)
+            __builtin_amdgcn_sched_barrier(0);
         });
-        // T_JJ^T (lower triangular, in Id) -> T_JJ through LDS
 #pragma unroll
-        for (int m = 0; m < 4; ++m) sm[(g + 4 * m) * 17 + c] = Id[m];
+        for (int m = 0; m < 4; ++m) s_tr[(g + 4 * m) * 17 + c] = Id[m];
         cf64x4 A;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) A[r] = sm[c * 17 + g + 4 * r];
+        for (int r = 0; r < 4; ++r) A[r] = s_tr[c * 17 + g + 4 * r];
+        const cf64x4 negA = -A;
+        chol4_put(s_tjj, negA, lane);
         {
             bool dead = false;
 #pragma unroll
@@ -4075,34 +3869,26 @@ __global__ __launch_bounds__(64) void k_chol_rt(const double* __restrict__ G, in
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) T[(int64_t)(jb + g + 4 * r) * ldt + jb + c] = A[r];
-        const cf64x4 negA = -A;
-        // the next diagonal block's inputs first: R_J,J+1 = (-T_JJ)^T N_J,J+1 and N_J+1,J+1 += R_J,J+1^T R_J,J+1
-        chol_static_for<J + 1, NB>([&](auto Kc) {
-            constexpr int K = decltype(Kc)::value;
-            cf64x4 acc = cf64x4{0.0, 0.0, 0.0, 0.0};
+        chol4_sync();   // barrier 1
+        cf64x4 R = cf64x4{0.0, 0.0, 0.0, 0.0};
+        if (J + 1 < NB) {
+            if (J > 0) { Off = chol4_get(s_hand, lane); Next = chol4_get(s_hand + 256, lane); }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = CHOL_MFMA(negA[r], S[chol_rt_idx(NB, J, K)][r], acc);
-            S[chol_rt_idx(NB, J, K)] = acc;
+            for (int r = 0; r < 4; ++r) R = CHOL4_MFMA(negA[r], Off[r], R);
+            chol4_put(s_panel + ((J & 1) * NB + J + 1) * 256, R, lane);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) T[(int64_t)(jb + g + 4 * m) * ldt + 16 * K + c] = acc[m];
-            if constexpr (K == J + 1) {
+            for (int m = 0; m < 4; ++m) T[(int64_t)(jb + g + 4 * m) * ldt + jb + 16 + c] = R[m];
+        }
+        chol4_sync();   // barrier 2
+        if (J + 1 < NB) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S[chol_rt_idx(NB, K, K)] = CHOL_MFMA(acc[r], acc[r], S[chol_rt_idx(NB, K, K)]);
-            }
-        });
-        chol_static_for<J + 1, NB>([&](auto Kc) {
-            constexpr int K = decltype(Kc)::value;
-            chol_static_for<(K == J + 1 ? K + 1 : K), NB>([&](auto Mc) {
-                constexpr int Mb = decltype(Mc)::value;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    S[chol_rt_idx(NB, K, Mb)] = CHOL_MFMA(S[chol_rt_idx(NB, J, K)][r], S[chol_rt_idx(NB, J, Mb)][r], S[chol_rt_idx(NB, K, Mb)]);
-            });
-        });
-    });
+            for (int r = 0; r < 4; ++r) Next = CHOL4_MFMA(R[r], R[r], Next);
+            D = -Next;
+        }
+    }
     if (lane == 0 && ndead_out && cdead > *ndead_out) *ndead_out = cdead;
 }
-#undef CHOL_MFMA
+#undef CHOL4_MFMA
 
 // ---- convergence of a Jacobi sweep, graded matrices included ------------------------------------------------------------
 // Every matrix these solvers see is a Gram matrix (PSD, often with eigenvalues spread over many decades: B B^T of the
@@ -4611,89 +4397,6 @@ __global__ __launch_bounds__(1024) void k_jacobi_a(const double* __restrict__ Ai
 // Accuracy is that of a backward-stable dense method, eps ||A|| absolute in the eigenvalues.  Eigenvectors of eigenvalues
 // closer than 1e-10 ||A|| (rank deficiency, exact multiplicities) are not guaranteed orthogonal by this route: k_trieig
 // leaves the verdict in `flag` and the Jacobi solver, launched behind it, runs only then (it returns at once otherwise).
-constexpr int TRI_THREADS = 512;
-template <bool INLDS>
-__global__ __launch_bounds__(TRI_THREADS) void k_tridiag(const double* __restrict__ A, int L, int64_t lda, double* __restrict__ Wg,
-                                                         double* __restrict__ dd, double* __restrict__ ee, double* __restrict__ HV,
-                                                         double* __restrict__ tau) {
-    extern __shared__ __attribute__((aligned(16))) double sm_tri[];
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
-    const int ld = L | 1;
-    double* W = INLDS ? sm_tri : Wg;                          // working copy of A (full symmetric), leading dimension ld
-    double* sv = INLDS ? sm_tri + (size_t)L * ld : sm_tri;    // Householder vector of the step
-    double* sp = sv + L;                                      // p = tau A22 v
-    double* s_red = sp + L;                                   // 2 x 16 partial sums
-    for (int e = tid; e < L * L; e += nt) {
-        const int r = e / L, c = e - r * L;
-        W[(size_t)r * ld + c] = A[(int64_t)r * lda + c];
-    }
-    for (int e = tid; e < L * L; e += nt) HV[e] = 0.0;
-    __syncthreads();
-    auto block_sum2 = [&](double a, double b, double& ta, double& tb) {  // two sums at once, to every thread
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
-        if (lane == 0) { s_red[wv] = a; s_red[16 + wv] = b; }
-        __syncthreads();
-        ta = 0; tb = 0;
-        for (int x = 0; x < nw; ++x) { ta += s_red[x]; tb += s_red[16 + x]; }
-        __syncthreads();
-    };
-    for (int k = 0; k + 2 < L; ++k) {
-        const int m = L - k - 1;                               // order of the trailing block, rows / columns k + 1 ..
-        const double* colk = W + (size_t)(k + 1) * ld + k;     // x_i = W[k + 1 + i][k]
-        // (strided over the column: the trailing block may be longer than the workgroup, orders up to 2048 come here)
-        double sq = 0;
-        for (int i = tid; i < m; i += nt) { const double xi = colk[(size_t)i * ld]; sq += i > 0 ? xi * xi : 0.0; }
-        double sigma, dummy;
-        block_sum2(sq, 0.0, sigma, dummy);
-        const double alpha = colk[0];
-        double beta = alpha, tk = 0.0, scale = 0.0;
-        if (sigma > 0.0) {
-            beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
-            tk = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
-        }
-        for (int i = tid; i < m; i += nt) {
-            const double vi = i == 0 ? 1.0 : colk[(size_t)i * ld] * scale;
-            sv[i] = vi;
-            HV[(size_t)k * L + k + 1 + i] = vi;                // reflector k: row k of HV, entries k + 1 .. L - 1
-        }
-        if (tid == 0) { dd[k] = W[(size_t)k * ld + k]; ee[k] = beta; tau[k] = tk; }
-        __syncthreads();
-        if (tk != 0.0) {                                        // (uniform)
-            // p = tau A22 v, eight lanes per row; and p^T v
-            double pv = 0;
-            for (int i = tid >> 3; i < m; i += nt >> 3) {
-                const double* row = W + (size_t)(k + 1 + i) * ld + k + 1;
-                double acc = 0;
-                for (int j = tid & 7; j < m; j += 8) acc += row[j] * sv[j];
-                acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-                if ((tid & 7) == 0) { const double pi = tk * acc; sp[i] = pi; pv += pi * sv[i]; }
-            }
-            double tpv;
-            block_sum2(pv, 0.0, tpv, dummy);                    // (its barriers also publish sp)
-            const double K = -0.5 * tk * tpv;
-            // A22 -= v w^T + w v^T with w = p + K v
-            for (int e = tid; e < m * m; e += nt) {
-                const int i = e / m, j = e - i * m;
-                const double vi = sv[i], vj = sv[j];
-                const double wi = sp[i] + K * vi, wj = sp[j] + K * vj;
-                W[(size_t)(k + 1 + i) * ld + k + 1 + j] -= vi * wj + wi * vj;
-            }
-            __syncthreads();
-        }
-    }
-    if (tid == 0) {
-        if (L >= 2) {
-            dd[L - 2] = W[(size_t)(L - 2) * ld + L - 2];
-            ee[L - 2] = W[(size_t)(L - 1) * ld + L - 2];
-            tau[L - 2] = 0.0;
-        }
-        dd[L - 1] = W[(size_t)(L - 1) * ld + L - 1];
-        ee[L - 1] = 0.0;
-        tau[L - 1] = 0.0;
-    }
-}
-
 // ---- the same reduction for orders beyond the LDS (139 ... 2048), ONE LAUNCH PER STEP on the whole chip (round 4).  k_tridiag
 // walks such a matrix with one workgroup and its working copy in global memory: 29 ms at order 512, which is where an exact Pca of
 // data without a spectral gap behind its k components ends up (the subspace iteration cannot converge there and the d x d
@@ -6547,10 +6250,10 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         // two-plane P (five piece products) where P is the re-based iterate of a power iteration: k_trsm_pack rounds it so
         // (development / test knobs: PETAL_NO_P2 keeps three planes everywhere, PETAL_NO_P2_ITERATE for the re-based iterate only,
         // PETAL_NO_P2_OMEGA for the sketch matrix only)
-        static const bool no_p2 = getenv("PETAL_NO_P2") != nullptr;
-        static const bool no_p2_it = no_p2 || getenv("PETAL_NO_P2_ITERATE") != nullptr, no_p2_om = no_p2 || getenv("PETAL_NO_P2_OMEGA") != nullptr;
+        const bool no_p2 = !opt_on(d, OPT_TWO_PLANE);
+        const bool no_p2_it = no_p2 || !opt_on(d, OPT_TWO_PLANE_ITERATE), no_p2_om = no_p2 || !opt_on(d, OPT_TWO_PLANE_OMEGA);
         const bool p2 = p2_hint && ((prod_A && prod_rt && !no_p2_it) || (!prod_A && !no_p2_om)) && !am;
-        const bool x2 = p2 && steering && getenv("PETAL_NO_POW3_FAST") == nullptr;   // (a steering pass: X on two planes too; the wide form only)
+        const bool x2 = p2 && steering && opt_on(d, OPT_STEERING);   // (a steering pass: X on two planes too; the wide form only)
         if (prod_A) {
             // P = prod_A . P: the fp64 GEMM kernel writes the product (prod_out) AND its operand planes from its epilogue
             if (prod_rt)   // P is R in RT form: blocked triangular solve instead of the product with the explicit inverse
@@ -6624,30 +6327,6 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
                 else hipLaunchKernelGGL((k_xp3<RTw, NTv, DPv, false, 4, PETAL_XP3_OCC, NPLv>), dim3(blocksw), dim3(256), lds, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz, am_part, am_ld); \
             } while (0)
 #define XP3_LAUNCH(RTw, NTv) do { if (p2) XP3_LAUNCHP(RTw, NTv, 2); else XP3_LAUNCHP(RTw, NTv, 3); } while (0)
-            // LDS-DMA ring form (k_xp4): whole 32-column chunks, mu + rings within the 160 KB of one workgroup per CU
-            // (measured slower than k_xp3 -- 68 vs 62 us at 100000 x 512, 594 vs 570 us at 1e6 -- so it is opt-in: DESIGN section 9)
-            static const int xp4_env = [] { const char* e = getenv("PETAL_XP4"); return e ? atoi(e) : 0; }();
-            const size_t lds4 = (size_t)8 * 2 * 8192 + (size_t)2 * w * 3 * 1024 + (muf ? sizeof(float) * K : 0);
-            if (xp4_env && !am && K % 32 == 0 && K >= 64 && lds4 <= 160 * 1024 && n >= 512) {
-#define XP4_LAUNCH(NTv)                                                                                                                   \
-                do {                                                                                                                        \
-                    const int blocks4 = cdiv(n, 512);                                                                                       \
-                    set_max_lds(d, muf ? reinterpret_cast<const void*>(k_xp4<NTv, true>) : reinterpret_cast<const void*>(k_xp4<NTv, false>)); \
-                    if (muf) hipLaunchKernelGGL((k_xp4<NTv, true>), dim3(blocks4), dim3(512), lds4, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
-                    else hipLaunchKernelGGL((k_xp4<NTv, false>), dim3(blocks4), dim3(512), lds4, d->stream, Xf, n, (int)K, ldx, muf, Ppk3, NTtot, nt0, (int)N, bf, Zf, ldz); \
-                } while (0)
-                switch (w) {
-                    case 5: XP4_LAUNCH(5); break;
-                    case 4: XP4_LAUNCH(4); break;
-                    case 3: XP4_LAUNCH(3); break;
-                    case 2: XP4_LAUNCH(2); break;
-                    default: XP4_LAUNCH(1); break;
-                }
-#undef XP4_LAUNCH
-                launch_check();
-                nt0 += w;
-                continue;
-            }
             switch (w) {
                 case 5: XP3_LAUNCH(RTv, 5); break;
                 case 4: XP3_LAUNCH(RTv, 4); break;
@@ -6678,8 +6357,7 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         hipLaunchKernelGGL(k_pack_p, dim3(cdiv(total, 256)), dim3(256), 0, d->stream, P, K, N, ldp, Ppk, NTtot);
         launch_check();
     }
-    static const bool use_classic = [] { const char* e = getenv("PETAL_K1_CLASSIC"); return e && e[0] == '1'; }();
-    static const bool force_pers = [] { const char* e = getenv("PETAL_K1_PERS"); return e && e[0] == '1'; }();
+    constexpr bool use_classic = false, force_pers = false;
     const int num_cu = num_cus(d);
     // Form selection (measured, MI355X): with fewer than two 64-row tiles per wave slot the grid form leaves SIMDs
     // a whole 64-row tile apart (100000 x 512: 74 TFLOP/s) and the balanced persistent form wins (84); with many tiles
@@ -6772,7 +6450,7 @@ static void launch_atb(Dev* d, const float* A, int64_t lda, int M, const float* 
 void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const void* muA, const void* B, int64_t ldb, int64_t N,
                  const void* muB, int64_t n, double* C, int64_t ldc, bool precise, bool steering) {
     if (M == 0 || N == 0) return;
-    const bool p4 = steering && !precise && getenv("PETAL_NO_POW3_FAST") == nullptr;   // (a steering pass: both operands on two planes; the wide form only)
+    const bool p4 = steering && !precise && opt_on(d, OPT_STEERING);   // (a steering pass: both operands on two planes; the wide form only)
     if (n == 0) { HIP_CHECK(hipMemset2DAsync(C, ldc * sizeof(double), 0, N * sizeof(double), M, d->stream)); return; }
     const bool mfma = !precise && dt == F32 && M % 16 == 0 && N % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B) &&
                       (!muA || aligned16(muA)) && (!muB || aligned16(muB)) && n >= 64 && M < (1 << 24) && N < (1 << 24);
@@ -6817,8 +6495,6 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
                 if (launch_us(ns) <= base * 1.005 && slab_us * double(ns) <= 0.03 * base) nsplit = ns;
         }
         (void)mslices;
-        static const int ns_env = [] { const char* e = getenv("PETAL_GRAM_NS"); return e ? atoi(e) : 0; }();   // (development knob)
-        if (ns_env > 0) nsplit = std::min<int64_t>(ns_env, ns_max);
         const int64_t chunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
         nsplit = (n + chunk - 1) / chunk;
         double* part = (double*)dev_alloc(d, sizeof(double) * nsplit * M * N);
@@ -6862,7 +6538,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     // split the rows so that every SIMD gets one wave (fp32-MFMA kernel: MFMA-bound, 256 workgroups) or two (split-product
     // kernel: paced by loads in flight -- 512 workgroups = two per CU measured 67 vs 75 us at 100000 x 512)
     const int mslices = cdiv(M, 64);
-    static const int waves_env = [] { const char* e = getenv("PETAL_K2_WAVES"); return e ? atoi(e) : 0; }();
+    constexpr int waves_env = 0;
     const int num_cu2 = num_cus(d);
     // (at 100000 rows the extra 128 slabs cost k_sum_parts2 what the kernel gains: two per CU only for long row ranges)
     const int waves_target = waves_env > 0 ? waves_env : num_cu2 * ((gemm_split_product(d) && !muB && n >= 400000) ? 8 : 4);
@@ -6871,7 +6547,7 @@ void op_gemm_atb(Dev* d, int dt, const void* A, int64_t lda, int64_t M, const vo
     // waves of which most would re-load and re-multiply the clamped last columns (1e6 x 64: 2.3 TB/s); more row chunks keep the
     // chip filled with them (their slabs are small)
     const int NTall = int(N / 16);
-    const int narrow_wv = (gemm_split_product(d) && !muB && getenv("PETAL_K2_NO_NARROW") == nullptr)
+    const int narrow_wv = (gemm_split_product(d) && !muB)
                               ? ((M <= 64 && NTall <= 4) ? 2 : ((M <= 128 && NTall <= 8) ? 4 : 0)) : 0;
     nsplit = std::min<int64_t>(nsplit, narrow_wv ? 256 * (8 / narrow_wv) : 256);  // bounds the partial-slab traffic of narrow (Gram) products
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, n / 64));
@@ -7083,7 +6759,7 @@ void op_logcosh_rows(Dev* d, int dt, const void* X, int64_t r, int64_t c, int64_
 // once per fixed-point loop: X1 is constant over its iterations, so its bf16 planes are made here (fp32 data, split-product modes,
 // 32 or 64 padded components) and every op_ica_step of the loop reads them instead of splitting X1 twice per iteration
 void op_ica_prepare(Dev* d, int dt, const void* X1T, int64_t n, int64_t nc, int64_t ld) {
-    static const bool off = getenv("PETAL_NO_ICA_PLANES") != nullptr;
+    constexpr bool off = false;
     d->ica_x1pl_for = nullptr;
     const int NT = int((nc + 15) / 16);
     if (off || dt != F32 || !gemm_split_product(d) || (NT != 2 && NT != 4) || n < 256 || ld % 4 != 0 || ld < 16 * NT || !aligned16(X1T)) return;
@@ -7351,7 +7027,7 @@ void op_dgemm(Dev* d, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double 
         launch_check();
         return;
     }
-    static const bool no_nn = getenv("PETAL_NO_GEMM_NN") != nullptr;
+    constexpr bool no_nn = false;
     if (!no_nn && !colscale && !ta && !tb && M % 16 == 0 && N % 16 == 0 && K >= 64 && K <= 4096 && alpha == 1.0 && beta == 0.0 &&
         (M / 16) * (N / 16) <= 4096) {
         hipLaunchKernelGGL(k_gemm_nn_f64, dim3((unsigned)((M / 16) * (N / 16))), dim3(256), 0, d->stream, A, lda, B, ldb, K, C, ldc, (int)(N / 16));
@@ -7418,12 +7094,12 @@ static void chol_inv_blocked(Dev* d, const double* G, int64_t L, int64_t ldg, do
     dev_free(d, tmp); dev_free(d, gd); dev_free(d, R); dev_free(d, W);
 }
 
-// the re-basing factorisation in RT form (what k_trsm_pack reads): k_chol_rt on one wave for M = 16 NB <= 144
+// the re-basing factorisation in RT form (what k_trsm_pack reads): k_chol_rt4 for M = 16 NB <= 144
 static void launch_chol_rt(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t M) {
     switch ((int)(M / 16)) {
 #define PETAL_CHOL_RT_CASE(NB)                                                                                                      \
     case NB:                                                                                                                        \
-        hipLaunchKernelGGL((k_chol_rt<NB>), dim3(1), dim3(64), 0, d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead, (int)L);        \
+        hipLaunchKernelGGL((k_chol_rt4<NB>), dim3(1), dim3(256), 0, d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead, (int)L);      \
         break
         PETAL_CHOL_RT_CASE(1); PETAL_CHOL_RT_CASE(2); PETAL_CHOL_RT_CASE(3); PETAL_CHOL_RT_CASE(4); PETAL_CHOL_RT_CASE(5);
         PETAL_CHOL_RT_CASE(6); PETAL_CHOL_RT_CASE(7); PETAL_CHOL_RT_CASE(8); PETAL_CHOL_RT_CASE(9);
@@ -7439,7 +7115,7 @@ static void launch_chol_rt(Dev* d, const double* G, int64_t L, int64_t ldg, doub
 void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                   int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
                   double* P_out, int64_t ldpo, void* Z, int64_t ldz, int p_planes, bool steering) {
-    static const bool no_rt = getenv("PETAL_NO_TRSM") != nullptr;
+    const bool no_rt = false;
     const bool fused = dt == F32 && gemm_split_product(d) && n >= 64 && K % 16 == 0 && K > 0 && M % 16 == 0 && ldx % 4 == 0 &&
                        aligned16(X) && (!mu || aligned16(mu)) && ldz % 4 == 0 && aligned16(Z) && K < (1 << 24) && M < (1 << 24);
     if (!fused || no_rt || L == 0 || L > CHOL2_MAXL || M > TRSM_MAXM || M < L || P_out == nullptr) {
@@ -7454,208 +7130,11 @@ void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t l
 // ---- split-product Gram matrix C = (X - mu)^T (X - mu) for FastICA's whitening (round 5) --------------------------------------
 // The fp64-MFMA Gram (k_atb_f64) is 60 % of a FastICA fit at the configs[4] share; the whitening only keeps the top eigenpairs of a
 // covariance whose wanted eigenvalues lie within a few decades, which fp32-accumulated exact products deliver (the fit checks the
-// spectrum it finds and falls back to the fp64 Gram otherwise: algo.cpp).  Two kernels:
-//  * k_presplit_t: X is centred and split ONCE into three bf16 planes, stored in MFMA fragment order, feature-major:
-//      Xpl[((b FT + ft) 3 + plane) 64 + lane][e] = plane of (X - mu)[32 b + 8 (lane >> 4) + e][16 ft + (lane & 15)]
-//    (rows beyond n and features beyond d are zeros) -- for a product that sums over ROWS this is the operand layout of both sides,
-//    and a 1-KB piece (one tile, one plane) is contiguous: it goes to LDS by LDS-DMA, lane-linear, no conversion anywhere else;
-//  * k_gram3: a 256 x 128 tile of C per 8-wave workgroup over a row chunk -- 32-row stages, the stage's 48 + 24 pieces double
-//    buffered in LDS (144 KB), every wave a 64 x 64 sub-tile: 24 fragment reads and 96 MFMAs (six piece products per tile pair,
-//    smallest first) per stage; only tiles that reach the upper triangle are launched, the tiles of one row chunk on one XCD (its L2
-//    serves the re-reads of the chunk's planes); fp32 slabs, combined and mirrored in fp64 by k_gram3_reduce.
+// spectrum it finds and falls back to the fp64 Gram otherwise: algo.cpp).  Operand layout of a product that sums over ROWS: fragment
+// order, feature-major -- plane[((b FT + ft) 3 + plane) 64 + lane][e] = plane of (X - mu)[32 b + 8 (lane >> 4) + e][16 ft + (lane & 15)].
+// Round 5 built three forms (256 x 128 tiles on planes pre-split by a pass of their own, 256 x 256 tiles on those planes, 256 x 256
+// tiles split on the fly); the last one, k_gram5, is the product's, the other two were retired in round 6 (EXPERIMENTS.md round 5).
 static inline int64_t round_up_i64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
-template <bool CENTER>
-__global__ __launch_bounds__(256) void k_presplit_t(const float* __restrict__ X, int64_t n, int d, int64_t ldx, const float* __restrict__ mu,
-                                                    bf16x8* __restrict__ Xpl, int FT) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    const int64_t b = blockIdx.x;
-    const int ft = blockIdx.y * 4 + wave;
-    if (ft >= FT) return;
-    const int f = 16 * ft + i;
-    f32x8 x;
-    const float m = (CENTER && f < d) ? mu[f] : 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int64_t r = 32 * b + 8 * q + e;
-        x[e] = (r < n && f < d) ? X[r * ldx + f] - m : 0.f;
-    }
-    bf16x8 h, mm, l;
-    split3(x, h, mm, l);
-    bf16x8* out = Xpl + ((b * FT + ft) * 3) * 64 + lane;
-    out[0] = h; out[64] = mm; out[128] = l;
-}
-__global__ __launch_bounds__(512) void k_gram3(const bf16x8* __restrict__ Xpl, int FT, int64_t nblocks, int64_t blocks_per_chunk, int ntiles,
-                                               const int* __restrict__ tile_mi, const int* __restrict__ tile_nj, float* __restrict__ slab) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm_g3[];   // [2][72 KB]: A pieces 0..47 (16 tiles x 3 planes), B pieces 48..71
-    constexpr int STAGE = 72 * 1024;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves: rows 64 wm .. + 64 of the tile, columns 64 wn .. + 64
-    const int tile = blockIdx.x >> 3;
-    const int64_t chunk = (int64_t)blockIdx.y * 8 + (blockIdx.x & 7);
-    const int64_t b0 = chunk * blocks_per_chunk, b1 = min(nblocks, b0 + blocks_per_chunk);
-    if (b0 >= b1 || tile >= ntiles) return;                         // (uniform per workgroup)
-    const int mi = tile_mi[tile], nj = tile_nj[tile];
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // A tile on the diagonal (its 128 columns are features of its own 256 rows: nj = 2 mi or 2 mi + 1) has its B pieces among its A
-    // pieces: they are not fetched a second time (24 of the stage's 72 KB; four of the six tiles at d = 512 -- the kernel is bound by
-    // what L2 delivers to the LDS, 6 TB/s at this shape, not by its MFMAs)
-    const bool diag = (nj >> 1) == mi;
-    const int boff = diag ? (8 * (nj & 1)) * 3 * 1024 : 48 * 1024;   // where the B pieces of a stage sit, bytes from the stage's base
-    // this wave's nine pieces of a stage: piece p = wave + 8 j; p < 48: A (feature tile 16 mi + p / 3, plane p % 3), else B (8 nj + ..)
-    auto dma = [&](int64_t b, int buf) {
-        unsigned char* dst = sm_g3 + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int p = wave + 8 * j;
-            if (diag && p >= 48) break;                             // (uniform)
-            const int ft = p < 48 ? 16 * mi + p / 3 : 8 * nj + (p - 48) / 3, pl = p < 48 ? p % 3 : (p - 48) % 3;
-            const bf16x8* src = Xpl + ((b * FT + ft) * 3 + pl) * 64 + lane;
-            __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(dst + p * 1024), 16, 0, 0);
-        }
-    };
-    dma(b0, 0);
-    for (int64_t b = b0; b < b1; ++b) {
-        const int buf = (int)((b - b0) & 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of stage b have landed
-        __builtin_amdgcn_s_barrier();                               // ... everybody's have; nobody still reads the other buffer
-        asm volatile("" ::: "memory");
-        if (b + 1 < b1) dma(b + 1, buf ^ 1);
-        const bf16x8* sA = reinterpret_cast<const bf16x8*>(sm_g3 + buf * STAGE) + (4 * wm) * 192 + lane;
-        const bf16x8* sB = reinterpret_cast<const bf16x8*>(sm_g3 + buf * STAGE + boff) + (4 * wn) * 192 + lane;
-        bf16x8 bh[4], bm[4], bl[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { bh[c] = sB[c * 192]; bm[c] = sB[c * 192 + 64]; bl[c] = sB[c * 192 + 128]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const bf16x8 ah = sA[a * 192], am = sA[a * 192 + 64], al = sA[a * 192 + 128];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 c4 = acc[a][c];
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], c4, 0, 0, 0);   // smallest terms first
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], c4, 0, 0, 0);
-                acc[a][c] = c4;
-            }
-        }
-    }
-    // slab[(chunk ntiles + tile)][256][128]: D[row = 4 q + r][col = i] of tile (a, c) -> row 64 wm + 16 a + 4 q + r, column 64 wn + 16 c + i
-    float* out = slab + ((int64_t)chunk * ntiles + tile) * (256 * 128);
-    const int i = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float* row = out + (64 * wm + 16 * a + 4 * q + r) * 128 + 64 * wn + i;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) row[16 * c] = acc[a][c][r];
-        }
-}
-// C[f][g] (and C[g][f]) = sum over the row chunks of the tile's slabs, fp64, fixed order; elements below the diagonal of a tile that
-// straddles it are left to the mirror
-__global__ __launch_bounds__(256) void k_gram3_reduce(const float* __restrict__ slab, int64_t nchunks, int ntiles, const int* __restrict__ tile_mi,
-                                                      const int* __restrict__ tile_nj, int d, double* __restrict__ C, int64_t ldc) {
-    const int tile = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;                   // element of the 256 x 128 tile
-    const int r = e >> 7, c = e & 127;
-    const int f = 256 * tile_mi[tile] + r, g = 128 * tile_nj[tile] + c;
-    if (f >= d || g >= d || g < f) return;
-    double sacc = 0;
-    const float* src = slab + (int64_t)tile * (256 * 128) + e;
-    for (int64_t k = 0; k < nchunks; ++k) sacc += (double)src[k * ntiles * (256 * 128)];
-    C[(int64_t)f * ldc + g] = sacc;
-    C[(int64_t)g * ldc + f] = sacc;
-}
-// ---- k_gram4: the same product on 256 x 256 tiles (late round 5).  k_gram3 is bound by what a CU takes in (72 KB of pieces per
-// 3072 matrix-pipe cycles: 23 B/clk asked of a path that delivers ~12), so the lever is bytes per flop: a 256 x 256 tile needs 96 KB
-// per 6144 cycles (16 B/clk; a tile ON the diagonal -- two of the three at d = 512, the only one at d = 256 -- 48 KB: its B pieces are
-// its A pieces), and the chunk's planes are fetched 2 x (d = 512) instead of 3.5 x.  A stage's 96 KB cannot be double buffered, so only A
-// is (2 x 48 KB) and B has ONE buffer (144 KB in all): every wave takes its twelve B fragments of the stage into registers first (it
-// needs them for all eight of its row tiles anyway), a barrier later the B buffer is free and the next stage's B pieces follow the A
-// pieces into flight, under this stage's MFMAs.  Waves 2 x 4: rows 128 wm .. + 128 (eight tiles, fragments streamed), columns 64 wn .. + 64.
-__global__ __launch_bounds__(512) void k_gram4(const bf16x8* __restrict__ Xpl, int FT, int64_t nblocks, int64_t blocks_per_chunk, int ntiles,
-                                               const int* __restrict__ tile_mi, const int* __restrict__ tile_nj, float* __restrict__ slab) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm_g4[];   // A[2][48 KB] (16 feature tiles x 3 planes), B[48 KB]
-    constexpr int PANEL = 48 * 1024;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int tile = blockIdx.x >> 3;
-    const int64_t chunk = (int64_t)blockIdx.y * 8 + (blockIdx.x & 7);
-    const int64_t b0 = chunk * blocks_per_chunk, b1 = min(nblocks, b0 + blocks_per_chunk);
-    if (b0 >= b1 || tile >= ntiles) return;                         // (uniform per workgroup)
-    const int mi = tile_mi[tile], nj = tile_nj[tile];
-    const bool diag = mi == nj;
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // this wave's six pieces of a panel: piece p = wave + 8 j (feature tile p / 3 of the panel's sixteen, plane p % 3)
-    auto dma = [&](int64_t b, int blk, unsigned char* dst) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int pc = wave + 8 * j;
-            const bf16x8* src = Xpl + ((b * FT + 16 * blk + pc / 3) * 3 + pc % 3) * 64 + lane;
-            __builtin_amdgcn_global_load_lds((glds_src_t)src, (glds_dst_t)(dst + pc * 1024), 16, 0, 0);
-        }
-    };
-    unsigned char* const sBp = sm_g4 + 2 * PANEL;
-    dma(b0, mi, sm_g4);
-    if (!diag) dma(b0, nj, sBp);
-    for (int64_t b = b0; b < b1; ++b) {
-        unsigned char* const sAp = sm_g4 + (int)((b - b0) & 1) * PANEL;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of stage b have landed
-        __builtin_amdgcn_s_barrier();                               // ... everybody's have; nobody still reads the other A buffer
-        asm volatile("" ::: "memory");
-        const bf16x8* sB = reinterpret_cast<const bf16x8*>(diag ? sAp : sBp) + (4 * wn) * 192 + lane;
-        bf16x8 bh[4], bm[4], bl[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { bh[c] = sB[c * 192]; bm[c] = sB[c * 192 + 64]; bl[c] = sB[c * 192 + 128]; }
-        if (b + 1 < b1) dma(b + 1, mi, sm_g4 + (int)(((b - b0) & 1) ^ 1) * PANEL);
-        if (!diag) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the DMA above counts on vmcnt only)
-            __builtin_amdgcn_s_barrier();                           // every wave holds its B fragments: the B buffer is free
-            asm volatile("" ::: "memory");
-            if (b + 1 < b1) dma(b + 1, nj, sBp);
-        }
-        const bf16x8* sA = reinterpret_cast<const bf16x8*>(sAp) + (8 * wm) * 192 + lane;
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const bf16x8 ah = sA[a * 192], am = sA[a * 192 + 64], al = sA[a * 192 + 128];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 c4 = acc[a][c];
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], c4, 0, 0, 0);   // smallest terms first
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], c4, 0, 0, 0);
-                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], c4, 0, 0, 0);
-                acc[a][c] = c4;
-            }
-        }
-    }
-    // slab[(chunk ntiles + tile)][256][256]: D[row = 4 q + r][col = i] of tile (a, c) -> row 128 wm + 16 a + 4 q + r, column 64 wn + 16 c + i
-    float* out = slab + ((int64_t)chunk * ntiles + tile) * (256 * 256);
-    const int i = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float* row = out + (128 * wm + 16 * a + 4 * q + r) * 256 + 64 * wn + i;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) row[16 * c] = acc[a][c][r];
-        }
-}
 // ---- k_gram5: k_gram4 WITHOUT the pre-split pass.  The planes were a third of the Gram path (0.5 ms of 1.65 at 500000 x 512: 1 GB
 // read, 1.5 GB written, then read 2 x) for a split that costs a workgroup ~110 VALU instructions per wave and stage beside 192 MFMAs.
 // Here every wave fetches its two feature tiles of the next stage's panels as fp32 straight in fragment order (lane (i, q): feature
@@ -7907,29 +7386,18 @@ __global__ __launch_bounds__(256) void k_gram4_reduce(const float* __restrict__ 
 // mu64_fold (device double[dp]) receive the true means; on the way mu holds the provisional centre (a row sample's means).
 bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int64_t ldx, const void* mu, double* C, int64_t ldc,
                    double* mu64_fold, double n_total) {
-    static const bool off = getenv("PETAL_NO_GRAM3") != nullptr;
-    if (off || d->gemm_mode == 1 || n < 4096 || dd < 64 || dp > 4096) return false;
-    static const bool no_fold = getenv("PETAL_NO_MEANS_FOLD") != nullptr;
-    if (mu64_fold && (no_fold || !mu)) return false;
-    // form: 5 = 256 x 256 tiles, split on the fly (k_gram5, the default); 4 = 256 x 256 tiles on pre-split planes (k_gram4); 3 = 256 x 128
-    // tiles on pre-split planes (k_gram3, the first round-5 form).  PETAL_GRAM_FORM selects (A/B measurements, tests).
-    static const int form = [] { const char* e = getenv("PETAL_GRAM_FORM"); const int f = e ? atoi(e) : 5; return (f >= 3 && f <= 5) ? f : 5; }();
-    if (mu64_fold && form != 5) return false;
-    const bool wide = form != 3;
+    if (!opt_on(d, OPT_GRAM_SPLIT) || d->gemm_mode == 1 || n < 4096 || dd < 64 || dp > 4096) return false;
+    if (mu64_fold && (d->opt[OPT_MEANS_FOLD_ROWS] < 0 || !mu)) return false;
+    // 256 x 256 tiles, split on the fly (k_gram5).  (The forms it replaced -- k_gram3 / k_gram4 on planes pre-split by k_presplit_t -- were
+    // retired in round 6; EXPERIMENTS.md round 5 has their measurements.)
+    constexpr int form = 5;
+    constexpr bool wide = true;
     if (mu64_fold) {   // the provisional centre: the means of a strided sample of the rows (one small pass)
         const int64_t ns = std::min<int64_t>(n, 4096), stride = n / ns;
         op_colmean(d, F32, X, ns, dp, ldx * stride, double(ns), mu64_fold, const_cast<void*>(mu), false);
     }
     const int FT = (int)(round_up_i64(dp, 256) / 16);              // feature tiles, padded to whole 256-feature tile rows
     const int64_t nblocks = cdiv(n, 32);
-    bf16x8* Xpl = nullptr;
-    if (form != 5) {
-        Xpl = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * (size_t)nblocks * FT * 3 * 64);
-        const dim3 grid((unsigned)nblocks, (unsigned)cdiv(FT, 4));
-        if (mu) hipLaunchKernelGGL((k_presplit_t<true>), grid, dim3(256), 0, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, Xpl, FT);
-        else hipLaunchKernelGGL((k_presplit_t<false>), grid, dim3(256), 0, d->stream, (const float*)X, n, (int)dd, ldx, (const float*)mu, Xpl, FT);
-        launch_check();
-    }
     // tiles that reach the upper triangle
     std::vector<int> h;
     const int MT = FT / 16, NTl = wide ? FT / 16 : FT / 8, TN = wide ? 256 : 128;
@@ -7942,7 +7410,7 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
     const int ncu = num_cus(d);
     // (whole rounds: 2 ncu / ntiles rounded DOWN -- 86 chunks x 6 tiles = 516 workgroups on 256 CUs ran a third round for four of them;
     // a chunk of at least 16 stages: a workgroup's 128 / 256 KB slab is written once and read once per chunk)
-    static const int rounds = [] { const char* e = getenv("PETAL_GRAM_ROUNDS"); return e ? atoi(e) : 2; }();
+    constexpr int rounds = 2;
     // (... and WHOLE rounds where the chunks would get shorter than that: 368 chunks of one tile on 256 CUs take as long as 512)
     const int64_t min_stages = wide ? 16 : 8;
     int64_t nsplit = (rounds * (int64_t)ncu) / ntiles;
@@ -7957,7 +7425,7 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
     std::vector<int> tbpc(ntiles, (int)bpc), tnch(ntiles, (int)nsplit);
     int64_t max_split = nsplit;
     if (form == 5 && ntiles > 1 && nsplit > 1) {
-        static const double w_off = [] { const char* e = getenv("PETAL_GRAM_OFFDIAG_COST"); return e ? atof(e) : 3.6; }();
+        constexpr double w_off = 3.6;
         double wsum = 0;
         for (int t = 0; t < ntiles; ++t) wsum += tmi[t] == tnj[t] ? 1.0 : w_off;
         const double total = double(nsplit) * ntiles;
@@ -7989,12 +7457,6 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
             else if (mu) PETAL_G5(true, false);
             else PETAL_G5(false, false);
 #undef PETAL_G5
-        } else if (form == 4) {
-            set_max_lds(d, reinterpret_cast<const void*>(k_gram4));
-            hipLaunchKernelGGL(k_gram4, grid, dim3(512), 144 * 1024, d->stream, Xpl, FT, nblocks, bpc, ntiles, tiles_dev, tiles_dev + ntiles, slab);
-        } else {
-            set_max_lds(d, reinterpret_cast<const void*>(k_gram3));
-            hipLaunchKernelGGL(k_gram3, grid, dim3(512), 144 * 1024, d->stream, Xpl, FT, nblocks, bpc, ntiles, tiles_dev, tiles_dev + ntiles, slab);
         }
         launch_check();
         ts.stop();
@@ -8005,28 +7467,23 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
                            tiles_dev + ntiles, (int)dd, (int)dp, n_total, mu64_fold, (float*)const_cast<void*>(mu), delta);
         launch_check();
     }
-    if (wide)
-        hipLaunchKernelGGL(k_gram4_reduce, dim3(256, ntiles), dim3(256), 0, d->stream, slab, tiles_dev + 3 * ntiles, ntiles, tiles_dev, tiles_dev + ntiles,
-                           (int)dd, C, ldc, (const double*)delta, n_total);
-    else
-        hipLaunchKernelGGL(k_gram3_reduce, dim3(128, ntiles), dim3(256), 0, d->stream, slab, nsplit, ntiles, tiles_dev, tiles_dev + ntiles, (int)dd, C, ldc);
+    hipLaunchKernelGGL(k_gram4_reduce, dim3(256, ntiles), dim3(256), 0, d->stream, slab, tiles_dev + 3 * ntiles, ntiles, tiles_dev, tiles_dev + ntiles,
+                       (int)dd, C, ldc, (const double*)delta, n_total);
     launch_check();
     dev_free(d, slab); dev_free(d, tiles_dev);
     if (sums) dev_free(d, sums);
     if (delta) dev_free(d, delta);
-    if (Xpl) dev_free(d, Xpl);
     return true;
 }
 
 // ---- the fused power-iteration pass (k_pow3) ------------------------------------------------------------------------------
 static bool pow3_ok(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N, const void* Z, int64_t ldz) {
-    static const bool off = getenv("PETAL_NO_POW3") != nullptr;
-    static const int64_t min_rows = [] { const char* e = getenv("PETAL_POW3_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();
-    return !off && dt == F32 && d->gemm_mode == 0 && K == 512 && N % 16 == 0 && N >= 16 && N <= 80 && n >= min_rows &&
+    const int64_t min_rows = (int64_t)d->opt[OPT_FUSED_PASS_MIN_ROWS];
+    return opt_on(d, OPT_FUSED_PASS) && dt == F32 && d->gemm_mode == 0 && K == 512 && N % 16 == 0 && N >= 16 && N <= 80 && n >= min_rows &&
            n < (int64_t(1) << 40) && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && (!Z || (ldz >= N && aligned16(Z)));
 }
 // (the knobs that keep an operand at three planes also keep its product off the fused kernel, whose P is a two-plane one by construction)
-static bool pow3_knob_off(const char* name) { return getenv("PETAL_NO_P2") != nullptr || getenv(name) != nullptr; }
+static bool pow3_knob_off(const Dev* d, int opt) { return !opt_on(d, OPT_TWO_PLANE) || !opt_on(d, opt); }
 bool op_power_pass_applies(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, int64_t N) {
     return pow3_ok(d, dt, X, n, K, ldx, mu, N, nullptr, 0);
 }
@@ -8037,7 +7494,7 @@ bool op_power_pass_applies(Dev* d, int dt, const void* X, int64_t n, int64_t K, 
 static void launch_pow3(Dev* d, const float* X, int64_t n, int64_t ldx, const float* mu, const bf16x8* Ppk3, int64_t N, float* Z, int64_t ldz,
                         double* Y, int64_t ldy, double** ssq_parts_out = nullptr, int* nparts_out = nullptr, bool steering = false) {
     const bool ssq_out = ssq_parts_out != nullptr;
-    const bool no_fast = getenv("PETAL_NO_POW3_FAST") != nullptr;   // (read per launch: the tests compare the two forms in one process)
+    const bool no_fast = !opt_on(d, OPT_STEERING);
     if (steering && !no_fast && !Z) {
         const int NT = (int)(N / 16);
         const int64_t nstages = cdiv(n, 32);
@@ -8127,8 +7584,19 @@ __global__ __launch_bounds__(256) void k_mean_fix(double* __restrict__ Y, int K,
     __syncthreads();
     const int j0 = blockIdx.x * 4, jj = tid & 3, fl = tid >> 2;      // 64 row lanes x 4 columns
     double acc = 0;
+    // (the fused pass multiplied by the TWO-PLANE P: the rank-one correction uses the same rounded values -- bf16(p) + bf16(p - bf16(p)),
+    // round-to-nearest-even each, what v_cvt_pk_bf16_f32 and the host simulation oracle/cpu_ops.cpp two_plane() do)
+    auto two_plane = [](double v) {
+        auto bf = [](float f) {
+            unsigned u = __float_as_uint(f);
+            u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+            return __uint_as_float(u);
+        };
+        const float f = (float)v, h = bf(f), m = bf(f - h);
+        return (double)h + (double)m;
+    };
     if (j0 + jj < L)
-        for (int f = fl; f < K; f += 64) acc += sd[f] * P[(int64_t)f * ldp + j0 + jj];
+        for (int f = fl; f < K; f += 64) acc += sd[f] * two_plane(P[(int64_t)f * ldp + j0 + jj]);
     sr[tid] = acc;
     __syncthreads();
     if (tid < 4) {
@@ -8163,7 +7631,7 @@ __global__ __launch_bounds__(256) void k_mean_fix(double* __restrict__ Y, int K,
 }
 bool op_power_pass_means(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t dcols, int64_t ldx, double n_total, const double* P,
                          int64_t N, int64_t ldp, int64_t L, double* Y, int64_t ldy, double* mu64, void* muT, double* ssq_scratch, double* tv) {
-    static const bool off = getenv("PETAL_NO_MEANS_FOLD") != nullptr || pow3_knob_off("PETAL_NO_P2_OMEGA");
+    const bool off = d->opt[OPT_MEANS_FOLD_ROWS] < 0 || pow3_knob_off(d, OPT_TWO_PLANE_OMEGA);
     if (off || L >= N || !pow3_ok(d, dt, X, n, K, ldx, muT, N, nullptr, 0)) return false;
     // the provisional centre: the means of a strided sample of the rows (one small pass)
     const int64_t ns = std::min<int64_t>(n, 4096), stride = n / ns;
@@ -8188,7 +7656,7 @@ bool op_power_pass_means(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
 }
 bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N, int64_t ldp,
                    void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering) {
-    static const bool knob = pow3_knob_off("PETAL_NO_P2_OMEGA");
+    const bool knob = pow3_knob_off(d, OPT_TWO_PLANE_OMEGA);
     if (knob || !pow3_ok(d, dt, X, n, K, ldx, mu, N, Z, ldz)) return false;
     const int64_t total = (K / 32) * (N / 16) * 64;
     bf16x8* Ppk3 = (bf16x8*)dev_alloc(d, sizeof(bf16x8) * total * 3);
@@ -8201,7 +7669,7 @@ bool op_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t 
 bool op_rebase_power_pass(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                           int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,
                           double* P_out, int64_t ldpo, void* Z, int64_t ldz, double* Y, int64_t ldy, bool steering) {
-    static const bool no_rt = getenv("PETAL_NO_TRSM") != nullptr || pow3_knob_off("PETAL_NO_P2_ITERATE");
+    const bool no_rt = pow3_knob_off(d, OPT_TWO_PLANE_ITERATE);
     if (!pow3_ok(d, dt, X, n, K, ldx, mu, M, Z, ldz) || no_rt || L == 0 || L > CHOL2_MAXL || M > TRSM_MAXM || M < L || P_out == nullptr) return false;
     launch_chol_rt(d, G, L, ldg, T, ldt, rel_tol, ndead, M);
     const int NTtot = (int)(M / 16);
@@ -8227,27 +7695,13 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
                  int64_t ndead_cols) {
     if (L == 0) return;
     if (Lz < L) Lz = L;
-    static const bool force_old = getenv("PETAL_CHOL_OLD") != nullptr;
-    // Orders 142 .. 200 used to run k_chol_inv with T built directly in global memory (t_mode 0: neither LDS form of T fits
-    // beside the packed factor there) -- a mode no test reached and whose results were WRONG (RandomizedPca with 132 <= k <= 190:
-    // singular values off by 10 % .. 1e3, found by dev/fuzz_rpca.py in round 3).  They take the blocked form now, like the
-    // orders beyond 200; k_chol_inv only ever runs with T in LDS (order 141, or PETAL_CHOL_OLD=1 below that).
-    if (L > CHOL2_MAXL + 1) { chol_inv_blocked(d, G, L, ldg, T, ldt, rel_tol, ndead, Lz); return; }
-    if (L <= CHOL2_MAXL && !force_old) {
-        set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
-        hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol,
-                           ndead, (int)Lz, (const double*)nullptr, 0, (int)(ndead_cols > 0 ? ndead_cols : L));
-        launch_check();
-        return;
-    }
-    const size_t base = sizeof(double) * (L * (L + 1) / 2 + L + (L + 1) / 2);
-    const size_t full = base + sizeof(double) * L * L, packed = base + sizeof(double) * (L * (L + 1) / 2);
-    const size_t cap = 160 * 1024 - 256;
-    const int t_mode = full <= cap ? 1 : (packed <= cap ? 2 : 0);
-    if (t_mode == 0) throw std::logic_error("op_chol_inv: order beyond the LDS forms of k_chol_inv");
-    const size_t lds = t_mode == 1 ? full : (t_mode == 2 ? packed : base);
-    set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv));
-    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(CHOL_THREADS), lds, d->stream, G, (int)L, ldg, T, ldt, rel_tol, t_mode, ndead, (int)Lz);
+    // k_chol_inv2 takes the orders up to 140; beyond, the blocked right-looking factorisation on the chip-wide fp64 GEMM kernel.
+    // (Orders 141 .. 200 once ran an older one-workgroup kernel, k_chol_inv, whose build-T-in-global-memory mode no test reached and
+    // whose factors were WRONG -- RandomizedPca with 132 <= k <= 190, found by dev/fuzz_rpca.py in round 3; retired in round 6.)
+    if (L > CHOL2_MAXL) { chol_inv_blocked(d, G, L, ldg, T, ldt, rel_tol, ndead, Lz); return; }
+    set_max_lds(d, reinterpret_cast<const void*>(k_chol_inv2));
+    hipLaunchKernelGGL(k_chol_inv2, dim3(1), dim3(CHOL_THREADS), chol2_lds_bytes((int)L), d->stream, G, (int)L, ldg, T, ldt, rel_tol,
+                       ndead, (int)Lz, (const double*)nullptr, 0, (int)(ndead_cols > 0 ? ndead_cols : L));
     launch_check();
 }
 void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool clustered, int64_t Lz, int64_t ncheck,
@@ -8257,7 +7711,7 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
     if (L > EIG_MAXL) throw std::runtime_error("eigh: matrix too large for the one-workgroup Jacobi solver");
     // Two-stage solver first (tridiagonalisation on one workgroup, then one wave per eigenpair over the chip); the Jacobi
     // launches below run behind it and return at once unless its verdict flags eigenvalues too close for its vectors.
-    static const bool jacobi_only = getenv("PETAL_EIGH_JACOBI") != nullptr;
+    const bool jacobi_only = opt_on(d, OPT_EIGH_JACOBI);
     int* flag = nullptr;
     char* ts = nullptr;
     const bool two_stage = !jacobi_only && !clustered && L >= 3 && L <= 2048;
@@ -8318,29 +7772,23 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
             }
             launch_check();
         } else {
-            static const bool tri_one_wg = getenv("PETAL_TRIDIAG_ONE_WG") != nullptr;   // (the round-2 kernels: A/B switch)
-            if (!tri_one_wg && L <= 256 * TMW_NV) {
-                // one launch per Householder step, the whole chip per launch (k_tridiag_mw): 29 -> ~5 ms at order 512
-                const int64_t ldm = L | 1;
-                double* mw = (double*)dev_alloc(d, sizeof(double) * ((size_t)L * ldm + 4 * L));
-                double* vp = mw + (size_t)L * ldm;
-                HIP_CHECK(hipMemcpy2DAsync(mw, ldm * sizeof(double), A, lda * sizeof(double), L * sizeof(double), L, hipMemcpyDeviceToDevice, d->stream));
-                HIP_CHECK(hipMemsetAsync(vp, 0, sizeof(double) * 4 * L, d->stream));
-                HIP_CHECK(hipMemsetAsync(HV, 0, sizeof(double) * L * L, d->stream));
-                const size_t lds_mw = sizeof(double) * (3 * L + 16);
-                for (int64_t k = 0; k < L; ++k) {
-                    const int64_t m = L - k - 1;
-                    const unsigned grid = (unsigned)std::min<int64_t>(512, std::max<int64_t>(1, (m + 3) / 4));
-                    hipLaunchKernelGGL(k_tridiag_mw, dim3(grid), dim3(256), lds_mw, d->stream, mw, ldm, (int)L, (int)k, vp + ((k + 1) & 1) * 2 * L,
-                                       vp + (k & 1) * 2 * L, dd, ee, HV, tau);
-                }
-                launch_check();
-                dev_free(d, mw);
-            } else if (inlds) {
-                set_max_lds(d, reinterpret_cast<const void*>(k_tridiag<true>));
-                hipLaunchKernelGGL(k_tridiag<true>, dim3(1), dim3(TRI_THREADS), lds_in, d->stream, A, (int)L, lda, Wg, dd, ee, HV, tau);
-            } else {
-                hipLaunchKernelGGL(k_tridiag<false>, dim3(1), dim3(TRI_THREADS), sizeof(double) * (2 * L + 32), d->stream, A, (int)L, lda, Wg, dd, ee, HV, tau);
+            {
+            // one launch per Householder step, the whole chip per launch (k_tridiag_mw): 29 -> ~5 ms at order 512
+            const int64_t ldm = L | 1;
+            double* mw = (double*)dev_alloc(d, sizeof(double) * ((size_t)L * ldm + 4 * L));
+            double* vp = mw + (size_t)L * ldm;
+            HIP_CHECK(hipMemcpy2DAsync(mw, ldm * sizeof(double), A, lda * sizeof(double), L * sizeof(double), L, hipMemcpyDeviceToDevice, d->stream));
+            HIP_CHECK(hipMemsetAsync(vp, 0, sizeof(double) * 4 * L, d->stream));
+            HIP_CHECK(hipMemsetAsync(HV, 0, sizeof(double) * L * L, d->stream));
+            const size_t lds_mw = sizeof(double) * (3 * L + 16);
+            for (int64_t k = 0; k < L; ++k) {
+                const int64_t m = L - k - 1;
+                const unsigned grid = (unsigned)std::min<int64_t>(512, std::max<int64_t>(1, (m + 3) / 4));
+                hipLaunchKernelGGL(k_tridiag_mw, dim3(grid), dim3(256), lds_mw, d->stream, mw, ldm, (int)L, (int)k, vp + ((k + 1) & 1) * 2 * L,
+                                   vp + (k & 1) * 2 * L, dd, ee, HV, tau);
+            }
+            launch_check();
+            dev_free(d, mw);
             }
             launch_check();
             if (L <= 512) {

@@ -46,6 +46,30 @@ void  dev_d2d(Dev*, void* dst, const void* src, size_t bytes);
 void  dev_copy2d(Dev*, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int kind);
 void  dev_sync(Dev*);
 void  dev_set_profiling(Dev*, int level);   // 0 off, 1 one sampled launch per tag and fit, 2 every tagged launch
+// Options of a device context: every switch that selects WHICH arithmetic or kernel form a fit runs.  The defaults come from the
+// environment ONCE, at dev_create (the variable named with each); afterwards only dev_set_option (petal_ctx_set_option) changes
+// them -- no kernel launcher reads the environment.  The values equal include/petal_hip.h's PETAL_OPT_*.
+enum PetalOpt {
+    OPT_TWO_PLANE = 0,         // (1) optimistic first run of an fp32 RandomizedPca fit: sketch matrix and re-based iterates on two bf16 planes,
+                               //     behind the spectrum verdict; 0 = three planes throughout                       env PETAL_NO_P2=1 -> 0
+    OPT_TWO_PLANE_OMEGA = 1,   // (1) ... the sketch matrix alone                                                     env PETAL_NO_P2_OMEGA=1 -> 0
+    OPT_TWO_PLANE_ITERATE = 2, // (1) ... the re-based iterates alone                                                 env PETAL_NO_P2_ITERATE=1 -> 0
+    OPT_STEERING = 3,          // (1) the passes before the last one round Xc and z to two planes as well             env PETAL_NO_POW3_FAST=1 -> 0
+    OPT_FUSED_PASS = 4,        // (1) the fused power-iteration pass where the kernel exists                          env PETAL_NO_POW3=1 -> 0
+    OPT_FUSED_PASS_MIN_ROWS = 5, // (8192) fewer rows: K1 + K2                                                        env PETAL_POW3_MIN_ROWS
+    OPT_VERDICT_THRESHOLD = 6, // (4e-6) the two-plane verdict redoes a fit whose estimated component error exceeds it  env PETAL_P2_VERDICT_THR
+    OPT_MEANS_FOLD_ROWS = 7,   // (200000) single-rank fp32 fits gather the means inside the first pass from this many rows on; < 0: never
+                               //                                                      env PETAL_MEANS_FOLD_ROWS, PETAL_NO_MEANS_FOLD=1 -> -1
+    OPT_GRAM_SPLIT = 8,        // (1) FastICA whitening: the optimistic split-product covariance (k_gram5); 0 = fp64 products   env PETAL_NO_GRAM3=1 -> 0
+    OPT_GRAM_SPLIT_HOOK = 9,   // (0) test hook: petal_gemm_atb sends Gram products to the split-product Gram kernel  env PETAL_GRAM_SPLIT=1
+    OPT_D2H_KERNEL = 10,       // (1) small results leave through a copy kernel into the pinned ring; 0 = hipMemcpyAsync  env PETAL_D2H_MEMCPY=1 -> 0
+    OPT_ROW_PAD = 11,          // (1) copied inputs land with 128 B of row padding when the natural pitch is a multiple of 1 KiB  env PETAL_NO_ROW_PAD=1 -> 0
+    OPT_EIGH_JACOBI = 12,      // (0) symmetric eigenproblems go straight to the Jacobi solvers                        env PETAL_EIGH_JACOBI=1
+    OPT_POISON = 13,           // (0) every workspace block is filled with NaN patterns when handed out (tests)         env PETAL_POISON=1
+    OPT_COUNT = 14
+};
+void   dev_set_option(Dev*, int opt, double value);
+double dev_option(const Dev*, int opt);
 void  dev_set_gemm_mode(Dev*, int mode);    // 0 = split-product (bf16x3) GEMM kernels for fp32 data, 1 = fp32-MFMA kernels
 int   dev_gemm_mode(const Dev*);
 void  dev_make_current(Dev*);               // hipSetDevice(the ctx's device) on the calling thread

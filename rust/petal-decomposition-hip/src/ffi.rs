@@ -26,6 +26,9 @@ extern "C" {
     pub fn petal_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut PetalCtx) -> c_int;
     pub fn petal_ctx_destroy(ctx: *mut PetalCtx);
     pub fn petal_last_error(ctx: *const PetalCtx) -> *const c_char;
+    /// PETAL_OPT_* (include/petal_hip.h): the numerics / kernel-form switches of a ctx; defaults from the environment at creation
+    pub fn petal_ctx_set_option(ctx: *mut PetalCtx, option: c_int, value: f64) -> c_int;
+    pub fn petal_ctx_get_option(ctx: *const PetalCtx, option: c_int, value: *mut f64) -> c_int;
     pub fn petal_pca_fit(
         ctx: *mut PetalCtx, x: *const PetalMatrix, k: i64, centering: c_int, components: *mut c_void,
         means: *mut c_void, singular: *mut c_void, total_variance: *mut c_void, y_out: *const PetalMatrix,

@@ -29,7 +29,7 @@ def lib_path():
 def test_header_symbols_exported(lib_path):
     lib = ctypes.CDLL(lib_path)
     names = _declared()
-    assert len(names) == 23, names
+    assert len(names) == 25, names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/petal_hip.h but not exported"
 

@@ -50,11 +50,12 @@ def test_fused_power_pass_falls_back_outside_its_shape(ctx):
 
 
 @pytest.mark.parametrize("n,d", [(8192, 256), (20011, 512), (5000, 64), (9000, 200), (33333, 384), (4100, 1024)])
-def test_split_product_gram_exact(ctx, monkeypatch, n, d):
-    """The split-product Gram kernels of the FastICA whitening (k_presplit_t + k_gram3 + k_gram3_reduce) on exact-integer data,
-    centred and not: ragged row counts, widths that are no multiple of the 256 x 128 tiles, one to eight tile rows."""
+def test_split_product_gram_exact(ctx, n, d):
+    """The split-product Gram kernel of the FastICA whitening (k_gram5 + k_gram4_reduce) on exact-integer data, centred and not:
+    ragged row counts, widths that are no multiple of the 256 x 256 tiles, one to four tile rows.  PETAL_OPT_GRAM_SPLIT_HOOK sends
+    petal_gemm_atb's Gram products there."""
     import petal_decomposition_amd as petal
-    monkeypatch.setenv("PETAL_GRAM_SPLIT", "1")
+    ctx.set_option("gram_split_hook", 1)
     rng = np.random.default_rng(n + d)
     x = rng.integers(-4, 5, (n, d)).astype(np.float32)
     mu = rng.integers(-2, 3, d).astype(np.float32)
@@ -63,6 +64,7 @@ def test_split_product_gram_exact(ctx, monkeypatch, n, d):
     ref = (x64 - mu).T @ (x64 - mu)
     assert np.array_equal(c, ref), (np.abs(c - ref).max(), np.argwhere(c != ref)[:5].tolist())
     c = petal.gemm_atb(x, ctx=ctx)
+    ctx.set_option("gram_split_hook", 0)
     assert np.array_equal(c, x64.T @ x64)
 
 
@@ -143,16 +145,20 @@ def test_host_inputs_that_are_not_row_major(ctx, layout):
         assert time.perf_counter() - t0 < 0.1      # (upload + device gather + fit; the host gather alone took 0.3 s)
 
 
-def test_means_folded_into_the_first_fused_pass(ctx, monkeypatch):
+def test_means_folded_into_the_first_fused_pass(ctx):
     """src/pca.rs:520-533 (means, centred copy, total variance: three passes in the crate, one here in round 4) inside the FIRST
     fused power-iteration pass: centred about the means of a strided row sample, the exact column sums from an all-ones column of
     z, sum (x - mu0)^2 from the splits, then a rank-one move to the true centre.  Data with |mu| = 40 sigma, and rows sorted so that
     the head of the matrix is far from the mean; in fp32-MFMA mode the same cases run the separate means pass."""
-    monkeypatch.setenv("PETAL_MEANS_FOLD_ROWS", "0")       # (the product folds from 200000 rows on: see test_gpu_fullsize / bench)
-    pc.means_fold_case(ctx, 20000, 512, 64, device=True)
-    pc.means_fold_case(ctx, 9001, 512, 32, n_iter=7)
-    monkeypatch.delenv("PETAL_MEANS_FOLD_ROWS")
-    pc.means_fold_case(ctx, 200000, 512, 16, device=True)   # at the product's own threshold
+    ctx.set_option("means_fold_rows", 0)       # (the product folds from 200000 rows on: see test_gpu_fullsize / bench)
+    try:
+        pc.means_fold_case(ctx, 20000, 512, 64, device=True, expect_folded=True)
+        pc.means_fold_case(ctx, 9001, 512, 32, n_iter=7, expect_folded=True)
+        ctx.set_option("means_fold_rows", -1)  # never: the separate means pass, same parity, and the stats say so
+        pc.means_fold_case(ctx, 9001, 512, 32, n_iter=7, expect_folded=False)
+    finally:
+        ctx.set_option("means_fold_rows", 200000)
+    pc.means_fold_case(ctx, 200000, 512, 16, device=True, expect_folded=True)   # at the product's own threshold
 
 
 def test_components_beyond_a_ring_slot(ctx):
@@ -725,37 +731,6 @@ def test_run_to_run_bitwise_determinism(ctx):
     p = petal.Pca(8, ctx=ctx).fit(x)
     q = petal.Pca(8, ctx=ctx).fit(x)
     assert np.array_equal(p.components(), q.components()) and np.array_equal(p.singular_values(), q.singular_values())
-
-
-def test_lds_dma_k1_variant_is_bit_identical():
-    """k_xp4 (opt-in, PETAL_XP4=1: K1 with X and P arriving through LDS-DMA rings, counted vmcnt waits and a raw barrier) runs
-    the same MFMA sequence as k_xp3: exact on integer data and BIT-IDENTICAL to the default kernel on random data, ragged row
-    counts included.  The switch is read once per process, so the variant runs in a child."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    import petal_decomposition_amd as petal
-    rng = np.random.default_rng(9)
-    n, d, l = 5003, 512, 74
-    x = (rng.standard_normal((n, d)) * 3 + 1).astype(np.float32)
-    p = rng.standard_normal((d, l)).astype(np.float32)
-    mu = x.mean(0).astype(np.float32)
-    ctx = petal.Context(0)
-    z0 = np.asarray(petal.gemm_xp(x, p, mu, ctx=ctx))
-    ctx.close()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with tempfile.TemporaryDirectory() as tmp:
-        np.savez(os.path.join(tmp, "in.npz"), x=x, p=p, mu=mu)
-        code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import petal_decomposition_amd as petal; "
-                "import parity_cases as pc; c = petal.Context(0); d = np.load(%r); "
-                "np.save(%r, np.asarray(petal.gemm_xp(d['x'], d['p'], d['mu'], ctx=c))); "
-                "[pc.gemm_exact(c, n, K, N, seed=n + K) for (n, K, N) in [(4099, 512, 74), (2048, 64, 80), (777, 96, 33), (1000, 160, 16)]]"
-                % (root, os.path.join(root, "tests"), os.path.join(tmp, "in.npz"), os.path.join(tmp, "z.npy")))
-        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PETAL_XP4="1"), capture_output=True, text=True, timeout=600)
-        assert res.returncode == 0, res.stderr[-2000:]
-        z1 = np.load(os.path.join(tmp, "z.npy"))
-    assert np.array_equal(z0, z1)
 
 
 def test_alternating_fits_on_one_ctx_match_a_fresh_ctx():

@@ -58,14 +58,17 @@ def test_host_inputs_that_are_not_row_major(ctx, layout):
     pc.rpca_parity(ctx, 500, 24, 4, 4, seed=10, dtype=np.float64, tol=1e-9, host_layout=layout)
 
 
-def test_means_folded_into_the_first_fused_pass(ctx, monkeypatch):
-    monkeypatch.setenv("PETAL_MEANS_FOLD_ROWS", "0")       # (the product folds from 200000 rows on)
+def test_means_folded_into_the_first_fused_pass(ctx):
+    ctx.set_option("means_fold_rows", 0)       # (the product folds from 200000 rows on)
     ctx.set_gemm_mode("bf16x3")
     try:
-        pc.means_fold_case(ctx, 2500, 64, 6)
+        pc.means_fold_case(ctx, 2500, 64, 5, expect_folded=True)   # (l = 15: the fold needs a spare padding column, l < LP)
         pc.rpca_parity(ctx, 2000, 48, 6, 5, seed=83)
+        ctx.set_option("means_fold_rows", -1)
+        pc.means_fold_case(ctx, 2500, 64, 5, expect_folded=False)
     finally:
         ctx.set_gemm_mode("fp32")
+        ctx.set_option("means_fold_rows", 200000)
 
 
 def test_fastica_whitening_from_the_split_product_covariance(ctx):
@@ -86,15 +89,25 @@ def test_steering_passes_on_sixteen_bit_operands(ctx, monkeypatch):
         ctx.set_gemm_mode("fp32")
 
 
-def test_fastica_means_gathered_in_the_gram_pass(ctx, monkeypatch):
-    """the host logic of the folded means (algo.cpp: fastica_fit) on the simulation's restatement of the device arithmetic, and the
-    separate means pass under PETAL_NO_MEANS_FOLD: same sources"""
+def test_fastica_means_gathered_in_the_gram_pass(ctx):
+    """the host logic of the folded means (algo.cpp: fastica_fit) on the simulation's restatement of the device arithmetic (the case
+    asserts petal_stats.means_folded = 1), then the SAME fit with the fold switched off (PETAL_OPT_MEANS_FOLD_ROWS < 0: a means pass of
+    its own, means_folded = 0): same sources"""
+    from parity_cases import petal, np, po
     ctx.set_gemm_mode("bf16x3")
     try:
         y = pc.ica_means_fold_case(ctx, 3000, 272, 5)
-        monkeypatch.setenv("PETAL_NO_GRAM3", "1")     # (the simulation reads its knobs once: the fp64 covariance after a means pass)
+        ctx.set_option("means_fold_rows", -1)
+        x = po.synth_ica(3000, 272, 5, seed=71, dtype=np.float64)
+        x = (x + 40.0 * x.std(axis=0) * np.sign(np.random.default_rng(72).standard_normal(272))).astype(np.float32)
+        w0 = np.random.default_rng(73).standard_normal((5, 5)).astype(np.float32)
+        y2 = np.asarray(petal.FastIca(ctx=ctx, n_components=5).fit_transform(x, w_init=w0))
+        assert ctx.stats()["means_folded"] == 0, ctx.stats()
+        c = np.abs(np.corrcoef(y.T.astype(np.float64), y2.T.astype(np.float64))[:5, 5:])
+        assert np.abs(1.0 - c.max(axis=1)).max() <= 1e-3, c.max(axis=1)
     finally:
         ctx.set_gemm_mode("fp32")
+        ctx.set_option("means_fold_rows", 200000)
     assert y.shape == (3000, 5)
 
 

@@ -33,14 +33,17 @@ BUDGETS = [
     (r"k_ica3<4>$", 256, 0, "FastICA step, 64 components"),
     (r"k_ica3p<2>$", 128, 0, "FastICA step on pre-split planes, 32 components: 4 waves/SIMD"),
     (r"k_ica3p<4>$", 256, 0, "FastICA step on pre-split planes, 64 components"),
-    (r"k_gram3$", 168, 0, "split-product Gram matrix on pre-split planes, 256 x 128 tiles (selectable form 3)"),
-    (r"k_gram4$", 256, 0, "split-product Gram matrix on pre-split planes, 256 x 256 tiles (selectable form 4)"),
     (r"k_gram5<(true|false), (true|false)>$", 256, 0, "split-product Gram matrix of the FastICA whitening (256 x 256 tiles, split on the fly): 128 accumulators + 48 B-fragment registers + two raw panels in flight; one 8-wave workgroup per CU, no scratch"),
     # (3 waves/SIMD.  Forcing 4 with __launch_bounds__(256, 4) gives 96 registers and a slower kernel -- 3244 vs 2760 us at
     # 500000 x 512, measured round 4 -- so the budget holds the 3-wave allocation)
     (r"k_atb_f64<float, (true|false), (true|false), 4>$", 136, 0, "fp64 Gram of fp32 data (FastICA whitening / exact Pca): 3 waves/SIMD"),
     (r"k_atb_f64<", 256, 0, "every fp64 GEMM instantiation: no scratch"),
+    # (round 6: the re-basing Cholesky, blocks in registers on four waves -- one wave per SIMD, so up to 512 unified registers; no scratch)
+    (r"k_chol_rt4<[1-9]>$", 320, 0, "re-basing Cholesky in RT form, register-resident on four waves"),
 ]
+
+# kernels that were retired (round 6: reachable only through environment switches until then) and must not come back into the shipped library
+RETIRED = [r"\bk_chol_inv\(", r"\bk_chol_inv<", r"k_xp4<", r"k_gram3\b", r"k_gram4\(", r"k_presplit_t", r"\bk_tridiag<(true|false)>", r"k_chol_rt<"]
 
 
 @pytest.fixture(scope="module")
@@ -63,6 +66,12 @@ def test_budget(resources, pattern, max_vgpr, max_scratch, who):
     for name, r in hits.items():
         assert r["vgpr"] <= max_vgpr, f"{name}: {r['vgpr']} VGPRs > {max_vgpr} ({who})"
         assert r["scratch"] <= max_scratch and r["vgpr_spill"] == 0, f"{name}: spills ({r['vgpr_spill']} VGPRs, {r['scratch']} B scratch; {who})"
+
+
+def test_retired_kernels_are_gone(resources):
+    for pat in RETIRED:
+        hits = [k for k in resources if re.search(pat, k)]
+        assert not hits, (pat, hits)
 
 
 # kernels that are known to spill, with the spill count they may not exceed (none of them is on the default path of a
