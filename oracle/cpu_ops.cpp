@@ -509,9 +509,19 @@ void op_gemm_xp_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K, int6
 }
 void op_gemm_xp_prod_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* A, int64_t M,
                             int64_t lda, const double* T, int64_t N, int64_t ldt, double* P_out, int64_t ldpo, void* Z, int64_t ldz,
-                            int64_t row_offset, double* absmax, double* idx, double* sign, bool) {
+                            int64_t row_offset, double* absmax, double* idx, double* sign, bool, bool a_rt) {
+    if (a_rt) throw std::logic_error("host sim: op_chol_rt never returns the RT form");
     op_gemm_xp_prod(d, dt, X, n, K, ldx, mu, A, M, lda, T, N, ldt, P_out, ldpo, Z, ldz);
     op_col_absmax(d, dt, Z, n, N, ldz, row_offset, absmax, idx, sign);
+}
+// (the simulation always forms the explicit inverse: the RT form is a device detail)
+bool op_chol_rt(Dev* d, int, int64_t, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t Lz,
+                int64_t ndead_cols) {
+    op_chol_inv(d, G, L, ldg, T, ldt, rel_tol, ndead, Lz, ndead_cols);
+    return false;
+}
+void op_trsm_right(Dev*, const double*, int64_t, int64_t, const double*, int64_t, int64_t, double*, int64_t) {
+    throw std::logic_error("host sim: op_trsm_right without an RT-form factor");
 }
 void op_rebase_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* G, int64_t L,
                   int64_t ldg, double rel_tol, int* ndead, const double* A, int64_t M, int64_t lda, double* T, int64_t ldt,

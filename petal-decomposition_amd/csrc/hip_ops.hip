@@ -3371,6 +3371,77 @@ __global__ __launch_bounds__(64) void k_trsm_pack(const double* __restrict__ A, 
     }
 }
 
+// X = R^-1 . B for an upper-triangular R in RT form (round 6: the final stage's U = Z (R^-1 Uh) without the explicit inverse -- with it
+// the last factorisation of a fit can be k_chol_rt4's): blocked BACK substitution X_I = T_II (B_I - sum_{K > I} R_IK X_K), one wave per
+// 16 COLUMNS of B (columns are independent), X_K in the accumulator layout (register r of lane (g, c): row g + 4 r, column c) -- the
+// B operand of the products that use it; the A operands R_IK / T_II come from L2 with transposed addressing (A[i][k'] = block[i][g + 4 r]).
+// Epilogue as k_trsm_pack's: X (fp64) and the three bf16 operand planes of the product that follows (k_pack_p3's layout), through
+// one LDS transpose.  M (the order of R) = 16 NB <= 144 is also the row count of B; rows of the planes beyond M are zeros.
+template <int NB>
+__global__ __launch_bounds__(64) void k_trsm_left_pack(const double* __restrict__ RT, int64_t ldt, const double* __restrict__ B, int64_t ldb,
+                                                       double* __restrict__ X_out, int64_t ldxo, bf16x8* __restrict__ pk3, int NTtot) {
+    constexpr int M = 16 * NB, MP = (M + 31) / 32 * 32;
+    __shared__ double sX[MP * 17];
+    const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+    const int64_t j0 = (int64_t)blockIdx.x * 16;
+    cf64x4 X[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[I][r] = B[(int64_t)(16 * I + lk + 4 * r) * ldb + j0 + li];
+    // block row I of RT (its blocks K >= I), transposed addressing, two register sets (as k_trsm_pack: the next row is requested while
+    // this one is used)
+    cf64x4 rt[2][NB];
+    auto load_row = [&](int I, cf64x4(&dst)[NB]) {
+        const double* rrow = RT + (int64_t)(16 * I + li) * ldt + lk;
+#pragma unroll
+        for (int K = 0; K < NB; ++K)
+            if (K >= I) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[K][r] = rrow[16 * K + 4 * r];
+            }
+    };
+    load_row(NB - 1, rt[(NB - 1) & 1]);
+#pragma unroll
+    for (int I = NB - 1; I >= 0; --I) {
+        if (I > 0) load_row(I - 1, rt[(I - 1) & 1]);
+        const cf64x4(&cur)[NB] = rt[I & 1];
+        cf64x4 acc = X[I];
+#pragma unroll
+        for (int K = I + 1; K < NB; ++K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur[K][r], X[K][r], acc, 0, 0, 0);
+        }
+        cf64x4 xi = cf64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xi = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][r], acc[r], xi, 0, 0, 0);
+        X[I] = xi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sX[(16 * I + lk + 4 * r) * 17 + li] = xi[r];
+            if (X_out) X_out[(int64_t)(16 * I + lk + 4 * r) * ldxo + j0 + li] = xi[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MP > M)
+        for (int e = lane; e < (MP - M) * 17; e += 64) sX[M * 17 + e] = 0.0;
+    __syncthreads();
+    if (pk3) {
+#pragma unroll
+        for (int cc = 0; cc < MP / 32; ++cc) {                    // item = 8 rows (group lk of the 32-row chunk) of column li
+            f32x8 x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (float)sX[(32 * cc + 8 * lk + e) * 17 + li];
+            bf16x8 h, m, l;
+            split3(x, h, m, l);
+            const int64_t tile = (int64_t)cc * NTtot + blockIdx.x;
+            pk3[(tile * 3 + 0) * 64 + lane] = h;
+            pk3[(tile * 3 + 1) * 64 + lane] = m;
+            pk3[(tile * 3 + 2) * 64 + lane] = l;
+        }
+    }
+}
+
 constexpr int CHOL_THREADS = 512;
 // ---- fast Cholesky-inverse for L <= 140: R and T both packed COLUMN-major in LDS (cp(k, c) = c (c + 1) / 2 + k, k <= c),
 // so every inner product below walks contiguous words with incremental addresses (no index arithmetic in the loops);
@@ -6121,7 +6192,7 @@ static void launch_xp(Dev* d, const float* X, int64_t n, int K, int64_t ldx, con
 struct AbsmaxReq { int64_t cols, row_offset; double *absmax, *idx, *sign; };
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
-                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am = nullptr,
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, int prod_rt, const AbsmaxReq* am = nullptr,
                          bool p2_hint = false, bool steering = false);
 void op_gemm_xp(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                 int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, int p_planes, bool steering) {
@@ -6147,10 +6218,11 @@ void op_gemm_xp_prod(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_
 }
 void op_gemm_xp_prod_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* A, int64_t M,
                             int64_t lda, const double* T, int64_t N, int64_t ldt, double* P_out, int64_t ldpo, void* Z, int64_t ldz,
-                            int64_t row_offset, double* absmax, double* idx, double* sign, bool store_product) {
+                            int64_t row_offset, double* absmax, double* idx, double* sign, bool store_product, bool a_rt) {
     const bool fused = dt == F32 && gemm_split_product(d) && n >= 64 && K % 16 == 0 && K > 0 && N % 16 == 0 && N > 0 && ldx % 4 == 0 &&
                        aligned16(X) && (!mu || aligned16(mu)) && ldz % 4 == 0 && aligned16(Z) && K < (1 << 24) && N < (1 << 24) &&
                        n < (int64_t(1) << 31) && P_out != nullptr;
+    if (a_rt && !(fused && M == K && M % 16 == 0 && M <= TRSM_MAXM)) throw std::logic_error("op_gemm_xp_prod_absmax: RT-form operand outside the fused path");
     if (!fused) {
         op_gemm_xp_prod(d, dt, X, n, K, ldx, mu, A, M, lda, T, N, ldt, P_out, ldpo, Z, ldz);
         op_col_absmax(d, dt, Z, n, N, ldz, row_offset, absmax, idx, sign);
@@ -6159,7 +6231,7 @@ void op_gemm_xp_prod_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K,
     const AbsmaxReq am{N, row_offset, absmax, idx, sign};
     // (store_product = false: the caller only wants svd_flip's scan -- the product stays in the accumulators, 26 MB less to write at
     // configs[1])
-    gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, N, ldt, nullptr, store_product ? Z : nullptr, ldz, nullptr, A, M, lda, P_out, ldpo, false, &am);
+    gemm_xp_impl(d, dt, X, n, K, ldx, mu, T, N, ldt, nullptr, store_product ? Z : nullptr, ldz, nullptr, A, M, lda, P_out, ldpo, a_rt ? 2 : 0, &am);
 }
 // Z = (X - mu) P with svd_flip's column scan (first row of largest |z| per column, its sign) taken from the product kernel's
 // accumulators where that kernel runs -- no second pass over Z, and no store of Z at all when store_product is false.
@@ -6178,7 +6250,7 @@ void op_gemm_xp_absmax(Dev* d, int dt, const void* X, int64_t n, int64_t K, int6
 }
 static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
                          int64_t ldp, const void* bias, void* Z, int64_t ldz, double* sumsq, const double* prod_A, int64_t prod_M,
-                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, bool prod_rt, const AbsmaxReq* am, bool p2_hint, bool steering) {
+                         int64_t prod_lda, double* prod_out, int64_t prod_ldo, int prod_rt, const AbsmaxReq* am, bool p2_hint, bool steering) {
     if (n == 0 || N == 0) return;
     const bool mfma = dt == F32 && K % 16 == 0 && K > 0 && ldx % 4 == 0 && aligned16(X) && (!mu || aligned16(mu)) && n >= 64 &&
                       K < (1 << 24) && N < (1 << 24) && N % 16 == 0 && ldz % 4 == 0 && aligned16(Z) && (!bias || aligned16(bias));
@@ -6256,7 +6328,18 @@ static void gemm_xp_impl(Dev* d, int dt, const void* X, int64_t n, int64_t K, in
         const bool x2 = p2 && steering && opt_on(d, OPT_STEERING);   // (a steering pass: X on two planes too; the wide form only)
         if (prod_A) {
             // P = prod_A . P: the fp64 GEMM kernel writes the product (prod_out) AND its operand planes from its epilogue
-            if (prod_rt)   // P is R in RT form: blocked triangular solve instead of the product with the explicit inverse
+            if (prod_rt == 2) {   // prod_A is R in RT form and the operand is R^-1 P: blocked back substitution, one wave per 16 columns
+                switch ((int)(prod_M / 16)) {
+#define PETAL_TRSML_CASE(NB)                                                                                                       \
+    case NB:                                                                                                                       \
+        hipLaunchKernelGGL((k_trsm_left_pack<NB>), dim3(cdiv(N, 16)), dim3(64), 0, d->stream, prod_A, prod_lda, P, ldp, prod_out, prod_ldo, Ppk3, NTtot); \
+        break
+                    PETAL_TRSML_CASE(1); PETAL_TRSML_CASE(2); PETAL_TRSML_CASE(3); PETAL_TRSML_CASE(4); PETAL_TRSML_CASE(5);
+                    PETAL_TRSML_CASE(6); PETAL_TRSML_CASE(7); PETAL_TRSML_CASE(8); PETAL_TRSML_CASE(9);
+#undef PETAL_TRSML_CASE
+                    default: throw std::runtime_error("k_trsm_left_pack: order out of range");
+                }
+            } else if (prod_rt)   // P is R in RT form: blocked triangular solve instead of the product with the explicit inverse
                 switch ((int)(N / 16)) {
 #define PETAL_TRSM_CASE(NB)                                                                                                        \
     case NB:                                                                                                                       \
@@ -7095,11 +7178,12 @@ static void chol_inv_blocked(Dev* d, const double* G, int64_t L, int64_t ldg, do
 }
 
 // the re-basing factorisation in RT form (what k_trsm_pack reads): k_chol_rt4 for M = 16 NB <= 144
-static void launch_chol_rt(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t M) {
+static void launch_chol_rt(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead, int64_t M,
+                           int64_t ncount = 0) {
     switch ((int)(M / 16)) {
 #define PETAL_CHOL_RT_CASE(NB)                                                                                                      \
     case NB:                                                                                                                        \
-        hipLaunchKernelGGL((k_chol_rt4<NB>), dim3(1), dim3(256), 0, d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead, (int)L);      \
+        hipLaunchKernelGGL((k_chol_rt4<NB>), dim3(1), dim3(256), 0, d->stream, G, (int)L, ldg, T, ldt, rel_tol, ndead, (int)(ncount > 0 ? ncount : L)); \
         break
         PETAL_CHOL_RT_CASE(1); PETAL_CHOL_RT_CASE(2); PETAL_CHOL_RT_CASE(3); PETAL_CHOL_RT_CASE(4); PETAL_CHOL_RT_CASE(5);
         PETAL_CHOL_RT_CASE(6); PETAL_CHOL_RT_CASE(7); PETAL_CHOL_RT_CASE(8); PETAL_CHOL_RT_CASE(9);
@@ -7704,6 +7788,30 @@ void op_chol_inv(Dev* d, const double* G, int64_t L, int64_t ldg, double* T, int
                        ndead, (int)Lz, (const double*)nullptr, 0, (int)(ndead_cols > 0 ? ndead_cols : L));
     launch_check();
 }
+bool op_chol_rt(Dev* d, int dt, int64_t n, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead,
+                int64_t Lz, int64_t ndead_cols) {
+    if (Lz < L) Lz = L;
+    const bool rt = dt == F32 && gemm_split_product(d) && n >= 64 && n < (int64_t(1) << 31) && L > 0 && L <= CHOL2_MAXL && Lz % 16 == 0 &&
+                    Lz <= TRSM_MAXM;
+    if (!rt) { op_chol_inv(d, G, L, ldg, T, ldt, rel_tol, ndead, Lz, ndead_cols); return false; }
+    launch_chol_rt(d, G, L, ldg, T, ldt, rel_tol, ndead, Lz, ndead_cols);
+    return true;
+}
+void op_trsm_right(Dev* d, const double* A, int64_t rows, int64_t lda, const double* RT, int64_t M, int64_t ldt, double* out, int64_t ldo) {
+    if (rows % 16 != 0 || M % 16 != 0 || M > TRSM_MAXM) throw std::logic_error("op_trsm_right: shape outside the kernel");
+    switch ((int)(M / 16)) {
+#define PETAL_TRSMR_CASE(NB)                                                                                                         \
+    case NB:                                                                                                                         \
+        hipLaunchKernelGGL((k_trsm_pack<NB, false>), dim3(cdiv(rows, 16)), dim3(64), trsm_lds_bytes(16 * NB), d->stream, A, lda, RT, ldt, rows, \
+                           out, ldo, (bf16x8*)nullptr, NB);                                                                          \
+        break
+        PETAL_TRSMR_CASE(1); PETAL_TRSMR_CASE(2); PETAL_TRSMR_CASE(3); PETAL_TRSMR_CASE(4); PETAL_TRSMR_CASE(5);
+        PETAL_TRSMR_CASE(6); PETAL_TRSMR_CASE(7); PETAL_TRSMR_CASE(8); PETAL_TRSMR_CASE(9);
+#undef PETAL_TRSMR_CASE
+        default: throw std::logic_error("op_trsm_right: order out of range");
+    }
+    launch_check();
+}
 void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool clustered, int64_t Lz, int64_t ncheck,
              int* verdict, bool verdict_fresh, double gap_tol_override) {
     if (L == 0) { if (verdict && verdict_fresh) HIP_CHECK(hipMemsetAsync(verdict, 0, sizeof(int), d->stream)); return; }
@@ -7755,7 +7863,9 @@ void op_eigh(Dev* d, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, 
         hipLaunchKernelGGL((k_tridiag_w<TM>), dim3(1), dim3(TRR_THREADS), lds_r, d->stream, A, (int)L, lda, dd, ee, HV, tau, gg, flag, V, ldv, (int)(pad_done ? 0 : Lz), (ext_verdict && !verdict_fresh) ? 0 : 1); \
     } while (0)
             // l <= 80: the 8-byte form (78.5 us at l = 74, where a step is a chain of latencies and the 16-byte form measures 83.6);
-            // above: the 16-byte form (238 us at l = 138 against 290)
+            // above: the 16-byte form (238 us at l = 138 against 290).  (Round 6 built a form with the MATRIX in registers, only vectors
+            // through LDS: parity-green and no faster -- 78.2 us at l = 74: the step is a chain of dependent latencies, not LDS
+            // bandwidth; dev/tridiag_q_kernel.h, EXPERIMENTS.md.)
             if (L <= 80) PETAL_TRI_LAUNCH(10, 2);
             else PETAL_TRIW_LAUNCH(9);
 #undef PETAL_TRI_LAUNCH

@@ -125,7 +125,9 @@ void op_gemm_xp_prod(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64
 void op_gemm_xp_prod_absmax(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu,
                             const double* A, int64_t M, int64_t lda, const double* T, int64_t N, int64_t ldt,
                             double* P_out, int64_t ldpo, void* Z, int64_t ldz,
-                            int64_t row_offset, double* absmax, double* idx, double* sign, bool store_product = true);
+                            int64_t row_offset, double* absmax, double* idx, double* sign, bool store_product = true, bool a_rt = false);
+// (a_rt: A is not a matrix to multiply with but an upper-triangular R in RT form, as op_chol_rt left it -- P = R^-1 T by blocked back
+//  substitution; only after op_chol_rt returned true)
 // (store_product = false: Z may be left unwritten where the scan comes out of the product kernel's accumulators)
 // op_gemm_xp with the same scan (absmax / idx / sign: N doubles each, as op_col_absmax delivers them over the leading N columns)
 void op_gemm_xp_absmax(Dev*, int dtype, const void* X, int64_t n, int64_t K, int64_t ldx, const void* mu, const double* P, int64_t N,
@@ -240,6 +242,15 @@ void op_components_out(Dev*, int dtype, const double* Bt, int64_t ldb, const dou
 // Lz > L: T is additionally zero-filled out to Lz x Lz (the padded extent of the caller's buffers).
 // ndead_cols > 0: only dependent columns j < ndead_cols count towards *ndead (orders the one-workgroup kernel takes; larger
 // orders count them all).
+// The factorisation of op_chol_inv WITHOUT the explicit inverse where the device has the kernels for it (fp32 data in the split-product
+// mode, L <= 140, Lz a multiple of 16 <= 144, 64 <= n < 2^31 rows in the product that follows): returns true and leaves T in "RT form"
+// -- diagonal 16 x 16 blocks T_JJ = R_JJ^-1, the blocks above them R itself, zeros below -- which only op_trsm_right and
+// op_gemm_xp_prod_absmax(a_rt = true) understand; otherwise it IS op_chol_inv and returns false.  (Round 6: the last factorisation of
+// a RandomizedPca fit on the register-resident kernel of the power iterations, 15 instead of 40 us at l = 74.)
+bool op_chol_rt(Dev*, int dtype, int64_t n, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead,
+                int64_t Lz, int64_t ndead_cols);
+// out (rows x M fp64, ldo) = A (rows x M, lda) . R^-1 for R in RT form (M x M, ldt); rows a multiple of 16
+void op_trsm_right(Dev*, const double* A, int64_t rows, int64_t lda, const double* RT, int64_t M, int64_t ldt, double* out, int64_t ldo);
 void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64_t ldt, double rel_tol, int* ndead = nullptr,
                  int64_t Lz = 0, int64_t ndead_cols = 0);
 // symmetric PSD A (L x L) -> eigenvalues w (descending) and eigenvectors in the COLUMNS of V.  A may be destroyed.

@@ -427,16 +427,16 @@ def ica_parity(ctx, n, d, nc, seed, dtype=np.float32, tol_src=5e-3, n_components
 def ica_split_gram_case(ctx, n, d, nc):
     """FastICA whitening from the split-product covariance (fp32 data, >= 256 padded features, optimistic run): parity as ica_parity on
     well-conditioned mixing (the fast covariance stands: ica_gram_split = 1, no redo); on mixing matrices whose kept eigenvalues
-    spread over 0.7 decades (inside the accept bound of ONE decade: stands) and over 1.5 and 4 decades (the spectrum verdict must send
+    spread over ~0.8 decades (inside the accept bound of ONE decade: stands) and over ~1.8 and ~4.3 decades (the spectrum verdict must send
     the fit to the fp64 covariance) -- every one of them held to the oracle (nothing pinned the accept boundary)."""
     ica_parity(ctx, n, d, nc, seed=61, dtype=np.float32, n_components=nc)
     st = ctx.stats()
     assert st["ica_gram_split"] == 1 and st["ica_redo"] == 0, st
-    for amp_decades, stands in ((0.35, True), (0.75, False), (2.0, False)):   # source amplitudes over a decades: lambda over 2 a
+    # source amplitudes over `a` decades: lambda over 2 a decades times the Gaussian mixing matrix's own spread (a factor ~2 at these shapes)
+    for amp_decades, stands in ((0.25, True), (0.75, False), (2.0, False)):
         rng = np.random.default_rng(62 + int(100 * amp_decades))
         s_ = rng.laplace(size=(n, nc))
-        q, _ = np.linalg.qr(rng.standard_normal((d, nc)))                     # orthonormal mixing directions: the spread is the amplitudes'
-        a = (q.T * np.sqrt(d)) * np.logspace(0, -amp_decades, nc)[:, None]
+        a = rng.standard_normal((nc, d)) * np.logspace(0, -amp_decades, nc)[:, None]
         x = (s_ @ a + 1e-4 * rng.standard_normal((n, d))).astype(np.float32)
         w0 = rng.standard_normal((nc, nc)).astype(np.float32)
         m = petal.FastIca(ctx=ctx, n_components=nc)

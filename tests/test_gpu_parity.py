@@ -15,6 +15,7 @@ def ctx(request):
     import petal_decomposition_amd as petal
     c = petal.Context(0)          # raises (no CPU fallback) when the HIP library or the GPU is missing
     c.set_gemm_mode(request.param)
+    c.gemm_mode_name = request.param
     yield c
     c.close()
 
@@ -150,15 +151,16 @@ def test_means_folded_into_the_first_fused_pass(ctx):
     fused power-iteration pass: centred about the means of a strided row sample, the exact column sums from an all-ones column of
     z, sum (x - mu0)^2 from the splits, then a rank-one move to the true centre.  Data with |mu| = 40 sigma, and rows sorted so that
     the head of the matrix is far from the mean; in fp32-MFMA mode the same cases run the separate means pass."""
+    fold = ctx.gemm_mode_name == "bf16x3"        # (the fused pass, and with it the fold, belongs to the split-product mode)
     ctx.set_option("means_fold_rows", 0)       # (the product folds from 200000 rows on: see test_gpu_fullsize / bench)
     try:
-        pc.means_fold_case(ctx, 20000, 512, 64, device=True, expect_folded=True)
-        pc.means_fold_case(ctx, 9001, 512, 32, n_iter=7, expect_folded=True)
+        pc.means_fold_case(ctx, 20000, 512, 64, device=True, expect_folded=fold)
+        pc.means_fold_case(ctx, 9001, 512, 32, n_iter=7, expect_folded=fold)
         ctx.set_option("means_fold_rows", -1)  # never: the separate means pass, same parity, and the stats say so
         pc.means_fold_case(ctx, 9001, 512, 32, n_iter=7, expect_folded=False)
     finally:
         ctx.set_option("means_fold_rows", 200000)
-    pc.means_fold_case(ctx, 200000, 512, 16, device=True, expect_folded=True)   # at the product's own threshold
+    pc.means_fold_case(ctx, 200000, 512, 16, device=True, expect_folded=fold)   # at the product's own threshold
 
 
 def test_components_beyond_a_ring_slot(ctx):
