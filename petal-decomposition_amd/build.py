@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpetal_hip.so")
 SOURCES = ["hip_ops.hip", "algo.cpp", "api.cpp", "rccl.cpp"]
-HEADERS = ["ops.h", "ctx.h", os.path.join("..", "..", "include", "petal_hip.h")]
+HEADERS = ["ops.h", "ctx.h", os.path.join("..", "..", "include", "petal_hip.h")] + \
+    [os.path.join("kernels", f) for f in sorted(os.listdir(os.path.join(CSRC, "kernels"))) if f.endswith(".inc")]   # the parts of hip_ops.hip
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -26,7 +26,7 @@ def main() -> int:
     torch.cuda.set_device(local)
     ctx = petal.Context(local)
     if world == 1:
-        os.environ["PETAL_FORCE_COLLECTIVE"] = "1"
+        ctx.set_option("force_collective", 1)   # (a one-rank communicator still takes the sharded code path)
     ctx.use_rccl()
     info = ctx.collective_info()
     # the communicator itself must say it spans the job (a library without the query reports -1: not a failure)
@@ -40,6 +40,9 @@ def main() -> int:
     omega = np.random.default_rng(6).standard_normal((d, k + 4)).astype(np.float32)
     model = petal.RandomizedPca(k, ctx=ctx, n_iter=2, n_oversample=4)
     model.fit(x, omega=omega)
+    if ctx.stats()["allreduce_calls"] < 2 + 3:    # prologue, n_iter + 1 products, the svd_flip key: the collective must have RUN
+        print(f"rccl_probe: rank {rank}: the fit did not go through the collective: {ctx.stats()}", file=sys.stderr)
+        return 1
     comp = torch.from_numpy(np.ascontiguousarray(model.components(), dtype=np.float64))
     ref = comp.clone()
     dist.broadcast(ref, src=0)

@@ -389,7 +389,7 @@ def test_rccl_allreduce_hook_single_rank(ctx):
 
 def test_builtin_rccl_collective_single_rank(ctx):
     """The library's own collective (petal_ctx_init_rccl: ncclAllReduce on the ctx stream, RCCL bound with dlopen) on a
-    one-rank communicator, with PETAL_FORCE_COLLECTIVE routing the fit through the complete sharded code path (rank
+    one-rank communicator, with PETAL_OPT_FORCE_COLLECTIVE routing the fit through the complete sharded code path (rank
     info, fused [G | Yp] all-reduces, device-packed svd_flip key).  A one-rank all-reduce is the identity, so the
     sharded path must reproduce the plain fit."""
     import os
@@ -412,14 +412,17 @@ def test_builtin_rccl_collective_single_rank(ctx):
                 c2.use_rccl()
             else:
                 c2.use_torch_distributed()
-            os.environ["PETAL_FORCE_COLLECTIVE"] = "1"
-            try:
-                m = petal.RandomizedPca(8, ctx=c2, n_iter=3)
-                m.fit(x, omega=omega)
-                ica = petal.FastIca(np.random.default_rng(1), c2, n_components=4)
-                ica.fit(x)
-            finally:
-                del os.environ["PETAL_FORCE_COLLECTIVE"]
+            c2.set_option("force_collective", 1)    # (PETAL_OPT_FORCE_COLLECTIVE: an option of the ctx since round 6, not an environment read per call)
+            m = petal.RandomizedPca(8, ctx=c2, n_iter=3)
+            m.fit(x, omega=omega)
+            st = c2.stats()
+            assert st["allreduce_calls"] == 3 + 3, st       # the sharded path RAN: prologue, n_iter + 1 products, the svd_flip key
+            if how == "rccl":
+                info = c2.collective_info()
+                assert info["kind"] == "rccl" and info["ncclCommCount"] in (-1, 1) and info["ncclCommUserRank"] in (-1, 0), info
+            ica = petal.FastIca(np.random.default_rng(1), c2, n_components=4)
+            ica.fit(x)
+            assert c2.stats()["allreduce_calls"] >= 2, c2.stats()
             np.testing.assert_allclose(m.components(), ref.components(), rtol=0, atol=2e-6)
             np.testing.assert_allclose(m.singular_values(), ref.singular_values(), rtol=1e-6)
             np.testing.assert_allclose(m.explained_variance_ratio(), ref.explained_variance_ratio(), rtol=1e-5)
@@ -427,6 +430,22 @@ def test_builtin_rccl_collective_single_rank(ctx):
             c2.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_probe_single_rank():
+    """petal-decomposition_amd/rccl_probe.py -- the child-process check `bench.py --gpus N` runs on every rank before it trusts the
+    built-in collective -- exercised at world = 1: own communicator (ncclCommCount == 1 asserted inside), one sharded fit, exit 0."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "petal-decomposition_amd", "rccl_probe.py")], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
 
 
 def test_split_product_gemm_matches_fp32_mfma():
