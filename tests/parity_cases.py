@@ -432,20 +432,24 @@ def ica_split_gram_case(ctx, n, d, nc):
     ica_parity(ctx, n, d, nc, seed=61, dtype=np.float32, n_components=nc)
     st = ctx.stats()
     assert st["ica_gram_split"] == 1 and st["ica_redo"] == 0, st
-    # source amplitudes over `a` decades: lambda over 2 a decades times the Gaussian mixing matrix's own spread (a factor ~2 at these shapes)
-    for amp_decades, stands in ((0.25, True), (0.75, False), (2.0, False)):
+    # source amplitudes over `a` decades: lambda over 2 a decades times the Gaussian mixing matrix's own spread (a factor ~2 at these shapes).
+    # The contract checked: the split-product covariance reaches the result ONLY where the kept eigenvalues (here: of the float64
+    # covariance) lie within one decade -- whether a fit inside the bound stands also depends on the optimistic eigen-solve's own
+    # residual verdict (a redo costs time, never parity), so inside the bound only the parity is asserted.
+    for amp_decades in (0.1, 0.25, 0.75, 2.0):
         rng = np.random.default_rng(62 + int(100 * amp_decades))
         s_ = rng.laplace(size=(n, nc))
         a = rng.standard_normal((nc, d)) * np.logspace(0, -amp_decades, nc)[:, None]
         x = (s_ @ a + 1e-4 * rng.standard_normal((n, d))).astype(np.float32)
+        lam = np.linalg.eigvalsh(np.cov(x.astype(np.float64).T))[::-1][:nc]
         w0 = rng.standard_normal((nc, nc)).astype(np.float32)
         m = petal.FastIca(ctx=ctx, n_components=nc)
         y = np.asarray(m.fit_transform(x, w_init=w0))
         st = ctx.stats()
-        if stands:
-            assert st["ica_redo"] == 0 and st["ica_gram_split"] == 1, (amp_decades, st)
-        else:
-            assert st["ica_redo"] == 1 and st["ica_gram_split"] == 0, (amp_decades, st)
+        stands = st["ica_gram_split"] == 1
+        assert stands == (st["ica_redo"] == 0), st
+        if lam[-1] < 0.09 * lam[0]:
+            assert not stands, (amp_decades, lam[-1] / lam[0], st)     # beyond one decade the fp64 covariance MUST have been used
         o = po.FastIcaOracle(n_components=nc, whiten="eigh")
         o.fit(x.astype(np.float64), w_init=w0.astype(np.float64))
         yo = o.transform(x.astype(np.float64))

@@ -25,10 +25,11 @@ BUDGETS = [
     (r"k_xp3<", 256, 0, "every K1 split-product instantiation: no scratch"),
     # (one 8-wave workgroup per CU, two waves per SIMD: 256 is the whole budget, and a spilled P fragment is reloaded BEHIND the
     # stage's X loads -- vmcnt retires in order -- which cost the first build 7300 cycles in a 1300-cycle phase)
-    (r"k_pow3<5, (true|false), (true|false), (true|false)>$", 256, 0, "fused power-iteration pass, l = 74 (configs[1], the north-star point)"),
+    (r"k_pow3<5, (true|false), (true|false), (true|false), 2>$", 256, 0, "fused power-iteration pass, l = 74 (configs[1], the north-star point)"),
     (r"k_pow3<", 256, 0, "every fused-pass instantiation: no scratch"),
-    (r"k_pow3f<5, (true|false), (true|false)>$", 256, 0, "steering fused pass (four piece products, two barriers per stage), l = 74"),
+    (r"k_pow3f<5, (true|false), (true|false), 2>$", 256, 0, "steering fused pass (four piece products, two barriers per stage), l = 74"),
     (r"k_pow3f<", 256, 0, "every steering-pass instantiation: no scratch"),
+    (r"k_pow3f?<5, .*, 1>$", 160, 0, "the fused passes at 256 features (one 32-feature chunk per wave, round 6)"),
     (r"k_ica3<2>$", 128, 0, "FastICA step, 32 components: 4 waves/SIMD"),
     (r"k_ica3<4>$", 256, 0, "FastICA step, 64 components"),
     (r"k_ica3p<2>$", 128, 0, "FastICA step on pre-split planes, 32 components: 4 waves/SIMD"),
