@@ -275,9 +275,11 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
         const double* in = src.f64();
         for (int rep = 2 - rounds; rep < 2; ++rep) {
             op_dgemm(dv, true, false, p, p, dp, 1.0, in, p, in, p, 0.0, G.f64(), p);
-            op_chol_inv(dv, G.f64(), p, p, T.f64(), p, 1e-14);
             double* out = rep == 0 ? R.f64() : dst.f64();
-            op_dgemm(dv, false, false, dp, p, p, 1.0, in, p, T.f64(), p, 0.0, out, p);
+            // (round 6: the register-resident factorisation + a triangular solve where the device has them -- p = 48 / 80 at the
+            // configs: 3 x 21 -> 3 x 9 us of a configs[2] fit; the explicit inverse otherwise)
+            if (op_chol_rt(dv, F64, dp, G.f64(), p, p, T.f64(), p, 1e-14, nullptr, p, 0)) op_trsm_right(dv, in, dp, p, T.f64(), p, p, out, p);
+            else op_dgemm(dv, false, false, dp, p, p, 1.0, in, p, T.f64(), p, 0.0, out, p);
             in = out;
         }
     };
