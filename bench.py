@@ -347,7 +347,7 @@ def main():
 
         if per["K3 (Y' = Xc^T.(Xc.P), fused)"] > 0:
             v = per["K3 (Y' = Xc^T.(Xc.P), fused)"]
-            out["fused_pass"] = {"kernel": "k_pow3", "avg_launch_ms": round(v, 5), "launches_per_fit": n_iter + 1,
+            out["fused_pass"] = {"kernel": "k_pow3", "avg_launch_ms": round(v, 5), "launches_per_fit": fused_launches(n_iter),
                                  "algorithmic_bytes": 4.0 * (n * d + 2 * d * l), "GB/s_algorithmic": round(4.0 * (n * d + 2 * d * l) / (v * 1e-3) / 1e9, 1),
                                  "note": "Y' = Xc^T (Xc P): both products of a power iteration in one pass, X read ONCE, Z neither written "
                                          "nor read (the last pass of a fit also stores Z)"}
@@ -503,12 +503,18 @@ def steering_passes(n, d, l, n_iter, mode, redo=0, world=1):
     per tile in both products) -- every fused pass but the last one of the fit, which stores Z and keeps its five / six piece products."""
     if not (mode == "bf16x3" and d == 512 and l <= 80 and n_iter >= 3 and redo == 0) or os.environ.get("PETAL_NO_POW3_FAST"):
         return 0
-    return n_iter   # (the first pass too, with or without the means gathered in it)
+    return fused_launches(n_iter) - 1   # (the first pass too, with or without the means gathered in it)
+
+
+def fused_launches(n_iter):
+    """fused passes per fit where the fused kernel runs: one per product pair, n_iter + 1 -- but n_iter at n_iter <= 3, whose first pair is
+    K1, a re-basing of the sketch on the tall side, K2 (algo.cpp, `rebase_sketch`)"""
+    return n_iter + 1 if n_iter >= 4 else n_iter
 
 
 def k3_pieces(n_iter, steering):
     """bf16 piece products per fp32 product, averaged over the n_iter + 1 fused passes of a fit: 4 in a steering pass, 5.5 in the others"""
-    return (4.0 * steering + 5.5 * (n_iter + 1 - steering)) / (n_iter + 1)
+    return (4.0 * steering + 5.5 * (fused_launches(n_iter) - steering)) / fused_launches(n_iter)
 
 
 def steering_k12(l, n_iter, mode, redo=0):

@@ -1,0 +1,77 @@
+"""dev: random shapes on the round-6 paths against the oracle -- RandomizedPca whose re-basing / final stage run on k_chol_rt4 + the
+triangular solves in EVERY data type and GEMM mode (any l <= 140), the fused pass at 241 .. 256 features beside 497 .. 512, short and long
+iteration counts, centred and not; FastICA / exact Pca whose whitening eigen-solve orthonormalises through the same kernels (few components of
+many features).  usage: python dev/fuzz_round6.py <seed> <cases>   (FUZZ_GEMM=fp32 for the fp32-MFMA mode)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import petal_decomposition_amd as petal
+import parity_cases as pc
+ctx = petal.Context(0)
+if os.environ.get("FUZZ_GEMM"): ctx.set_gemm_mode(os.environ["FUZZ_GEMM"])
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+rng = np.random.default_rng(seed0)
+only = os.environ.get('FUZZ6_ONLY', '')
+bad = 0
+from oracle import petal_oracle as po
+def tol_for(k):   # (dev/fuzz_rpca.py's: the planted spectrum spans three decades over k components)
+    return max(2e-5, 3e-6 / (1.0 - 10.0 ** (-3.0 / max(k, 1))))
+def classify(n, d, k, it, seed, cent, err_text):
+    """a miss of the tolerance: the ORACLE in float32 on the same input and Omega (the reference's own arithmetic) against the fp64 oracle"""
+    x = po.synth_pca(n, d, k, seed=seed, dtype=np.float32)
+    om = np.random.default_rng(seed + 1000).standard_normal((d, k + 10)).astype(np.float32)
+    o = po.RandomizedPcaOracle(k, centering=cent, n_iter=it); o._inner_fit(x.astype(np.float64), omega=om.astype(np.float64))
+    o32 = po.RandomizedPcaOracle(k, centering=cent, n_iter=it); o32._inner_fit(x, omega=om)
+    e32 = pc.rowwise_rel(o32.components.astype(np.float64), o.components).max()
+    return f"fp32 oracle misses the fp64 one by {e32:.2e}"
+def run(tag, fn):
+    global bad
+    try:
+        r = fn()
+        print(f"ok   {tag} -> {r}", flush=True)
+    except Exception as e:
+        bad += 1
+        print(f"FAIL {tag}: {str(e)[:200]}", flush=True)
+for case in range(ncase):
+    # 1. the fused pass at both feature widths (fp32 data, default mode) / K1 + K2 otherwise
+    d = int(rng.choice([241, 250, 255, 256, 497, 500, 511, 512]))
+    n = int(rng.choice([4096, 8192, 10000, 20011, 33333, 60000]))
+    k = int(rng.choice([3, 16, 33, 54, 64, 70]))
+    it = int(rng.choice([2, 3, 4, 5, 7]))
+    cent = bool(rng.integers(0, 4))
+    dev = bool(rng.integers(0, 2))
+    def fused():
+        try:
+            r = pc.rpca_parity(ctx, n, d, k, it, seed=6000 + case, dtype=np.float32, tol=tol_for(k), tol_sigma=5e-5, centering=cent, device=dev)
+        except AssertionError as e:
+            raise AssertionError(f"{str(e)[:90]} | {classify(n, d, k, it, 6000 + case, cent, str(e))}")
+        st = getattr(pc.rpca_parity, 'last_fit_stats', None) or ctx.stats()
+        return f"{r} fused launches {st['pow_launches']} redo {st['rpca_redo']}"
+    if only in ("", "fused"): run(f"rpca float32 n={n} d={d} k={k} n_iter={it} cent={cent} dev={dev}", fused)
+    # 2. the factorisation orders 1 .. 9 blocks in fp64 (no operand planes anywhere: k_trsm_pack / k_trsm_left_pack write fp64 only)
+    d2 = int(rng.choice([64, 100, 160, 200, 320]))
+    n2 = int(rng.choice([1000, 3001, 8000]))
+    k2 = int(rng.integers(1, min(d2, 130) - 10))
+    it2 = int(rng.choice([1, 2, 4, 7]))
+    if only in ("", "f64"): run(f"rpca float64 n={n2} d={d2} k={k2} n_iter={it2}",
+        lambda: pc.rpca_parity(ctx, n2, d2, k2, it2, seed=7000 + case, dtype=np.float64, tol=1e-9))
+    # 3. the same orders for fp32 data off the fused pass's widths
+    d3 = int(rng.choice([96, 128, 200, 300, 384, 640, 1024]))
+    k3 = int(rng.integers(1, min(d3 // 2, 128)))
+    it3 = int(rng.choice([3, 4, 5, 7]))
+    def wide():
+        try:
+            return pc.rpca_parity(ctx, n, d3, k3, it3, seed=8000 + case, dtype=np.float32, tol=tol_for(k3), tol_sigma=5e-5)
+        except AssertionError as e:
+            raise AssertionError(f"{str(e)[:90]} | {classify(n, d3, k3, it3, 8000 + case, True, str(e))}")
+    if only in ("", "wide"): run(f"rpca float32 n={n} d={d3} k={k3} n_iter={it3}", wide)
+    # 4. FastICA: few components of many features (subspace iteration with the RT-form orthonormalisation)
+    d4 = int(rng.choice([128, 256, 300, 512]))
+    nc = int(rng.choice([2, 5, 8, 16, 24, 32]))
+    n4 = int(rng.choice([5000, 20000, 50001]))
+    dt4 = np.float32 if rng.integers(0, 2) else np.float64
+    if only in ("", "ica"): run(f"ica {dt4.__name__} n={n4} d={d4} nc={nc}",
+        lambda: pc.ica_parity(ctx, n4, d4, nc, seed=9000 + case, dtype=dt4, n_components=nc, device=bool(case & 1)))
+print("failures:", bad)

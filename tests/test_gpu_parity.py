@@ -118,6 +118,18 @@ def test_rpca_low_iteration_counts_at_the_config_width(ctx, n_iter):
     pc.rpca_low_iter(ctx, 20000, 512, 64, n_iter, "geo97", np.float32, seed=320 + n_iter, device=True)
 
 
+@pytest.mark.parametrize("n,d,k,before", [(20011, 640, 89, 6.5e-5), (33333, 1024, 99, 1.5e-4), (4096, 384, 126, 3.6e-4), (20011, 300, 118, 1.4e-4)])
+def test_three_iterations_with_many_components(ctx, n, d, k, before):
+    """n_iter = 3 with 87 ... 126 components over the planted three decades (gaps of 2 - 3 % between neighbours): the junk the un-rebased
+    first product pair Xc^T (Xc Omega) leaves in the block's weakest directions is NOT washed out by two more iterations at such gaps --
+    dev/fuzz_round6.py (round 6) found these cases 3 - 10 x off the ORACLE RUN IN FLOAT32 (`before`: the round-5 and early round-6 errors, both
+    GEMM modes).  Three iterations therefore re-base the sketch on the tall side first, like n_iter 1 - 2 and like the crate's first LU
+    (src/pca.rs:709); the bar is dev/fuzz_rpca.py's, 3e-6 over the planted spectrum's relative gap."""
+    tol = max(2e-5, 3e-6 / (1.0 - 10.0 ** (-3.0 / k)))
+    assert before > tol
+    pc.rpca_parity(ctx, n, d, k, 3, seed=8000 + k, dtype=np.float32, tol=tol, tol_sigma=5e-5)
+
+
 def test_two_plane_verdict_and_exact_redo():
     """(split-product mode only: the fp32-MFMA mode has no two-plane operands)"""
     import petal_decomposition_amd as petal
@@ -141,10 +153,19 @@ def test_host_inputs_that_are_not_row_major(ctx, layout):
         x = np.asfortranarray(pc.po.synth_pca(100000, 512, 64, seed=2, dtype=np.float32))
         om = np.random.default_rng(3).standard_normal((512, 74)).astype(np.float32)
         m = petal.RandomizedPca(64, ctx=ctx, n_iter=5)
+        xc = np.ascontiguousarray(x)
+        def best_of(a, reps=3):
+            best = float("inf")
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                m.fit(a, omega=om)
+                best = min(best, time.perf_counter() - t0)
+            return best
         m.fit(x, omega=om)
-        t0 = time.perf_counter()
-        m.fit(x, omega=om)
-        assert time.perf_counter() - t0 < 0.1      # (upload + device gather + fit; the host gather alone took 0.3 s)
+        t_rowmajor, t_fortran = best_of(xc), best_of(x)
+        # (upload + device gather + fit against upload + fit of the same data, same box, same load: the host gather alone took
+        # 0.3 s = 50 x the row-major fit; an absolute bound here was flaky on shared boxes -- ADVICE round 5)
+        assert t_fortran < 4 * t_rowmajor + 0.02, (t_fortran, t_rowmajor)
 
 
 def test_means_folded_into_the_first_fused_pass(ctx):
@@ -417,7 +438,7 @@ def test_builtin_rccl_collective_single_rank(ctx):
             m = petal.RandomizedPca(8, ctx=c2, n_iter=3)
             m.fit(x, omega=omega)
             st = c2.stats()
-            assert st["allreduce_calls"] == 3 + 3, st       # the sharded path RAN: prologue, n_iter + 1 products, the svd_flip key
+            assert st["allreduce_calls"] == 3 + 3 + 1, st   # the sharded path RAN: prologue, n_iter + 1 products, the Gram matrix of the sketch (n_iter <= 3 re-bases it), the svd_flip key
             if how == "rccl":
                 info = c2.collective_info()
                 assert info["kind"] == "rccl" and info["ncclCommCount"] in (-1, 1) and info["ncclCommUserRank"] in (-1, 0), info
