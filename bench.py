@@ -21,6 +21,7 @@ alone at 1e6 x 512 in both modes; fastica_cfg3; pca_cfg1: the exact Pca on confi
 included -- never `value`).
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -103,13 +104,20 @@ def launch_ranks(n_ranks: int, share_gpu: bool = False) -> int:
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
+    # (ALL ranks are watched, not rank 0 first: a rank that dies leaves the others waiting in a collective for ever, and a parent
+    # blocked in rank 0's wait() would never see it)
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = max(rc, abs(p.returncode))
-        if p.returncode != 0:  # a failed rank leaves the others waiting in a collective: end exactly the ones we started
-            for q in procs:
-                if q.poll() is None:
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            if p.poll() is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(p.returncode))
+            if p.returncode != 0:  # end exactly the ones we started
+                print(f"[bench] a rank process exited with {p.returncode}: ending the others", file=sys.stderr)
+                for q in live:
                     q.kill()
     return rc
 
@@ -186,10 +194,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if args.share_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
             args.collective = "torch"
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=600))   # (a stuck collective is an error after ten minutes, not a hung job)
         if args.single_rank_group:
             os.environ["PETAL_FORCE_COLLECTIVE"] = "1"
     else:

@@ -74,4 +74,23 @@ for case in range(ncase):
     dt4 = np.float32 if rng.integers(0, 2) else np.float64
     if only in ("", "ica"): run(f"ica {dt4.__name__} n={n4} d={d4} nc={nc}",
         lambda: pc.ica_parity(ctx, n4, d4, nc, seed=9000 + case, dtype=dt4, n_components=nc, device=bool(case & 1)))
+    # 5. data far off centre, centred and NOT (uncentred: the mean direction is sigma_1, hundreds of times the planted spectrum's head)
+    d5 = int(rng.choice([256, 300, 512, 1024]))
+    k5 = int(rng.choice([8, 32, 64, 100]))
+    it5 = int(rng.choice([3, 4, 5, 7]))
+    off = float(rng.choice([3.0, 40.0, 300.0]))
+    cent5 = bool(rng.integers(0, 2))
+    def offcentre():
+        x = po.synth_pca(n, d5, k5, seed=9500 + case, dtype=np.float64)
+        x = (x + off * x.std(axis=0) * np.sign(np.random.default_rng(case).standard_normal(d5))).astype(np.float32)
+        om = np.random.default_rng(9500 + case + 1000).standard_normal((d5, k5 + 10)).astype(np.float32)
+        try:
+            r = pc.rpca_parity(ctx, n, d5, k5, it5, seed=9500 + case, dtype=np.float32, tol=tol_for(k5), tol_sigma=5e-5, centering=cent5, x=x)
+        except AssertionError as e:
+            o = po.RandomizedPcaOracle(k5, centering=cent5, n_iter=it5); o._inner_fit(x.astype(np.float64), omega=om.astype(np.float64))
+            o32 = po.RandomizedPcaOracle(k5, centering=cent5, n_iter=it5); o32._inner_fit(x, omega=om)
+            e32 = pc.rowwise_rel(o32.components.astype(np.float64), o.components).max()
+            raise AssertionError(f"{str(e)[:90]} | fp32 oracle misses the fp64 one by {e32:.2e}")
+        return f"{r} redo {getattr(pc.rpca_parity, 'last_fit_stats', {}).get('rpca_redo')}"
+    if only in ("", "off"): run(f"rpca float32 n={n} d={d5} k={k5} n_iter={it5} off={off} cent={cent5}", offcentre)
 print("failures:", bad)

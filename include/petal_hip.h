@@ -80,7 +80,10 @@ typedef struct petal_stats {
     int64_t x_zero_copy;       /* 1: the caller's device buffer was streamed in place                                       */
     /* RandomizedPca: how the last fit ran */
     int64_t rpca_redo;         /* 0: the optimistic run stood; 1: redone with three-plane operands (heavy-tailed spectrum: the
-                                  16-bit rounding of the sketch matrix / iterates was not harmless); 2: redone on the robust path */
+                                  16-bit rounding of the sketch matrix / iterates was not harmless); 3: redone with the sketch re-based on the
+                                  tall side before its product with Xc^T (fp32 data; a pivot was lost in the first run: on full-rank data
+                                  that is the un-rebased first product pair's, sigma_1 / sigma_l beyond ~5e3); 2: redone on the robust
+                                  path (a pivot lost again, or fp64 data: rank deficiency)                                        */
     double  pow_ms;            /* fused power-iteration pass Y' = Xc^T (Xc P) (one pass over X): summed kernel time           */
     int64_t pow_launches;
     double  stream_ms;         /* the other row-streaming kernels of a RandomizedPca fit (means pass, U = Z (T Uh)): with profiling at
@@ -93,6 +96,9 @@ typedef struct petal_stats {
     int64_t ica_gram_split;    /* 1: the covariance that reached the result came from the split-product Gram kernels              */
     int64_t means_folded;      /* 1: the column means of the last fit were gathered INSIDE its first pass over X (RandomizedPca: the
                                   first fused power-iteration pass; FastIca: the split-product Gram pass), 0: a means pass of its own */
+    int64_t eigh_redo;         /* RandomizedPca: 1: the small eigen-solve of the last fit (B B^T, order l) was repeated with the Jacobi solver --
+                                  wanted eigenvalues too close, relative to the largest, for the two-stage solver's vectors; the passes over
+                                  X were NOT repeated (round 6; until then this verdict redid the whole fit on the robust path)        */
 } petal_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */

@@ -222,7 +222,7 @@ bool op_gram_split(Dev* d, const void* X, int64_t n, int64_t dd, int64_t dp, int
     return true;
 }
 void op_flip_key(Dev*, const double* t, double* key, int64_t L, const int* flag) {
-    if (flag) key[L] = flag[0] != 0 ? 2.0 : (flag[1] != 0 ? 1.0 : 0.0);
+    if (flag) key[L] = flag[0] != 0 ? 3.0 : (flag[1] != 0 ? 1.0 : (flag[2] != 0 ? 2.0 : 0.0));
     for (int64_t j = 0; j < L; ++j) {
         uint64_t bits = 0;
         const double a = t[j] < 0 ? 0.0 : t[j];
@@ -363,9 +363,14 @@ void op_whiten_k(Dev*, const double* U, int64_t ldu, const double* lam, int64_t 
         }
     }
 }
-void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool /*clustered*/, int64_t Lz,
+void op_eigh(Dev* dv, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, double* w, double tol_rel, bool clustered, int64_t Lz,
              int64_t /*ncheck*/, int* verdict, bool verdict_fresh, double /*gap_tol_override*/) {
     if (verdict && verdict_fresh) *verdict = 0;
+    // TEST HOOK (this simulation only): PETAL_OPT_EIGH_JACOBI = 2 makes every optimistic solve report "eigenvalues too close", as the
+    // device's two-stage solver does on clustered spectra -- the host logic behind that verdict (RandomizedPca repeats its small stage
+    // alone with the Jacobi solver, `petal_stats.eigh_redo`; sharded fits agree on it) then runs in the CPU suite.  The solve below
+    // is the same Jacobi iteration either way, so the repeated stage must reproduce the first one's numbers.
+    if (verdict && !clustered && L > 0 && dv->opt[OPT_EIGH_JACOBI] == 2.0) *verdict |= 1;
     for (int64_t r = 0; r < Lz; ++r)
         for (int64_t c = 0; c < Lz; ++c)
             if (r >= L || c >= L) V[r * ldv + c] = 0.0;

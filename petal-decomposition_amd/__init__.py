@@ -73,7 +73,7 @@ class petal_stats(C.Structure):
                 ("x_row_pitch_bytes", C.c_int64), ("x_zero_copy", C.c_int64),
                 ("rpca_redo", C.c_int64), ("pow_ms", C.c_double), ("pow_launches", C.c_int64),
                 ("stream_ms", C.c_double), ("stream_launches", C.c_int64), ("ica_redo", C.c_int64), ("ica_gram_split", C.c_int64),
-                ("means_folded", C.c_int64)]
+                ("means_folded", C.c_int64), ("eigh_redo", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

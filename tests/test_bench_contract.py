@@ -21,7 +21,7 @@ def _run(*extra, launcher_env=True, n_gpus=1):
         for key in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(key, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-northstar", *extra],
-                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                         capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)   # (a run takes 10 - 60 s)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.split("\n") if ln.strip()]
     assert len(lines) == 1, f"stdout must be the JSON line only, got {len(lines)} lines: {res.stdout[:500]}"
@@ -155,7 +155,7 @@ def test_self_launch_two_ranks_sharing_the_gpu():
 def test_single_gpu_record_has_the_northstar_fit():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                         capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)   # (a run takes 10 - 60 s)
     assert res.returncode == 0, res.stderr[-2000:]
     rec = json.loads(res.stdout.strip().split("\n")[-1])
     assert rec["scaling"] == "weak" and rec["config"]["rows_per_gpu"] == 100000

@@ -46,6 +46,30 @@ def test_two_plane_verdict_and_exact_redo(ctx):
     pc.two_plane_verdict_case(ctx)
 
 
+def test_close_eigenvalues_repeat_the_small_stage_only(ctx):
+    """The eigen-solver's closeness verdict (forced by the simulation's hook, PETAL_OPT_EIGH_JACOBI = 2; on the device:
+    tests/test_gpu_parity.py::test_close_eigenvalues_repeat_the_small_eigen_solve_only) repeats the small stage of a RandomizedPca fit --
+    eigen-solve, verdicts, components, U, svd_flip -- with the Jacobi solver; the passes over X stand (rpca_redo = 0).  Also when the
+    heavy-tail verdict sends the same fit through the exact pipeline first."""
+    pc.rpca_parity(ctx, 1200, 64, 8, 4, seed=31)
+    base = (pc.rpca_parity.last_fit_stats["eigh_redo"], pc.rpca_parity.last_fit_stats["rpca_redo"])
+    assert base == (0, 0), base
+    ctx.set_option("eigh_jacobi", 2)
+    try:
+        pc.rpca_parity(ctx, 1200, 64, 8, 4, seed=31)
+        st = pc.rpca_parity.last_fit_stats
+        assert st["eigh_redo"] == 1 and st["rpca_redo"] == 0, st
+        ctx.set_gemm_mode("bf16x3")
+        ctx.set_option("verdict_threshold", 1e-12)      # (every optimistic run is "heavy-tailed": exact redo, then the small stage again)
+        pc.rpca_parity(ctx, 1200, 64, 8, 4, seed=31)
+        st = pc.rpca_parity.last_fit_stats
+        assert st["eigh_redo"] == 1 and st["rpca_redo"] == 1, st
+    finally:
+        ctx.set_option("eigh_jacobi", 0)
+        ctx.set_option("verdict_threshold", 4e-6)
+        ctx.set_gemm_mode("fp32")
+
+
 def test_components_beyond_a_ring_slot(ctx):
     """k d esz above the 8 MiB ring slot (the single result view threw there): the components leave by their own
     copy.  k = 512, d = 2048 fp64 = 8 MiB + the small block."""

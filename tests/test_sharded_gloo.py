@@ -41,6 +41,15 @@ def _worker(rank, world, port, out_dir):
     y = m.fit_transform(xs, omega=om)
     res["rpca_components"], res["rpca_singular"], res["rpca_mean"] = m.components(), m.singular_values(), m.mean()
     res["rpca_evr"], res["rpca_y"] = m.explained_variance_ratio(), y
+    # the eigen-solver's closeness verdict (forced by the simulation's hook): every rank repeats the SMALL stage with the Jacobi solver --
+    # the agreed code rides the svd_flip key's all-reduce -- and nothing else; same numbers as the fit above
+    ctx.set_option("eigh_jacobi", 2)
+    m3 = petal.RandomizedPca(k, ctx=ctx, n_iter=4)
+    y3 = m3.fit_transform(xs, omega=om)
+    st3 = ctx.stats()
+    ctx.set_option("eigh_jacobi", 0)
+    res["eig_components"], res["eig_singular"], res["eig_y"] = m3.components(), m3.singular_values(), y3
+    res["eig_stats"] = np.array([st3["eigh_redo"], st3["rpca_redo"]])
     # exact Pca, f64
     x64 = synth_pca(900, 12, 3, seed=78, dtype=np.float64)
     xs64 = x64[rank * 450:(rank + 1) * 450]
@@ -99,6 +108,11 @@ def test_two_rank_sharded_matches_single(tmp_path):
     assert np.abs(y - ys).max() <= 1e-4 * np.abs(ys).max()      # includes the cross-rank svd_flip decision
     o = po.RandomizedPcaOracle(k, n_iter=4).fit(x.astype(np.float64), omega=om.astype(np.float64))
     assert pc.rowwise_rel(r0["rpca_components"].astype(np.float64), o.components).max() < 1e-5
+
+    for r in (r0, r1):   # the repeated small stage: flagged on both ranks, no redo of the passes, the first fit's numbers
+        assert r["eig_stats"].tolist() == [1, 0], r["eig_stats"]
+        assert np.array_equal(r["eig_components"], r["rpca_components"]) and np.array_equal(r["eig_singular"], r["rpca_singular"])
+        assert np.array_equal(r["eig_y"], r["rpca_y"])
 
     own = petal.RandomizedPca(k, ctx=ctx, n_iter=4, rng=np.random.default_rng(100)).fit(x)   # rank 0's generator
     assert pc.rowwise_rel(r0["own_rpca_components"], own.components()).max() < 2e-6
