@@ -272,9 +272,7 @@ def main():
     # Clock ramp (untimed, like the W warm-up steps behind it): the seconds of host-side data generation above leave the GPU in its
     # idle clock state, and W = 5 one-millisecond fits do not bring it back (measured: the first 25 ms after an idle period run
     # 5-10 % slow).  A quarter of a second of the same fits does; the timed region below is still exactly K steps.
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.clock_ramp_s:
-        model.fit(x, omega=omega)
+    ramp(lambda: model.fit(x, omega=omega), args.clock_ramp_s, dist, torch, "cpu" if args.share_gpu else dev)
     for _ in range(args.warmup):
         model.fit(x, omega=omega)
     sync_all()
@@ -424,10 +422,20 @@ def main():
         dist.destroy_process_group()
 
 
-def ramp(fn, seconds=0.25):
-    """untimed repetitions of fn for `seconds`: brings the GPU clocks back up after an idle (host-side) stretch"""
+def ramp(fn, seconds=0.25, dist=None, torch=None, dev=None):
+    """untimed repetitions of fn for `seconds`: brings the GPU clocks back up after an idle (host-side) stretch.
+    With a process group (fn is then a SHARDED fit, full of all-reduces) the decision to go on is rank 0's, broadcast before every
+    repetition: a loop on each rank's own clock lets two ranks disagree about the number of fits by one -- the first then sits in its
+    last fit's all-reduce and the second in the barrier behind the loop, for ever (round 6: seen twice in ~20 two-rank runs)."""
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
+    while True:
+        go = time.perf_counter() - t0 < seconds
+        if dist is not None:
+            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=dev)
+            dist.broadcast(flag, src=0)
+            go = bool(int(flag.item()))
+        if not go:
+            return
         fn()
 
 
@@ -836,9 +844,7 @@ def bench_fastica(args, cfg, petal, ctx, torch, dist, dev, rank, world, collecti
     x = torch.from_numpy(synth_ica(n, d, nc, seed=8, dtype=np.float32, row_seed=None if world == 1 else 8 + 1000 * rank)).to(dev)
     w0 = np.random.default_rng(7).standard_normal((nc, nc)).astype(np.float32)
     m = petal.FastIca(ctx=ctx, n_components=nc)
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.clock_ramp_s:   # (clock ramp: see main)
-        m.fit(x, w_init=w0)
+    ramp(lambda: m.fit(x, w_init=w0), args.clock_ramp_s, dist, torch, "cpu" if args.share_gpu else dev)   # (clock ramp: see main)
     for _ in range(args.warmup):
         m.fit(x, w_init=w0)
     sync_all()

@@ -36,6 +36,31 @@ def _run(*extra, launcher_env=True, n_gpus=1):
     return rec
 
 
+def test_clock_ramp_follows_rank_zero():
+    """bench.py's untimed clock ramp repeats sharded fits for a quarter of a second: on each rank's OWN clock two ranks can disagree about
+    the number of fits by one, and then one waits in a fit's all-reduce while the other waits in the barrier behind the loop (a hung
+    `--gpus N` job; round 6).  The decision is rank 0's, broadcast before every repetition: a rank whose own clock says "go on" for
+    ever stops when the broadcast says stop, and one whose clock says "stop" at once goes on while the broadcast says go."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch
+
+    class FakeDist:                     # the broadcast delivers rank 0's decisions: go, go, go, stop
+        def __init__(self):
+            self.decisions = [1, 1, 1, 0]
+        def broadcast(self, flag, src=0):
+            assert src == 0
+            flag[0] = self.decisions.pop(0)
+
+    for seconds in (3600.0, 0.0):       # this rank's own clock: never done / done before it starts
+        calls = []
+        bench.ramp(lambda: calls.append(1), seconds, FakeDist(), torch, "cpu")
+        assert len(calls) == 3, (seconds, len(calls))
+    calls = []
+    bench.ramp(lambda: calls.append(1), 0.0)     # no process group: the local clock decides
+    assert calls == []
+
+
 def test_roofline_bound_is_computed_from_the_shape():
     """bench.py picks the binding roofline per shape: at l = 74 (configs[1]) the X stream binds the split-product kernels
     ("hbm"); at l = 138 (configs[3]) the six bf16 piece products take longer than the bytes ("mfma" on the bf16 pipe:
