@@ -93,4 +93,25 @@ for case in range(ncase):
             raise AssertionError(f"{str(e)[:90]} | fp32 oracle misses the fp64 one by {e32:.2e}")
         return f"{r} redo {getattr(pc.rpca_parity, 'last_fit_stats', {}).get('rpca_redo')}"
     if only in ("", "off"): run(f"rpca float32 n={n} d={d5} k={k5} n_iter={it5} off={off} cent={cent5}", offcentre)
+    # 6. exact Pca (full SVD) of off-centre data, centred and not, both data types, tall and wide
+    n6 = int(rng.choice([50, 300, 3001, 20000])); d6 = int(rng.choice([16, 64, 100, 256, 300]))
+    k6 = int(rng.integers(1, max(2, min(n6, d6, 48))))
+    dt6 = np.float32 if rng.integers(0, 2) else np.float64
+    off6 = float(rng.choice([0.0, 3.0, 40.0])); cent6 = bool(rng.integers(0, 2))
+    def exact_pca():
+        x = po.synth_pca(n6, d6, k6, seed=9700 + case, dtype=np.float64)
+        x = (x + off6 * x.std(axis=0) * np.sign(np.random.default_rng(case).standard_normal(d6))).astype(dt6)
+        o = po.PcaOracle(k6, centering=cent6, thin=True); o._inner_fit(x.astype(np.float64))
+        m = petal.Pca(k6, centering=cent6, ctx=ctx); m.fit(x)
+        rel = pc.rowwise_rel(m.components().astype(np.float64), o.components).max()
+        srel = np.abs(np.asarray(m.singular_values(), dtype=np.float64) / o.singular - 1).max()
+        tol = (5e-5 if dt6 == np.float32 else 1e-8) * (1.0 if (cent6 or off6 == 0.0) else (1.0 + off6))
+        if rel > tol or srel > tol:
+            e32 = float("nan")
+            if dt6 == np.float32:
+                o32 = po.PcaOracle(k6, centering=cent6, thin=True); o32._inner_fit(x)
+                e32 = pc.rowwise_rel(o32.components.astype(np.float64), o.components).max()
+            raise AssertionError(f"components {rel:.2e} sigma {srel:.2e} > {tol:.1e} | fp32 oracle misses the fp64 one by {e32:.2e}")
+        return f"rel {rel:.1e} sigma {srel:.1e}"
+    if only in ("", "pca"): run(f"pca {dt6.__name__} n={n6} d={d6} k={k6} off={off6} cent={cent6}", exact_pca)
 print("failures:", bad)

@@ -333,7 +333,7 @@ void op_chol_inv(Dev*, const double* G, int64_t L, int64_t ldg, double* T, int64
     }
 }
 void op_ritz_residual(Dev*, const double* CV, int64_t ldc, const double* Vr, int64_t ldv, int64_t rows, int64_t nc, const double* theta,
-                      const int* flag, double* out3, double* w_out) {
+                      const int* flag, double* out3, double* w_out, const int* flag2) {
     double worst = 0, bad = 0;
     if (w_out) for (int64_t j = 0; j < nc; ++j) w_out[j] = theta[j];
     for (int64_t j = 0; j < nc; ++j) {
@@ -343,6 +343,7 @@ void op_ritz_residual(Dev*, const double* CV, int64_t ldc, const double* Vr, int
         else worst = std::max(worst, s2);
     }
     if (flag && *flag != 0) bad = 1;
+    if (flag2 && *flag2 != 0) bad = 1;
     out3[0] = worst; out3[1] = nc > 0 ? theta[0] : 0.0; out3[2] = bad;
 }
 void op_whiten_k(Dev*, const double* U, int64_t ldu, const double* lam, int64_t rows, int64_t nc, int64_t ncp, double scale,

@@ -255,6 +255,14 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
     DBuf Q(dv, sizeof(double) * dp * p), Y(dv, sizeof(double) * dp * p), G(dv, sizeof(double) * p * p), T(dv, sizeof(double) * p * p);
     DBuf H(dv, sizeof(double) * p * p), S(dv, sizeof(double) * p * p), th(dv, sizeof(double) * p), R(dv, sizeof(double) * dp * p);
     DBuf r3(dv, sizeof(double) * 3), vf(dv, 64);
+    // vf: [0] the Ritz problem's closeness verdict, [1] the pivots the orthonormalisations below DROPPED.  A dropped column is a lost
+    // direction: from the random start every column of C Q carries eigen-direction j at lambda_j / lambda_1 of its length, the Gram matrix
+    // of the block squares that, and beyond lambda_1 / lambda_j ~ 1e7 the Cholesky pivot of direction j falls under the 1e-14 rule -- its
+    // Ritz value came back an exact ZERO with a zero residual, i.e. 'converged' (exact Pca of uncentred data 40 sigma off centre, 50 x 256,
+    // both data types: the last four of 22 singular values 0 instead of 1.2 ... 0.9; dev/fuzz_round6.py, round 6).  Any dropped pivot
+    // now fails the verdict and the caller's full eigen-solve takes over.
+    int* const ndrop = vf.as<int>() + 1;
+    dev_memset(dv, vf.p, 0, 64);
     if (!c.topk_seed || c.topk_seed_d != d || c.topk_seed_dp != dp || c.topk_seed_p != p) {   // (once per shape and ctx)
         std::vector<double> h(size_t(dp) * p, 0.0);
         uint64_t st = 0x9E3779B97F4A7C15ull;
@@ -278,7 +286,7 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
             double* out = rep == 0 ? R.f64() : dst.f64();
             // (round 6: the register-resident factorisation + a triangular solve where the device has them -- p = 48 / 80 at the
             // configs: 3 x 21 -> 3 x 9 us of a configs[2] fit; the explicit inverse otherwise)
-            if (op_chol_rt(dv, F64, dp, G.f64(), p, p, T.f64(), p, 1e-14, nullptr, p, 0)) op_trsm_right(dv, in, dp, p, T.f64(), p, p, out, p);
+            if (op_chol_rt(dv, F64, dp, G.f64(), p, p, T.f64(), p, 1e-14, ndrop, p, 0)) op_trsm_right(dv, in, dp, p, T.f64(), p, p, out, p);
             else op_dgemm(dv, false, false, dp, p, p, 1.0, in, p, T.f64(), p, 0.0, out, p);
             in = out;
         }
@@ -292,7 +300,7 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
         op_eigh(dv, H.f64(), p, p, S.f64(), p, th.f64(), 1e-15, false, 0, nc, resid3 ? vf.as<int>() : nullptr, true, gap_tol);
         op_dgemm(dv, false, false, dp, nc, p, 1.0, Q.f64(), p, S.f64(), p, 0.0, V, dp);        // Ritz vectors
         op_dgemm(dv, false, false, dp, nc, p, 1.0, Y.f64(), p, S.f64(), p, 0.0, R.f64(), p);   // C (Q S)
-        op_ritz_residual(dv, R.f64(), p, V, dp, dp, nc, th.f64(), resid3 ? vf.as<int>() : nullptr, out3, w);
+        op_ritz_residual(dv, R.f64(), p, V, dp, dp, nc, th.f64(), resid3 ? vf.as<int>() : nullptr, out3, w, ndrop);
     };
     auto deliver = [&] {};
     double h3[3], prev_rel = -1.0;
@@ -312,6 +320,7 @@ bool topk_eigh(petal_ctx& c, const double* C, int64_t d, int64_t dp, int64_t nc,
             dev_d2h(dv, h3, r3.p, sizeof(h3));
             dev_sync(dv);
             if (topk_verdict_ok(h3, verdict_tol)) { deliver(); return true; }
+            if (h3[2] != 0.0) return false;   // (a non-finite residual, or an orthonormalisation dropped a pivot: the full eigen-solve)
             // No gap behind the wanted pairs (a smoothly decaying spectrum): the residual falls by (lambda_{p+1} / lambda_nc)^2 per
             // check and would need hundreds of them.  Give up as soon as the measured rate says the remaining budget cannot get
             // there -- the caller's full eigen-solve costs about eight checks at d = 512 -- instead of running all twenty

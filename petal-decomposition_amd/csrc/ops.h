@@ -274,10 +274,10 @@ void op_eigh(Dev*, double* A, int64_t L, int64_t lda, double* V, int64_t ldv, do
 // (verdict_fresh: *verdict is cleared first instead of accumulated into; orders that ignore the verdict leave it 0)
 // Residual verdict of a Rayleigh-Ritz step without a host round trip: with the Ritz vectors Vr (rows x >= nc, ldv), their
 // images CV = C Vr (ldc) and the Ritz values theta,  out[0] = max_{j < nc} ||CV[:, j] - theta_j Vr[:, j]||_2^2,  out[1] = theta[0],
-// out[2] = 1 if one of those nc norms is not finite or *flag (nullable device int: op_eigh's verdict) is non-zero.  One launch,
-// no clear needed; the caller reads `out` with its other results.
+// out[2] = 1 if one of those nc norms is not finite or *flag / *flag2 (nullable device ints: op_eigh's verdict; the pivots the
+// orthonormalisations of the iteration dropped) is non-zero.  One launch, no clear needed; the caller reads `out` with its other results.
 void op_ritz_residual(Dev*, const double* CV, int64_t ldc, const double* Vr, int64_t ldv, int64_t rows, int64_t nc, const double* theta,
-                      const int* flag, double* out3, double* w_out = nullptr);   // w_out (nullable): receives theta[0 .. nc)
+                      const int* flag, double* out3, double* w_out = nullptr, const int* flag2 = nullptr);   // w_out (nullable): receives theta[0 .. nc)
 // FastICA whitening matrix from the eigenpairs of the covariance (ica.rs:190-208) in one launch:
 //   KT[i][j]  = s_j U[i][j] / sigma_j,  sigma_j = sqrt(max(lam_j, 0)) (0 where sigma_j == 0),  j < nc;  0 for nc <= j < ncp
 //   s_j = +-1 normalises the eigenvector's sign: its first component of largest magnitude becomes positive (an eigen-solver's

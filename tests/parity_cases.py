@@ -391,6 +391,25 @@ def pca_parity(ctx, n, d, k, seed, dtype=np.float64, tol=1e-9, thin_oracle=False
     assert np.abs(xr - xo).max() <= 100 * tol * np.abs(xo).max()
 
 
+def pca_wide_uncentred_case(ctx, dtype):
+    """Exact Pca WITHOUT centering (src/pca.rs:207-214 skipped) of a wide matrix 40 sigma off centre: 50 x 256, k = 22 -- the mean direction
+    is sigma_1 = 4.3e4, the last wanted singular values are ~1.  The subspace iteration that serves k << d orthonormalises by Cholesky-QR, and
+    from its random start the Gram matrix of C Q carries direction j at (lambda_j / lambda_1)^2 = 3e-19 of its diagonal: the pivots of the
+    last directions fell under the 1e-14 rule, their columns were dropped, and their Ritz pairs came back EXACT ZEROS with zero residual --
+    'converged' (both data types; dev/fuzz_round6.py, round 6).  A dropped pivot now fails the iteration's verdict and the full eigen-solver
+    takes over: every singular value within 1e-6 of the oracle's (the Gram route's floor at this kappa), components too."""
+    n, d, k = 50, 256, 22
+    x = po.synth_pca(n, d, k, seed=9711, dtype=np.float64)
+    x = (x + 40.0 * x.std(axis=0) * np.sign(np.random.default_rng(11).standard_normal(d))).astype(dtype)
+    o = po.PcaOracle(k, centering=False, thin=True)
+    o._inner_fit(x.astype(np.float64))
+    m = petal.Pca(k, centering=False, ctx=ctx)
+    m.fit(x)
+    s = np.asarray(m.singular_values(), dtype=np.float64)
+    assert s.min() > 0.5 and np.abs(s / o.singular - 1).max() <= 1e-6, (s[-4:], o.singular[-4:])
+    assert rowwise_rel(m.components().astype(np.float64), o.components).max() <= 1e-6
+
+
 def ica_parity(ctx, n, d, nc, seed, dtype=np.float32, tol_src=5e-3, n_components=None, device=False):
     """same X, same w_init: W_lib W_ref^T is the identity within tol; n_iter within +-1"""
     x = po.synth_ica(n, d, nc, seed=seed, dtype=dtype)

@@ -149,6 +149,11 @@ def test_close_eigenvalues_repeat_the_small_eigen_solve_only(ctx, n_iter):
     assert st["eigh_redo"] == 1 and st["rpca_redo"] == 0, st
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_exact_pca_keeps_small_singular_values_of_uncentred_data(ctx, dtype):
+    pc.pca_wide_uncentred_case(ctx, dtype)
+
+
 def test_two_plane_verdict_and_exact_redo():
     """(split-product mode only: the fp32-MFMA mode has no two-plane operands)"""
     import petal_decomposition_amd as petal

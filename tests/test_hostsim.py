@@ -70,6 +70,11 @@ def test_close_eigenvalues_repeat_the_small_stage_only(ctx):
         ctx.set_gemm_mode("fp32")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_exact_pca_keeps_small_singular_values_of_uncentred_data(ctx, dtype):
+    pc.pca_wide_uncentred_case(ctx, dtype)
+
+
 def test_components_beyond_a_ring_slot(ctx):
     """k d esz above the 8 MiB ring slot (the single result view threw there): the components leave by their own
     copy.  k = 512, d = 2048 fp64 = 8 MiB + the small block."""

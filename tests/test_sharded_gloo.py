@@ -50,6 +50,12 @@ def _worker(rank, world, port, out_dir):
     ctx.set_option("eigh_jacobi", 0)
     res["eig_components"], res["eig_singular"], res["eig_y"] = m3.components(), m3.singular_values(), y3
     res["eig_stats"] = np.array([st3["eigh_redo"], st3["rpca_redo"]])
+    # rank-deficient fp32 data (rank 3, l = 16): a pivot is lost, every rank retries with the sketch re-based (agreed code 3), loses it again
+    # and takes the robust path -- three runs, each rank the same collectives
+    rl = np.random.default_rng(12)
+    xl = (rl.standard_normal((n, 3)) @ rl.standard_normal((3, d))).astype(np.float32)
+    m4 = petal.RandomizedPca(k, ctx=ctx, n_iter=4).fit(xl[cut[rank]:cut[rank + 1]], omega=om)
+    res["low_components"], res["low_singular"], res["low_redo"] = m4.components(), m4.singular_values(), np.array([ctx.stats()["rpca_redo"]])
     # exact Pca, f64
     x64 = synth_pca(900, 12, 3, seed=78, dtype=np.float64)
     xs64 = x64[rank * 450:(rank + 1) * 450]
@@ -113,6 +119,15 @@ def test_two_rank_sharded_matches_single(tmp_path):
         assert r["eig_stats"].tolist() == [1, 0], r["eig_stats"]
         assert np.array_equal(r["eig_components"], r["rpca_components"]) and np.array_equal(r["eig_singular"], r["rpca_singular"])
         assert np.array_equal(r["eig_y"], r["rpca_y"])
+
+    rl = np.random.default_rng(12)
+    xl = (rl.standard_normal((n, 3)) @ rl.standard_normal((3, d))).astype(np.float32)
+    low = petal.RandomizedPca(k, ctx=ctx, n_iter=4).fit(xl, omega=om)
+    assert ctx.stats()["rpca_redo"] == 2 and int(r0["low_redo"][0]) == 2 and int(r1["low_redo"][0]) == 2
+    assert np.array_equal(r0["low_components"], r1["low_components"]) and np.array_equal(r0["low_singular"], r1["low_singular"])
+    sv = low.singular_values()
+    assert np.allclose(r0["low_singular"][:3], sv[:3], rtol=2e-6) and np.abs(r0["low_singular"][3:]).max() <= 1e-5 * sv[0]
+    assert pc.rowwise_rel(r0["low_components"][:3], low.components()[:3]).max() < 2e-5
 
     own = petal.RandomizedPca(k, ctx=ctx, n_iter=4, rng=np.random.default_rng(100)).fit(x)   # rank 0's generator
     assert pc.rowwise_rel(r0["own_rpca_components"], own.components()).max() < 2e-6
