@@ -34,4 +34,11 @@ rm -rf gpurun_out/pmc_ica3_j1 gpurun_out/pmc_pow3_j1 gpurun_out/pmc_pow3_j2 gpur
 # the phase stamps of the fused pass (debug library)
 bash dev/build_dbg.sh > /dev/null 2>&1
 python dev/pow3_phases.py > gpurun_out/final6_pow3_phases.txt 2>&1
+# the sweeps of the round (dev/fuzz_round6.py: six kinds, both GEMM modes; the standing sweeps; eig_stress; the determinism soak)
+timeout 1500 python dev/fuzz_round6.py 61 40 > gpurun_out/final6_fuzz_round6.txt 2>&1
+FUZZ_GEMM=fp32 timeout 1200 python dev/fuzz_round6.py 62 25 > gpurun_out/final6_fuzz_round6_fp32.txt 2>&1
+bash dev/fuzz_sweep.sh > gpurun_out/final6_fuzz_sweep.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o dev/eig_stress dev/eig_stress.hip petal-decomposition_amd/csrc/algo.cpp petal-decomposition_amd/csrc/api.cpp petal-decomposition_amd/csrc/rccl.cpp -ldl > /dev/null 2>&1
+./dev/eig_stress > gpurun_out/final6_eig_stress.txt 2>&1
+timeout 900 python dev/soak.py 1500 > gpurun_out/final6_soak.txt 2>&1
 echo done

@@ -67,3 +67,28 @@ for case in range(ncase):
         report(f"rpca {dt.__name__} {mode} n={n} d={d} k={k} it={it} off={off} cent={cent}", False, str(e)[:200])
     ctx.set_gemm_mode("fp32")
 print("failures:", bad)
+# FastICA, strictly: the oracle started from the LIBRARY's side of the whitening rows' sign ambiguity (w_init . diag(s), s_j = the sign the
+# library's convention -- largest-magnitude component positive -- gives LAPACK's row j), so both run the same trajectory
+bad = 0
+rng = np.random.default_rng(seed0 + 1000)
+for case in range(ncase):
+    dt = np.float32 if rng.integers(0, 2) else np.float64
+    n = int(rng.choice([500, 2000, 5000])); d = int(rng.choice([4, 8, 16, 40, 100, 130]))
+    nc = int(rng.integers(2, min(d, 24) + 1)); off = float(rng.choice([0.0, 3.0, 40.0]))
+    x = po.synth_ica(n, d, nc, seed=400 + case, dtype=np.float64)
+    x = (x + off * x.std(axis=0) * np.sign(np.random.default_rng(case).standard_normal(d))).astype(dt)
+    w0 = np.random.default_rng(500 + case).standard_normal((nc, nc))
+    tag = f"ica {dt.__name__} n={n} d={d} nc={nc} off={off}"
+    try:
+        o = po.FastIcaOracle(n_components=nc, whiten="eigh"); o.fit(x.astype(np.float64), w_init=w0)
+        kk = o.k_
+        s = np.sign(kk[np.arange(nc), np.abs(kk).argmax(axis=1)])
+        o2 = po.FastIcaOracle(n_components=nc, whiten="eigh"); o2.fit(x.astype(np.float64), w_init=w0 * s[None, :]); yo = o2.transform(x.astype(np.float64))
+        m = petal.FastIca(ctx=ctx, n_components=nc); y = np.asarray(m.fit_transform(x, w_init=w0.astype(dt)), dtype=np.float64)
+        c = np.abs(y.T @ yo); perm = c.argmax(axis=1)
+        dev = max(np.abs(1.0 - c[np.arange(nc), perm]).max(), np.abs(c - np.eye(nc)[perm]).max()) if sorted(perm.tolist()) == list(range(nc)) else 9.0
+        tol = 5e-3 if dt == np.float32 else 1e-6
+        report(tag, dev <= tol and abs(m.n_iter - o2.n_iter) <= 1, f"dev {dev:.1e} iterations {m.n_iter}/{o2.n_iter} (plain oracle {o.n_iter}) redo {ctx.stats()['ica_redo']}")
+    except Exception as e:
+        report(tag, False, str(e)[:200])
+print("ica failures:", bad)

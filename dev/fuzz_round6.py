@@ -72,8 +72,21 @@ for case in range(ncase):
     nc = int(rng.choice([2, 5, 8, 16, 24, 32]))
     n4 = int(rng.choice([5000, 20000, 50001]))
     dt4 = np.float32 if rng.integers(0, 2) else np.float64
-    if only in ("", "ica"): run(f"ica {dt4.__name__} n={n4} d={d4} nc={nc}",
-        lambda: pc.ica_parity(ctx, n4, d4, nc, seed=9000 + case, dtype=dt4, n_components=nc, device=bool(case & 1)))
+    def ica_strict():
+        # STRICT: the oracle is started from the library's side of the whitening rows' sign ambiguity (w_init . diag(s), s_j = the sign the
+        # library's convention -- largest-magnitude component positive -- gives LAPACK's row j): same trajectory, same stop
+        x = po.synth_ica(n4, d4, nc, seed=9000 + case, dtype=dt4)
+        w0 = np.random.default_rng(9000 + case + 7).standard_normal((nc, nc))
+        o = po.FastIcaOracle(n_components=nc, whiten="eigh"); o.fit(x.astype(np.float64), w_init=w0)
+        sg = np.sign(o.k_[np.arange(nc), np.abs(o.k_).argmax(axis=1)])
+        o2 = po.FastIcaOracle(n_components=nc, whiten="eigh"); o2.fit(x.astype(np.float64), w_init=w0 * sg[None, :]); yo = o2.transform(x.astype(np.float64))
+        m = petal.FastIca(ctx=ctx, n_components=nc); y = np.asarray(m.fit_transform(x, w_init=w0.astype(dt4)), dtype=np.float64)
+        c = np.abs(y.T @ yo); perm = c.argmax(axis=1)
+        assert sorted(perm.tolist()) == list(range(nc)), perm
+        dev = max(np.abs(1.0 - c[np.arange(nc), perm]).max(), np.abs(c - np.eye(nc)[perm]).max())
+        assert dev <= (5e-3 if dt4 == np.float32 else 1e-6) and abs(m.n_iter - o2.n_iter) <= 1, (dev, m.n_iter, o2.n_iter)
+        return f"dev {dev:.1e} iterations {m.n_iter}/{o2.n_iter} (plain oracle {o.n_iter})"
+    if only in ("", "ica"): run(f"ica {dt4.__name__} n={n4} d={d4} nc={nc}", ica_strict)
     # 5. data far off centre, centred and NOT (uncentred: the mean direction is sigma_1, hundreds of times the planted spectrum's head)
     d5 = int(rng.choice([256, 300, 512, 1024]))
     k5 = int(rng.choice([8, 32, 64, 100]))

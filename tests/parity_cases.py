@@ -443,6 +443,34 @@ def ica_parity(ctx, n, d, nc, seed, dtype=np.float32, tol_src=5e-3, n_components
     return dev
 
 
+def ica_strict_parity(ctx, n, d, nc, seed, dtype=np.float32, tol=None, offset=0.0):
+    """FastIca::fit end to end (src/ica.rs:167-221) on the SAME trajectory as the oracle.  The whitening rows' signs are the eigen-solver's
+    (LAPACK's in the crate: arbitrary; here a convention: the component of largest magnitude positive), so `ica_parity` above can only compare
+    up to a signed permutation, each run stopped on its own trajectory -- and two trajectories of the same algorithm do not always stop at the
+    same fixed point (dev/r6_case_d.py, EXPERIMENTS.md round 6).  X1_lib = diag(s) X1_oracle, so the library's fit from w_init IS the
+    oracle's fit from w_init . diag(s): started there, the oracle must reproduce the library's sources and its iteration count."""
+    x = po.synth_ica(n, d, nc, seed=seed, dtype=np.float64)
+    if offset:
+        x = x + offset * x.std(axis=0) * np.sign(np.random.default_rng(seed + 1).standard_normal(d))
+    x = x.astype(dtype)
+    w0 = np.random.default_rng(seed + 7).standard_normal((nc, nc))
+    o = po.FastIcaOracle(n_components=nc, whiten="eigh")
+    o.fit(x.astype(np.float64), w_init=w0)
+    s = np.sign(o.k_[np.arange(nc), np.abs(o.k_).argmax(axis=1)])
+    o2 = po.FastIcaOracle(n_components=nc, whiten="eigh")
+    o2.fit(x.astype(np.float64), w_init=w0 * s[None, :])
+    yo = o2.transform(x.astype(np.float64))
+    m = petal.FastIca(ctx=ctx, n_components=nc)
+    y = np.asarray(m.fit_transform(x, w_init=w0.astype(dtype)), dtype=np.float64)
+    c = np.abs(y.T @ yo)
+    perm = c.argmax(axis=1)
+    assert perm.tolist() == list(range(nc)), perm          # not even a permutation: the same rows in the same order
+    dev = max(np.abs(1.0 - np.diag(c)).max(), np.abs(c - np.eye(nc)).max())
+    assert dev <= (tol if tol is not None else (2e-3 if dtype == np.float32 else 1e-7)), dev
+    assert abs(m.n_iter - o2.n_iter) <= (1 if dtype == np.float32 else 0), (m.n_iter, o2.n_iter)
+    return dev
+
+
 def ica_split_gram_case(ctx, n, d, nc):
     """FastICA whitening from the split-product covariance (fp32 data, >= 256 padded features, optimistic run): parity as ica_parity on
     well-conditioned mixing (the fast covariance stands: ica_gram_split = 1, no redo); on mixing matrices whose kept eigenvalues

@@ -154,6 +154,14 @@ def test_exact_pca_keeps_small_singular_values_of_uncentred_data(ctx, dtype):
     pc.pca_wide_uncentred_case(ctx, dtype)
 
 
+@pytest.mark.parametrize("n,d,nc,dtype,offset", [(20000, 128, 8, np.float64, 0.0), (50001, 256, 32, np.float32, 0.0), (20000, 300, 16, np.float32, 40.0),
+                                               (5000, 512, 24, np.float64, 3.0), (200000, 256, 32, np.float32, 0.0)])
+def test_fastica_on_the_oracles_trajectory(ctx, n, d, nc, dtype, offset):
+    """src/ica.rs:167-221 end to end, strictly (same rows, same order, same iteration count): see ica_strict_parity.  The first case is the
+    seed on which the sign-blind comparison had library and oracle 0.70 apart (both at a fixed point of the same iteration)."""
+    pc.ica_strict_parity(ctx, n, d, nc, seed=9034 if (n, d, nc) == (20000, 128, 8) else 600 + nc, dtype=dtype, offset=offset)
+
+
 def test_two_plane_verdict_and_exact_redo():
     """(split-product mode only: the fp32-MFMA mode has no two-plane operands)"""
     import petal_decomposition_amd as petal

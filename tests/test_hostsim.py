@@ -75,6 +75,12 @@ def test_exact_pca_keeps_small_singular_values_of_uncentred_data(ctx, dtype):
     pc.pca_wide_uncentred_case(ctx, dtype)
 
 
+@pytest.mark.parametrize("n,d,nc,dtype,offset", [(2000, 8, 8, np.float64, 0.0), (5000, 40, 12, np.float64, 40.0), (3000, 100, 5, np.float32, 0.0),
+                                               (2000, 130, 24, np.float32, 3.0)])
+def test_fastica_on_the_oracles_trajectory(ctx, n, d, nc, dtype, offset):
+    pc.ica_strict_parity(ctx, n, d, nc, seed=600 + nc, dtype=dtype, offset=offset)
+
+
 def test_components_beyond_a_ring_slot(ctx):
     """k d esz above the 8 MiB ring slot (the single result view threw there): the components leave by their own
     copy.  k = 512, d = 2048 fp64 = 8 MiB + the small block."""
