@@ -926,6 +926,14 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         htv = 0;
         for (int64_t j = 0; j < d; ++j) htv += std::max(0.0, hmu[dp + j] - ri.n_total * hmu[j] * hmu[j]);
     }
+    {   // non-finite input: the crate's gesdd reports info != 0 -> "did not converge" (linalg.rs:115).  Checked on what came back anyway --
+        // means, sums of squares, the spectrum: replicated values, so every rank of a sharded fit raises -- and on the RAW values (the
+        // max(., 0) clamps above turn a NaN into a zero)
+        bool finite = std::isfinite(keep[0]) && std::isfinite(htv);
+        for (int64_t j = 0; j < d; ++j) finite = finite && std::isfinite(hmu[j]) && (!tv_from_sq || tv_direct || std::isfinite(hmu[dp + j]));
+        for (int64_t j = 0; j < k; ++j) finite = finite && std::isfinite(hlam[j]);
+        if (!finite) linalg_error("did not converge");
+    }
     for (int64_t j = 0; j < k; ++j) {   // the components leave the ring with svd_flip's sign on row j (pca.rs:684)
         if (dt == F32) {
             const float* src = static_cast<const float*>(hcomp) + j * d;
@@ -1082,6 +1090,9 @@ void pca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, bool centering, voi
                                    : signs_from_triple(std::vector<double>(deferred.begin(), deferred.begin() + 3 * rp), rp);
     double tvar = 0;
     for (int64_t j = 0; j < d; ++j) tvar += hdiag[j];
+    // (non-finite input: the crate's gesvd comes back with info != 0 -> "did not converge", linalg.rs:84; the trace is replicated,
+    // so every rank of a sharded fit raises)
+    if (!std::isfinite(tvar)) linalg_error("did not converge");
     for (int64_t j = 0; j < k; ++j) {   // svd_flip's sign on row j of the components (already in place)
         if (sg[j] < 0) {
             if (dt == F32) { float* row = static_cast<float*>(components) + j * d; for (int64_t i = 0; i < d; ++i) row[i] = -row[i]; }

@@ -443,6 +443,29 @@ def ica_parity(ctx, n, d, nc, seed, dtype=np.float32, tol_src=5e-3, n_components
     return dev
 
 
+def degenerate_input_case(ctx, n, d, dtype):
+    """Inputs no factorisation exists for.  A NaN or an infinity anywhere in X: the crate's LAPACK calls come back with info != 0 and
+    every fit returns `DecompositionError::LinalgError` (src/linalg.rs:58, 84, 115) -- so do these (round 6: exact Pca had returned
+    finite garbage, RandomizedPca non-finite components).  All-zero and constant matrices are legal: zero singular values, finite
+    outputs, no hang."""
+    for bad in (np.nan, np.inf):
+        x = po.synth_pca(n, d, 5, seed=1, dtype=dtype)
+        x[n // 3, d // 2] = bad
+        for make in (lambda: petal.RandomizedPca(5, ctx=ctx, n_iter=4), lambda: petal.Pca(5, ctx=ctx), lambda: petal.FastIca(ctx=ctx, n_components=5)):
+            m = make()
+            try:
+                m.fit(x)
+            except petal.LinalgError:
+                continue
+            raise AssertionError(f"{type(m).__name__} accepted an input with {bad}")
+    for value in (0.0, 3.5):
+        x = np.full((n, d), value, dtype=dtype)
+        for make in (lambda: petal.RandomizedPca(5, ctx=ctx, n_iter=4), lambda: petal.Pca(5, ctx=ctx)):
+            m = make()
+            m.fit(x)
+            assert np.isfinite(np.asarray(m.components())).all() and np.abs(np.asarray(m.singular_values())).max() <= 1e-3 * max(value, 1.0) * np.sqrt(n * d)
+
+
 def ica_strict_parity(ctx, n, d, nc, seed, dtype=np.float32, tol=None, offset=0.0):
     """FastIca::fit end to end (src/ica.rs:167-221) on the SAME trajectory as the oracle.  The whitening rows' signs are the eigen-solver's
     (LAPACK's in the crate: arbitrary; here a convention: the component of largest magnitude positive), so `ica_parity` above can only compare

@@ -162,6 +162,12 @@ def test_fastica_on_the_oracles_trajectory(ctx, n, d, nc, dtype, offset):
     pc.ica_strict_parity(ctx, n, d, nc, seed=9034 if (n, d, nc) == (20000, 128, 8) else 600 + nc, dtype=dtype, offset=offset)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_inputs_without_a_factorisation(ctx, dtype):
+    pc.degenerate_input_case(ctx, 20000, 512, dtype)
+    pc.degenerate_input_case(ctx, 300, 24, dtype)
+
+
 def test_two_plane_verdict_and_exact_redo():
     """(split-product mode only: the fp32-MFMA mode has no two-plane operands)"""
     import petal_decomposition_amd as petal

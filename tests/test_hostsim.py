@@ -81,6 +81,11 @@ def test_fastica_on_the_oracles_trajectory(ctx, n, d, nc, dtype, offset):
     pc.ica_strict_parity(ctx, n, d, nc, seed=600 + nc, dtype=dtype, offset=offset)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_inputs_without_a_factorisation(ctx, dtype):
+    pc.degenerate_input_case(ctx, 500, 40, dtype)
+
+
 def test_components_beyond_a_ring_slot(ctx):
     """k d esz above the 8 MiB ring slot (the single result view threw there): the components leave by their own
     copy.  k = 512, d = 2048 fp64 = 8 MiB + the small block."""
