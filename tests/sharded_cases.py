@@ -103,7 +103,29 @@ def run_cfg5(petal, ctx, xs, rank):
     return {"components": ica.components, "mean": ica.means, "n_iter": np.array([ica.n_iter])}
 
 
+# UNCENTRED data 3 sigma off centre, k = 100 of 512 features, n_iter = 3: the eigen-solver's closeness verdict fires (round 6), every rank
+# must repeat the SMALL stage (agreed code 2 on the svd_flip key's all-reduce) and nothing else
+EIG = dict(n=12000, d=512, k=100, n_iter=3)
+
+
+def x_eig():
+    x = synth_pca(EIG["n"], EIG["d"], EIG["k"], seed=9500, dtype=np.float64)
+    return (x + 3.0 * x.std(axis=0) * np.sign(np.random.default_rng(7).standard_normal(EIG["d"]))).astype(np.float32)
+
+
+def omega_eig():
+    return np.random.default_rng(10500).standard_normal((EIG["d"], EIG["k"] + 10)).astype(np.float32)
+
+
+def run_eig(petal, ctx, xs, rank):
+    m = petal.RandomizedPca(EIG["k"], centering=False, ctx=ctx, n_iter=EIG["n_iter"])
+    m.fit(xs, omega=omega_eig())
+    st = ctx.stats()
+    return {"components": m.components(), "singular": m.singular_values(), "redo": np.array([st["eigh_redo"], st["rpca_redo"]])}
+
+
 CASES = {
+    "rpca32_close_eigenvalues": {"x": x_eig, "run": run_eig},
     "rpca32": {"x": x_rpca32, "run": run_rpca(np.float32, True), "both_modes": True},
     "rpca32_rerun": {"x": x_rpca32, "run": run_rpca(np.float32, True), "both_modes": True},   # run-to-run determinism
     "rpca32_own_omega": {"x": x_rpca32, "run": run_rpca(np.float32, False)},

@@ -123,6 +123,24 @@ def test_sharded_rpca_fp32_matches_single_and_oracle(ranks, mode):
     assert np.all(np.sign(np.sum(r0[pre + "components"] * o.components, axis=1)) == 1)
 
 
+def test_sharded_fit_repeats_only_the_small_stage_on_close_eigenvalues(ranks):
+    """the eigen-solver's closeness verdict in a SHARDED fit (round 6): agreed through the svd_flip key's all-reduce, every rank repeats the
+    small stage with the Jacobi solver and nothing else; same numbers as the single-process fit of the whole matrix"""
+    import petal_decomposition_amd as petal
+    r0, r1 = ranks[0], ranks[1]
+    name = "rpca32_close_eigenvalues.bf16x3."
+    assert r0[name + "redo"].tolist() == [1, 0] and r1[name + "redo"].tolist() == [1, 0], (r0[name + "redo"], r1[name + "redo"])
+    assert np.array_equal(r0[name + "components"], r1[name + "components"]) and np.array_equal(r0[name + "singular"], r1[name + "singular"])
+    ctx = petal.Context(0)
+    try:
+        m = petal.RandomizedPca(sc.EIG["k"], centering=False, ctx=ctx, n_iter=sc.EIG["n_iter"]).fit(sc.x_eig(), omega=sc.omega_eig())
+        assert ctx.stats()["eigh_redo"] == 1
+        assert pc.rowwise_rel(r0[name + "components"].astype(np.float64), m.components().astype(np.float64)).max() <= 2e-5
+        assert np.allclose(r0[name + "singular"], m.singular_values(), rtol=2e-6)
+    finally:
+        ctx.close()
+
+
 def test_sharded_rpca_rank0_omega_wins(ranks):
     """no explicit Omega: every rank's model draws from its own generator; the library replicates rank 0's draw"""
     import petal_decomposition_amd as petal
