@@ -17,6 +17,18 @@ def cases(seed):
         e = np.concatenate([[0], np.round(np.cumsum(w) * n)]).astype(int); e[-1] = n
         out.append((kind, n, d, k, [int(v) for v in e], 900 + 10 * seed + c))
     return out
+def variant(sd):
+    """per-case flavour of the RandomizedPca cases (round 6: the verdict codes a sharded fit has to agree on): data off centre without
+    centering, the eigen-solver's closeness verdict forced (the simulation's hook), rank-deficient data, the iteration count"""
+    r = np.random.default_rng(sd + 77)
+    return dict(off=float(r.choice([0.0, 0.0, 40.0])), cent=bool(r.integers(0, 2)), hook=bool(r.integers(0, 3) == 0), lowrank=bool(r.integers(0, 4) == 0),
+                n_iter=int(r.choice([1, 3, 4, 7])))
+def rpca_data(synth_pca, n, d, k, sd, dt, v):
+    x = synth_pca(n, d, k, seed=sd, dtype=np.float64)
+    if v["lowrank"]:
+        r = np.random.default_rng(sd + 5); x = r.standard_normal((n, 2)) @ r.standard_normal((2, d))
+    x = x + v["off"] * x.std(axis=0) * np.sign(np.random.default_rng(sd + 6).standard_normal(d))
+    return x.astype(dt)
 def worker(rank, world, port, out_dir, seed):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -29,9 +41,12 @@ def worker(rank, world, port, out_dir, seed):
         try:
             if kind.startswith("rpca"):
                 dt = np.float32 if kind.endswith("32") else np.float64
-                x = synth_pca(n, d, k, seed=sd, dtype=dt); xs = x[e[rank]:e[rank + 1]]
+                v = variant(sd)
+                x = rpca_data(synth_pca, n, d, k, sd, dt, v); xs = x[e[rank]:e[rank + 1]]
                 om = np.random.default_rng(sd + 1).standard_normal((d, k + 10)).astype(dt)
-                m = petal.RandomizedPca(k, ctx=ctx, n_iter=4); y = m.fit_transform(xs, omega=om)
+                ctx.set_option("eigh_jacobi", 2 if v["hook"] else 0)
+                m = petal.RandomizedPca(k, centering=v["cent"], ctx=ctx, n_iter=v["n_iter"]); y = m.fit_transform(xs, omega=om)
+                ctx.set_option("eigh_jacobi", 0)
                 res[f"{i}.comp"], res[f"{i}.sing"], res[f"{i}.y"] = m.components(), m.singular_values(), y
             elif kind == "pca64":
                 kk = min(k, 8)
@@ -69,8 +84,12 @@ if __name__ == "__main__":
                     print("ERR ", tag, errs); continue
                 if kind.startswith("rpca"):
                     dt = np.float32 if kind.endswith("32") else np.float64
-                    x = synth_pca(n, d, k, seed=sd, dtype=dt); om = np.random.default_rng(sd + 1).standard_normal((d, k + 10)).astype(dt)
-                    m = petal.RandomizedPca(k, ctx=ctx, n_iter=4); y = m.fit_transform(x, omega=om); comp, sing = m.components(), m.singular_values()
+                    v = variant(sd); tag += f" {v}"
+                    x = rpca_data(synth_pca, n, d, k, sd, dt, v); om = np.random.default_rng(sd + 1).standard_normal((d, k + 10)).astype(dt)
+                    ctx.set_option("eigh_jacobi", 2 if v["hook"] else 0)
+                    m = petal.RandomizedPca(k, centering=v["cent"], ctx=ctx, n_iter=v["n_iter"]); y = m.fit_transform(x, omega=om); comp, sing = m.components(), m.singular_values()
+                    ctx.set_option("eigh_jacobi", 0)
+                    tag += f" redo {ctx.stats()['rpca_redo']} eigh_redo {ctx.stats()['eigh_redo']}"
                     tol = 2e-4 if dt == np.float32 else 1e-8
                 elif kind == "pca64":
                     kk = min(k, 8); x = synth_pca(n, d, kk, seed=sd, dtype=np.float64)
