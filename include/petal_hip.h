@@ -30,7 +30,10 @@ extern "C" {
 
 typedef struct petal_ctx petal_ctx;
 
-/* DecompositionError (src/lib.rs:22-28) + a device/collective failure class. */
+/* DecompositionError (src/lib.rs:22-28) + a device/collective failure class.
+ * PETAL_LINALG_ERROR: where the crate's LAPACK calls report info != 0 (src/linalg.rs:58, 84, 115) -- in practice a NaN or an infinity in
+ * the input: petal_pca_fit / petal_rpca_fit return it with "did not converge", petal_fastica_fit with "cannot compute eigenvalues"
+ * (petal_last_error has the text); all-zero and constant matrices are legal inputs (zero singular values). */
 enum { PETAL_OK = 0, PETAL_INVALID_INPUT = 1, PETAL_LINALG_ERROR = 2, PETAL_DEVICE_ERROR = 3 };
 enum { PETAL_F32 = 0, PETAL_F64 = 1 };
 enum { PETAL_HOST = 0, PETAL_DEVICE = 1 };
