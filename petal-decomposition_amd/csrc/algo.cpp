@@ -650,9 +650,10 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     void* Ubuf = nullptr;        // ... and the buffer it goes to
     bool t_rt = false;           // T holds R in RT form (op_chol_rt), not the explicit inverse
     bool steered = false;        // fused / steering passes ran: the heavy-tail verdict prices their rounding too
+    int pipeline_runs = 0;       // (every run after the first clears the verdict words itself -- the re-based retry of an OPTIMISTIC run too)
     auto pipeline = [&](bool robust, bool exact) {
     const int planes = (n_iter > 0 && !robust && !exact) ? 2 : 3;
-    if (robust || exact) dev_memset(c.dev, tvp, 0, sizeof(double) * (3 + LP));  // tv, ndead, neig, lam (only lam[0 .. L) is written below); the first run's were cleared with Omega
+    if (pipeline_runs++ > 0) dev_memset(c.dev, tvp, 0, sizeof(double) * (3 + LP));  // tv, ndead, neig, lam (only lam[0 .. L) is written below); the first run's were cleared with Omega
     // The FUSED power-iteration pass Y' = Xc^T (Xc P) (one pass over X where K1 + K2 make two; it needs P on two planes, so it
     // belongs to the optimistic run): every product pair of the loop below, the last one also storing Z.
     const bool use_pow = planes == 2 && op_power_pass_applies(c.dev, dt, X.p, n, dp, X.ld, muT.p, LP);

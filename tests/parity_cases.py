@@ -443,6 +443,25 @@ def ica_parity(ctx, n, d, nc, seed, dtype=np.float32, tol_src=5e-3, n_components
     return dev
 
 
+def rebased_retry_case(ctx, expect_retry=None):
+    """UNCENTRED data 40 sigma off centre (3000 x 128, k = 30): from the random start the first product pair Xc^T (Xc Omega) is singular to
+    fp64 (sigma_1 / sigma_l ~ 1e5) and its Cholesky loses pivots.  Until round 6 that sent the fit to the robust pipeline, a different
+    iteration; now the same pipeline is tried again with the sketch re-based on the tall side (`rpca_redo` = 3) -- also when the first run was
+    the OPTIMISTIC one (its verdict words are cleared for the retry: the first version of the retry forgot, and fell through to the robust path).
+    The float32 oracle is 3e-4 ... 5e-4 off the fp64 one on this input; the re-based fit holds 7e-5 on the device (the apply Z T is an fp32
+    product that cancels five decades) and 7e-6 on the host simulation, the surviving un-rebased fit of the device's default mode 9e-5."""
+    n, d, k, n_iter = 3000, 128, 30, 5
+    x = po.synth_pca(n, d, k, seed=5, dtype=np.float64)
+    x = (x + 40.0 * x.std(axis=0) * np.sign(np.random.default_rng(7).standard_normal(d))).astype(np.float32)
+    # (where the first Gram matrix survives -- the device's default mode: the steering passes' own rounding noise lifts it above the
+    # pivot rule -- the un-rebased fit stands at ~1e-4, still 5 x closer to the fp64 answer than the float32 oracle)
+    rpca_parity(ctx, n, d, k, n_iter, seed=5, dtype=np.float32, tol=1e-4 if expect_retry else 2e-4, tol_sigma=5e-5, centering=False, x=x)
+    st = rpca_parity.last_fit_stats
+    assert st["rpca_redo"] != 2, st                      # never the robust pipeline on this full-rank input
+    if expect_retry is not None:
+        assert (st["rpca_redo"] == 3) == expect_retry, st
+
+
 def degenerate_input_case(ctx, n, d, dtype):
     """Inputs no factorisation exists for.  A NaN or an infinity anywhere in X: the crate's LAPACK calls come back with info != 0 and
     every fit returns `DecompositionError::LinalgError` (src/linalg.rs:58, 84, 115) -- so do these (round 6: exact Pca had returned

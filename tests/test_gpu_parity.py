@@ -168,6 +168,18 @@ def test_inputs_without_a_factorisation(ctx, dtype):
     pc.degenerate_input_case(ctx, 300, 24, dtype)
 
 
+def test_lost_pivot_retries_with_the_sketch_rebased(ctx):
+    """(on the device the default mode's steering passes may keep the first Gram matrix above the pivot rule -- their own rounding noise --
+    so only "never the robust pipeline" and the parity are asserted there; the exact-planes mode must take the retry)"""
+    pc.rebased_retry_case(ctx)
+    if ctx.gemm_mode_name == "bf16x3":
+        ctx.set_gemm_mode("bf16x3-exact")
+        try:
+            pc.rebased_retry_case(ctx, expect_retry=True)
+        finally:
+            ctx.set_gemm_mode("bf16x3")
+
+
 def test_two_plane_verdict_and_exact_redo():
     """(split-product mode only: the fp32-MFMA mode has no two-plane operands)"""
     import petal_decomposition_amd as petal

@@ -86,6 +86,15 @@ def test_inputs_without_a_factorisation(ctx, dtype):
     pc.degenerate_input_case(ctx, 500, 40, dtype)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+def test_lost_pivot_retries_with_the_sketch_rebased(ctx, mode):
+    ctx.set_gemm_mode(mode)
+    try:
+        pc.rebased_retry_case(ctx, expect_retry=True)
+    finally:
+        ctx.set_gemm_mode("fp32")
+
+
 def test_components_beyond_a_ring_slot(ctx):
     """k d esz above the 8 MiB ring slot (the single result view threw there): the components leave by their own
     copy.  k = 512, d = 2048 fp64 = 8 MiB + the small block."""
