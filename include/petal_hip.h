@@ -84,9 +84,9 @@ typedef struct petal_stats {
     /* RandomizedPca: how the last fit ran */
     int64_t rpca_redo;         /* 0: the optimistic run stood; 1: redone with three-plane operands (heavy-tailed spectrum: the
                                   16-bit rounding of the sketch matrix / iterates was not harmless); 3: redone with the sketch re-based on the
-                                  tall side before its product with Xc^T (fp32 data; a pivot was lost in the first run: on full-rank data
-                                  that is the un-rebased first product pair's, sigma_1 / sigma_l beyond ~5e3); 2: redone on the robust
-                                  path (a pivot lost again, or fp64 data: rank deficiency)                                        */
+                                  tall side before its product with Xc^T (a pivot was lost in the first run: on full-rank data that is
+                                  the un-rebased first product pair's, sigma_1 / sigma_l beyond ~5e3); 2: redone on the robust
+                                  path (a pivot lost again: rank deficiency)                                                       */
     double  pow_ms;            /* fused power-iteration pass Y' = Xc^T (Xc P) (one pass over X): summed kernel time           */
     int64_t pow_launches;
     double  stream_ms;         /* the other row-streaming kernels of a RandomizedPca fit (means pass, U = Z (T Uh)): with profiling at

@@ -896,13 +896,16 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
         std::memcpy(hdead, &keep[o_dead - o_tv], sizeof(hdead));
         double code = hdead[0] != 0 ? 3.0 : (hdead[1] != 0 ? 1.0 : (hdead[2] != 0 ? 2.0 : 0.0));
         if (sharded(c)) code = flip_slot_keys(c, dt) ? keep[o_flip - o_tv + 4 * kp] : agree_max(c, code);  // the agreed verdict
-        if (code >= 3.0 && !rebase_now && dt == F32 && n_iter >= 1) {
-            // A lost pivot on fp32 data is, on full-rank data, the FIRST product pair's: from a random start every column of Xc^T (Xc Omega)
+        if (code >= 3.0 && !rebase_now && n_iter >= 1) {
+            // A lost pivot is, on full-rank data, the FIRST product pair's: from a random start every column of Xc^T (Xc Omega)
             // is dominated by sigma_1, and beyond sigma_1 / sigma_l ~ 5e3 its Gram matrix is singular to fp64 (uncentred data far off
             // centre: the mean direction is sigma_1).  The robust path would answer with a different iteration (dependent columns dropped
             // and refilled): 1.9e-3 / 5e-4 off the oracle at n_iter 4 / 5 on such data, where the same pipeline with the sketch re-based
             // on the tall side first -- what short iterations do anyway, and the crate's first LU -- holds 1e-4 / 3e-5.  So that is
-            // tried first; rank-deficient data loses its pivot again and takes the robust path one run later.
+            // tried first; rank-deficient data loses its pivot again and takes the robust path one run later.  (fp64 data too: its first pair
+            // breaks down beyond sigma_1 / sigma_l ~ 5e3 all the same -- (sigma_1 / sigma_l)^4 against 1e-15 -- while the re-based sketch's
+            // tall-side Gram matrix holds to ~3e6; uncentred fp64 data 300 sigma off centre came back 1e-5 ... 1e-7 off at n_iter 1 - 3 on the
+            // robust path: dev/fuzz_hostsim6.py)
             rebase_now = true; jacobi = false; c.stats.rpca_redo = 3;
             continue;
         }

@@ -460,6 +460,13 @@ def rebased_retry_case(ctx, expect_retry=None):
     assert st["rpca_redo"] != 2, st                      # never the robust pipeline on this full-rank input
     if expect_retry is not None:
         assert (st["rpca_redo"] == 3) == expect_retry, st
+    # fp64 data takes the same retry (300 sigma off centre: its first pair breaks down beyond sigma_1 / sigma_l ~ 5e3 all the same); on the
+    # robust path this input came back 1e-5 / 8e-7 / 3e-9 off at n_iter 1 / 2 / 4
+    x64 = po.synth_pca(3000, 100, 43, seed=270, dtype=np.float64)
+    x64 = x64 + 300.0 * x64.std(axis=0) * np.sign(np.random.default_rng(270).standard_normal(100))
+    for it in (1, 4):
+        rpca_parity(ctx, 3000, 100, 43, it, seed=270, dtype=np.float64, tol=1e-9, centering=False, x=x64)
+        assert rpca_parity.last_fit_stats["rpca_redo"] == 3, rpca_parity.last_fit_stats
 
 
 def degenerate_input_case(ctx, n, d, dtype):
