@@ -524,9 +524,9 @@ def steering_passes(n, d, l, n_iter, mode, redo=0, world=1):
 
 
 def fused_launches(n_iter):
-    """fused passes per fit where the fused kernel runs: one per product pair, n_iter + 1 -- but n_iter at n_iter <= 3, whose first pair is
+    """fused passes per fit where the fused kernel runs: one per product pair, n_iter + 1 -- but n_iter at n_iter <= 4, whose first pair is
     K1, a re-basing of the sketch on the tall side, K2 (algo.cpp, `rebase_sketch`)"""
-    return n_iter + 1 if n_iter >= 4 else n_iter
+    return n_iter + 1 if n_iter >= 5 else n_iter
 
 
 def k3_pieces(n_iter, steering):

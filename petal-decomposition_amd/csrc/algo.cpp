@@ -584,9 +584,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // (From 200000 rows on: at configs[1]'s 100000 x 512 the matrix sits in the Infinity Cache, the means pass costs 37 us and what
     // replaces it -- the sample's means, the all-ones column and the squares in the first pass, the move to the true centre -- costs
     // the same; at 1e6 rows the pass is 0.33 ms of HBM time and the fold takes 5 % off the fit.)
-    // (fp32 data, up to three iterations: the sketch Z = Xc Omega is re-based on the tall side before its product with Xc^T -- see the
+    // (fp32 data, up to FOUR iterations: the sketch Z = Xc Omega is re-based on the tall side before its product with Xc^T -- see the
     // pipeline -- so the first product pair is not a fused pass and cannot gather the means)
-    const bool rebase_sketch = dt == F32 && n_iter >= 1 && n_iter <= 3;
+    const bool rebase_sketch = dt == F32 && n_iter >= 1 && n_iter <= 4;
     // (... and, at any n_iter, the second attempt of a fit whose first one lost a pivot: see the attempt loop)
     bool rebase_now = rebase_sketch;
     const double fold_rows = dev_option(c.dev, OPT_MEANS_FOLD_ROWS);   // (PETAL_OPT_MEANS_FOLD_ROWS; negative: never)
@@ -685,7 +685,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     op_gemm_xp(c.dev, dt, X.p, n, dp, X.ld, muT.p, P.f64(), LP, LP, nullptr, Z.p, LP, tv_from_sq ? nullptr : tvp, planes, steer);
     dev_set_tag(c.dev, TAG_NONE);
 
-    // A SHORT iteration (n_iter 1 - 3) on fp32 data re-bases the sketch Z = Xc Omega on the tall side first, as the crate does
+    // A SHORT iteration (n_iter 1 - 4) on fp32 data re-bases the sketch Z = Xc Omega on the tall side first, as the crate does
     // with its first LU (pca.rs:709).  Every column of Z is dominated by sigma_1, so the un-rebased double product Xc^T (Xc Omega)
     // carries direction j at (sigma_j / sigma_1)^2 of a column -- 1e-6 on the planted spectra -- under an fp32 accumulation that
     // is good to 6e-8 of it: the block's weakest directions come back 6 % junk, and with only one or two products behind it the
@@ -693,8 +693,9 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // column of Xc^T Q carries direction j at sigma_j / sigma_1.  Later products wash the junk out at the rate of the spectrum's
     // gaps: at n_iter = 3 it was gone for k = 64 of 512 features (3e-6) but NOT for 87 ... 126 components (1.5e-4 ... 3.6e-4
     // where the oracle run in float32 holds 1.4e-5 ... 8e-5: dev/fuzz_round6.py, round 6), so three iterations re-base too --
-    // only their first product pair: the later ones are fused / steering passes as for any n_iter >= 3.  From four iterations on
-    // the two extra passes over Z are not spent (2e-5 at k = 105).
+    // only their first product pair: the later ones are fused / steering passes as for any n_iter >= 3.  FOUR iterations likewise: a later
+    // seed of the same sweep had 60000 x 1024, k = 93, n_iter = 4 at 1.07e-4 against the float32 oracle's 1.0e-5.  From five iterations
+    // on the two extra passes over Z are not spent (no miss of this kind in ~400 random cases at n_iter 5 / 7 with up to 127 components).
     }
     const void* Zfirst = Z.p;   // what the first product with Xc^T reads
     if (rebase_now && !robust) {

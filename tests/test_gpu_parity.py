@@ -123,7 +123,7 @@ def test_three_iterations_with_many_components(ctx, n, d, k, before):
     """n_iter = 3 with 87 ... 126 components over the planted three decades (gaps of 2 - 3 % between neighbours): the junk the un-rebased
     first product pair Xc^T (Xc Omega) leaves in the block's weakest directions is NOT washed out by two more iterations at such gaps --
     dev/fuzz_round6.py (round 6) found these cases 3 - 10 x off the ORACLE RUN IN FLOAT32 (`before`: the round-5 and early round-6 errors, both
-    GEMM modes).  Three iterations therefore re-base the sketch on the tall side first, like n_iter 1 - 2 and like the crate's first LU
+    GEMM modes).  Three (and four: see the second test) iterations therefore re-base the sketch on the tall side first, like n_iter 1 - 2 and like the crate's first LU
     (src/pca.rs:709); the bar is dev/fuzz_rpca.py's, 3e-6 over the planted spectrum's relative gap."""
     tol = max(2e-5, 3e-6 / (1.0 - 10.0 ** (-3.0 / k)))
     assert before > tol
@@ -178,6 +178,12 @@ def test_lost_pivot_retries_with_the_sketch_rebased(ctx):
             pc.rebased_retry_case(ctx, expect_retry=True)
         finally:
             ctx.set_gemm_mode("bf16x3")
+
+
+def test_four_iterations_with_many_components(ctx):
+    """the same one iteration further out (dev/fuzz_round6.py 102 40): 60000 x 1024, k = 93, n_iter = 4 was 1.07e-4 off where the oracle in
+    float32 holds 1.0e-5; four-iteration fits re-base the sketch too"""
+    pc.rpca_parity(ctx, 60000, 1024, 93, 4, seed=8001, dtype=np.float32, tol=max(2e-5, 3e-6 / (1.0 - 10.0 ** (-3.0 / 93))), tol_sigma=5e-5)
 
 
 def test_two_plane_verdict_and_exact_redo():
