@@ -245,6 +245,8 @@ def main():
 
     if cfg["model"] == "ica":
         out = bench_fastica(args, cfg, petal, ctx, torch, dist, dev, rank, world, collective, sync_all)
+        if world > 1:
+            out["speedup_vs_one_gpu_same_matrix"] = None   # (a weak-scaling line: no same-matrix one-GPU fit in this job; the key is on every N > 1 line)
         if rank == 0:
             os.write(json_fd, (json.dumps(out) + "\n").encode())
         if dist is not None:
@@ -308,6 +310,9 @@ def main():
         except Exception as e:  # informational
             ranks_info = [me, {"error": repr(e)}]
 
+    # (the chain's extra fits are SHARDED fits where world > 1 -- a weak-scaling run, `--config cfg2 / cfg4 --gpus N`: every rank has to run
+    # them, not rank 0 alone beside ranks already waiting at the last barrier; round 6)
+    chain = serial_chain(ctx, model, x, omega, elapsed / args.steps * 1e3) if (not strong or world == 1) else None
     out = None
     if rank == 0:
         # dominant kernel = the power-iteration GEMM kind with the larger summed time
@@ -358,8 +363,8 @@ def main():
                                  "algorithmic_bytes": 4.0 * (n * d + 2 * d * l), "GB/s_algorithmic": round(4.0 * (n * d + 2 * d * l) / (v * 1e-3) / 1e9, 1),
                                  "note": "Y' = Xc^T (Xc P): both products of a power iteration in one pass, X read ONCE, Z neither written "
                                          "nor read (the last pass of a fit also stores Z)"}
-        if not strong or world == 1:
-            out["serial_chain"] = serial_chain(ctx, model, x, omega, elapsed / args.steps * 1e3)
+        if chain is not None:
+            out["serial_chain"] = chain
             if cfg["model"] == "rpca" and world == 1:
                 out["predicted_scaling"] = predicted_scaling(out["ms_per_step"], out["serial_chain"], n_iter, d, l, strong)
         if world == 1 and x_host is not None:

@@ -162,6 +162,17 @@ def test_self_launch_single_gpu_without_launcher_variables():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config", ["cfg2", "cfg5"])
+def test_weak_scaling_line_with_two_ranks_sharing_the_gpu(config):
+    """`--config cfg2 / cfg5 --gpus 2`: per-GPU workloads (weak scaling).  The replicated-chain measurement behind `serial_chain` is a few more
+    SHARDED fits: until round 6 rank 0 ran them alone, beside ranks already waiting at the last barrier -- a hung job."""
+    rec = _run("--config", config, "--gpus", "2", "--share-gpu", "--no-cpu-baseline", launcher_env=False, n_gpus=2)
+    assert rec["scaling"] == "weak" and rec["config"]["parallelism"] == "sample-sharded x2" and "speedup_vs_one_gpu_same_matrix" in rec
+    if config == "cfg2":
+        assert rec["serial_chain"]["serial_chain_ms"] > 0 and rec["collective"]["allreduce_calls_per_fit"] == 5 + 3
+
+
+@pytest.mark.gpu
 def test_self_launch_two_ranks_sharing_the_gpu():
     """The launcher path end to end with N = 2 on the one-GPU box: bench.py starts two rank processes itself (fresh children,
     before any GPU call), they share GPU 0 and all-reduce over gloo; rank 0 prints the one record with n_gpus = 2."""
