@@ -695,7 +695,7 @@ void rpca_fit(petal_ctx& c, const petal_matrix& x, int64_t k, int64_t n_oversamp
     // where the oracle run in float32 holds 1.4e-5 ... 8e-5: dev/fuzz_round6.py, round 6), so three iterations re-base too --
     // only their first product pair: the later ones are fused / steering passes as for any n_iter >= 3.  FOUR iterations likewise: a later
     // seed of the same sweep had 60000 x 1024, k = 93, n_iter = 4 at 1.07e-4 against the float32 oracle's 1.0e-5.  From five iterations
-    // on the two extra passes over Z are not spent (no miss of this kind in ~400 random cases at n_iter 5 / 7 with up to 127 components).
+    // on the two extra passes over Z are not spent (no miss of this kind in ~220 random cases at n_iter 5 / 7 with up to 127 components, 425 in all).
     }
     const void* Zfirst = Z.p;   // what the first product with Xc^T reads
     if (rebase_now && !robust) {
